@@ -1,0 +1,159 @@
+/*
+ * mca_oracle.h -- CPU restatement (double precision, plain C) of the mcarray
+ * per-frame localisation + beamforming hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke()
+ * check in __graft_entry__.py and bench.py's cpu_baseline leg may load it.
+ * The product path (libmcarray_hip.so) never links or calls anything here.
+ *
+ * PARITY STATUS: "parity unpinned" against an executed reference.  The
+ * reference (jordi-adell/mcarray) cannot be compiled in this image: its
+ * arithmetic lives in the un-vendored WIPP and DSPONE libraries (unpinned
+ * Debian packages libwipp-dev / libdspone-dev, .travis.yml:11,21-22) and it
+ * needs boost, fftw3, libsndfile and gtest, none of which are present.  The
+ * oracle is therefore pinned only by what the reference's own tests hold for
+ * this path: the ArrayDescription known-answer table
+ * (test/test_mcarray.cpp:518-580), the +-7 degree SRP property (:390,:417),
+ * the >=5.5 dB delay-and-sum property (:640-656,:757,:785) and the masking
+ * dB windows (:943-956, :1039-1064).  tests/test_oracle_reference_properties.py
+ * checks all of them.  Everything marked [BUILD-DEFINES] below is a decision
+ * this build owns because the deciding code is inside DSPONE/WIPP.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference root).
+ */
+#ifndef MCA_ORACLE_H
+#define MCA_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- helpers: src/mcarray/microhponeArrayHelpers.cpp ------------------- */
+double mca_or_speed_of_sound(void);                               /* :38-43  */
+float  mca_or_doa_to_delay_far_field(float doa, float microDist); /* :46-67  */
+float  mca_or_doa_to_delay_samples(float doa, float microDist, int fs); /* :69-72 */
+float  mca_or_angle2doaidx(float angle, float step);              /* :110-115 */
+float  mca_or_doaidx2angle(int idx, float step);                  /* :117-120 */
+float  mca_or_doa_step(double step_deg);  /* float(step_deg*M_PI/180), SteeringBeamforming.cpp:39 */
+int    mca_or_num_steps(float step);      /* round(M_PI/step)+1, SteeringBeamforming.cpp:40 */
+
+/* ---- geometry: src/mcarray/ArrayDescription.cpp ------------------------ */
+double mca_or_distance(const double *xyz, int i, int j);          /* :57-64  */
+double mca_or_max_distance(const double *xyz, int M);             /* :77-91  */
+double mca_or_min_distance(const double *xyz, int M);             /* :93-107 (always 0: quirk kept) */
+double mca_or_bandwidth(const double *xyz, int M);                /* :294-301 */
+
+/* ---- STFT engine [BUILD-DEFINES, DSPONE absent]: SURVEY A.1 ------------ */
+int  mca_or_order_from_sample_rate(int fs, double frame_seconds);
+void mca_or_hann_periodic(double *w, int N);
+/* x[N] real -> ccs[N+2] (bin k at ccs[2k],ccs[2k+1]); unnormalised forward */
+void mca_or_rfft_ccs(const double *x, int N, double *ccs);
+/* ccs[N+2] -> x[N], 1/N inverse */
+void mca_or_irfft_ccs(const double *ccs, int N, double *x);
+/* windowed analysis of frame t of one channel: x points at sample t*hop */
+void mca_or_stft_frame(const double *x, const double *win, int N, double *ccs);
+
+/* ---- power: dsp::SignalPower [INFERRED], SURVEY A.8 -------------------- */
+double mca_or_fft_power(const double *const *frames, int M, int ccs_len);
+double mca_or_fft_log_power(const double *const *frames, int M, int ccs_len);
+double mca_or_log_power(const double *x, int n);
+
+/* ---- GCC-PHAT at steering delays: dsp::GeneralisedCrossCorrelation ------
+ * [INFERRED] SURVEY A.3; call sites SteeringBeamforming.cpp:84-88,115-119,
+ * BinauralLocalisation.cpp:371,438-442. T is D*K complex (re,im interleaved). */
+void mca_or_precompute_tau_matrix(const double *tau, int D, int K, double *T);
+void mca_or_gcc_phat_tau_matrix(const double *A, const double *B, const double *T,
+                                int K, int D, double *out_complex);
+
+/* ---- SteeringBeamforming: src/mcarray/SteeringBeamforming.cpp ---------- */
+typedef struct mca_or_steering mca_or_steering;
+mca_or_steering *mca_or_steering_create(int fs, const double *xyz, int M,
+                                        int fft_ccs_length, double doa_step_deg); /* :34-94 */
+void mca_or_steering_destroy(mca_or_steering *s);
+int  mca_or_steering_num_steps(const mca_or_steering *s);
+int  mca_or_steering_num_pairs(const mca_or_steering *s);
+const double *mca_or_steering_delays(const mca_or_steering *s, int pair);  /* D delays */
+/* processFrame :96-102.  frames[M] -> ccs double[fft_ccs_length].
+ * DOA[S] in radians, prob[S]; doa_bin[S] = idx+1 (the "DOA bin" of SURVEY A.5);
+ * energy_out (may be NULL) receives the un-normalised smoothed E_t[D];
+ * corr_out (may be NULL) receives C_t[d] = sum_p R_p[d] (un-scaled). */
+void mca_or_steering_process_frame(mca_or_steering *s, const double *const *frames,
+                                   double *DOA, double *prob, int *doa_bin, int n_sources,
+                                   double *energy_out, double *corr_out);
+void mca_or_steering_reset(mca_or_steering *s);
+/* selectDOA alone (:146-195) on a given un-normalised energy vector */
+void mca_or_select_doa(const double *E, int D, int n_pairs, float step, int n_sources,
+                       double *DOA, double *prob, int *doa_bin);
+
+/* ---- Beamformer: src/mcarray/Beamformer.cpp:51-71 ---------------------- */
+void mca_or_beamformer_process_frame(int fs, const double *xyz, int M, int fft_ccs_length,
+                                     const double *const *frames, double *out, double DOA);
+
+/* ---- BeamformingSeparationAndLocalisation:
+ *      src/mcarray/BeamformingSeparationAndLocalisation.cpp:29-119 -------- */
+typedef struct mca_or_bsl mca_or_bsl;
+mca_or_bsl *mca_or_bsl_create(int fs, int fft_ccs_length, const double *xyz, int M,
+                              int n_sources, int use_power_floor, double doa_step_deg);
+void mca_or_bsl_destroy(mca_or_bsl *b);
+/* returns 1 if the frame passed the gate (callback would fire), else 0.
+ * doa_deg[S], prob[S], *power as handed to LocalisationCallback::setDOA (:93) */
+int  mca_or_bsl_localise(mca_or_bsl *b, const double *const *frames,
+                         double *doa_deg, double *prob, double *power);
+/* processFrameSeparation :103-119 ; frames are modified in place like the
+ * hook at SourceSeparationAndLocalisation.cpp:92 */
+void mca_or_bsl_separate(mca_or_bsl *b, double *const *frames);
+const double *mca_or_bsl_current_doa(const mca_or_bsl *b);
+const int    *mca_or_bsl_current_bin(const mca_or_bsl *b);
+
+/* ---- whole stream: SourceSeparationAndLocalisation driven by the
+ *      [BUILD-DEFINES] STFT engine: analysis Hann(periodic),
+ *      hop N/2, plain overlap-add synthesis.
+ * pcm: M channels, channel c at pcm + c*stride, (F+1)*hop samples each.
+ * doa_bin[F*S], prob[F*S], out_pcm[S][F*hop] (channel s at out + s*F*hop),
+ * energy_map (may be NULL) [F][D].                                        */
+void mca_or_ssl_stream(int fs, int N, const double *xyz, int M, int n_sources,
+                       double doa_step_deg, const double *pcm, long stride, int F,
+                       int *doa_bin, double *doa_rad, double *prob, double *out_pcm,
+                       double *energy_map);
+
+/* ---- FreqGCCBinauralLocalisation: src/mcarray/BinauralLocalisation.cpp:320-631
+ * deterministic part only: smoothed corr, argmax, setProbability */
+typedef struct mca_or_freqgcc mca_or_freqgcc;
+mca_or_freqgcc *mca_or_freqgcc_create(int fs, const double *xyz, int M, int fft_ccs_length,
+                                      int use_power_floor, double doa_step_deg);
+void mca_or_freqgcc_destroy(mca_or_freqgcc *g);
+int  mca_or_freqgcc_num_steps(const mca_or_freqgcc *g);
+/* returns 1 if voiced (gate passed). corr_out[D] smoothed correlation,
+ * *argmax_idx first-max index, *doa_rad smoothed DOA (the #else branch :502-504) */
+int  mca_or_freqgcc_process(mca_or_freqgcc *g, const double *left, const double *right,
+                            double *corr_out, int *argmax_idx, double *doa_rad, double *power);
+void mca_or_freqgcc_set_probability(const mca_or_freqgcc *g, const double *doas,
+                                    double *probs, int size);     /* :569-631 */
+
+/* ---- FastBinauralMasking: src/mcarray/FastBinauralMasking.cpp:51-538 --- */
+enum { MCA_OR_FACTOR = 0, MCA_OR_RELATIVE = 1, MCA_OR_FULL = 3, MCA_OR_NOISY = 4, MCA_OR_NOTHING = 5 };
+enum { MCA_OR_BOTH = 0, MCA_OR_SPATIAL = 1, MCA_OR_TEMPORAL = 2 };
+typedef struct mca_or_masking mca_or_masking;
+mca_or_masking *mca_or_masking_create(int fs, int N, double micro_distance, float low_freq,
+                                      float high_freq, int method, int algorithm);
+void mca_or_masking_destroy(mca_or_masking *m);
+int  mca_or_masking_nbins(void);
+const double *mca_or_masking_thresholds(const mca_or_masking *m);   /* 45 */
+const double *mca_or_masking_filters(const mca_or_masking *m);      /* 45*K reals */
+const double *mca_or_masking_center_freqs(const mca_or_masking *m); /* 45, cycles/sample */
+const double *mca_or_masking_short_time_power(const mca_or_masking *m);
+/* processParametrisation :126-210 : left/right ccs double[N+2] in place.
+ * decisions (may be NULL) [45]: 0 enhance, 1 temporal mask, 2 spatial mask */
+void mca_or_masking_process(mca_or_masking *m, double *left, double *right, int *decisions);
+/* whole 2-channel stream through the [BUILD-DEFINES] STFT engine */
+void mca_or_masking_stream(mca_or_masking *m, const double *pcm_l, const double *pcm_r, int F,
+                           double *out_l, double *out_r);
+/* mel filter bank [BUILD-DEFINES] stand-in for dsp::FilterBankFFTWMelScale */
+void mca_or_mel_filterbank(int N, int nbins, int fs, double fmin, double fmax,
+                           double *coefs /* nbins*K */, double *center_cyc /* nbins */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,291 @@
+"""numpy twin of the C oracle (oracle/mca_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  An independent, vectorised restatement of the same
+spec used to cross-check the C oracle in the CPU test suite
+and to emit the golden fixtures under tests/golden/ (tests/golden/make_golden.py).
+It is never imported by the product package.  "parity unpinned" against an
+executed reference (see mca_oracle.h).
+"""
+import numpy as np
+
+C_SOUND = 346.1  # microhponeArrayHelpers.cpp:42
+f32 = np.float32
+
+
+def doa_step(step_deg):
+    return f32(step_deg * np.pi / 180.0)  # SteeringBeamforming.cpp:39
+
+
+def num_steps(step):
+    return int(np.round(np.pi / float(step)) + 1)  # :40  (C round() = half away from zero; ties do not occur)
+
+
+def doaidx2angle(idx, step):
+    # microhponeArrayHelpers.cpp:117-120 : float product, double subtraction, float return
+    prod = f32(idx) * f32(step)
+    return f32(np.float64(prod) - np.pi / 2)
+
+
+def delay_samples(doa, dist, fs):
+    # :46-72 : (float dist * sin(float doa) in double) / 346.1 -> float ; * fs in float
+    d = f32(np.float64(f32(dist)) * np.sin(np.float64(f32(doa))) / C_SOUND)
+    return f32(d * f32(fs))
+
+
+def pair_list(M):
+    return [(i, j) for i in range(M) for j in range(i + 1, M)]
+
+
+def xyz_of(x):
+    a = np.asarray(x, dtype=np.float64)
+    if a.ndim == 1:
+        a = np.stack([a, np.zeros_like(a), np.zeros_like(a)], axis=1)
+    return a
+
+
+def distance(xyz, i, j):
+    d = xyz[j] - xyz[i]
+    return float(np.sqrt(d[0] ** 2 + d[1] ** 2 + d[2] ** 2))
+
+
+def delay_table(fs, xyz, step_deg):
+    """[P][D] float64 holding the float delays of generateLookupTable (:58-94)."""
+    xyz = xyz_of(xyz)
+    step = doa_step(step_deg)
+    D = num_steps(step)
+    pairs = pair_list(len(xyz))
+    tab = np.empty((len(pairs), D))
+    for p, (i, j) in enumerate(pairs):
+        dist = distance(xyz, i, j)
+        for d in range(D):
+            tab[p, d] = float(delay_samples(doaidx2angle(d, step), dist, fs))
+    return tab
+
+
+def hann(N):
+    return 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / N)
+
+
+def to_c(ccs):
+    """CCS double[..., N+2] -> complex[..., K]"""
+    return ccs[..., 0::2] + 1j * ccs[..., 1::2]
+
+
+def to_ccs(X):
+    out = np.empty(X.shape[:-1] + (2 * X.shape[-1],))
+    out[..., 0::2] = X.real
+    out[..., 1::2] = X.imag
+    return out
+
+
+def stft_frames(pcm, N):
+    """[M][(F+1)*hop] -> complex [F][M][K]"""
+    pcm = np.asarray(pcm, dtype=np.float64)
+    hop = N // 2
+    F = pcm.shape[1] // hop - 1
+    w = hann(N)
+    idx = np.arange(N)[None, :] + hop * np.arange(F)[:, None]
+    fr = pcm[:, idx] * w  # [M][F][N]
+    return np.fft.rfft(fr, axis=-1).transpose(1, 0, 2)
+
+
+def gcc_phat(A, B, tau, K):
+    """R[d] = Re sum_k Ghat[k] exp(+j 2 pi k tau_d / N)  """
+    G = A * np.conj(B)
+    mag = np.maximum(np.abs(G), 1e-30)
+    Gh = G / mag
+    N = 2 * (K - 1)
+    ph = 2 * np.pi * np.outer(tau, np.arange(K)) / N
+    return (Gh[None, :] * np.exp(1j * ph)).sum(axis=1)
+
+
+def srp_map(X, delays):
+    """X complex [M][K]; delays [P][D] -> per-pair R [P][D] (real)."""
+    M, K = X.shape
+    pairs = pair_list(M)
+    R = np.empty((len(pairs), delays.shape[1]))
+    for p, (i, j) in enumerate(pairs):
+        R[p] = gcc_phat(X[i], X[j], delays[p], K).real
+    return R
+
+
+MU = float(f32(0.8))
+ONE_MINUS_MU = float(f32(1) - f32(0.8))
+
+
+def energy_update(E_prev, R):
+    """computeEnergyInDOA :132-144 (summation order p = 0..P-1)."""
+    E = MU * E_prev
+    for p in range(R.shape[0]):
+        E = E + ONE_MINUS_MU * R[p]
+    return E
+
+
+def median3(x):
+    xp = np.concatenate([x[:1], x, x[-1:]])
+    return np.median(np.stack([xp[:-2], xp[1:-1], xp[2:]]), axis=0)
+
+
+def select_doa(E, n_pairs, step, n_sources=1):
+    """selectDOA :146-195. returns (doa[S], prob[S], bin[S])"""
+    mn = -15.0 * n_pairs
+    En = (E - mn) / (-2 * mn)
+    fd = En[1:] - En[:-1]
+    fd = np.where(fd < 0, 1.0, np.where(fd > 0, 0.0, fd))
+    fd = median3(fd)
+    sd = (fd[1:] - fd[:-1]) * En[1:-1]
+    doa, prob, bins = [], [], []
+    for _ in range(n_sources):
+        idx = int(np.argmax(sd))  # first max
+        prob.append(sd[idx])
+        sd[idx] = 0
+        bins.append(idx + 1)
+        doa.append(float(doaidx2angle(idx + 1, step)))
+    return np.array(doa), np.array(prob), np.array(bins, dtype=np.int32)
+
+
+def beamformer(fs, xyz, X, doa):
+    """Beamformer::processFrame (Beamformer.cpp:51-71). X complex [M][K] -> complex [K]"""
+    xyz = xyz_of(xyz)
+    M, K = X.shape
+    N = 2 * (K - 1)
+    k = np.arange(K)
+    out = np.zeros(K, dtype=complex)
+    for c in range(M):
+        slope = 2 * np.pi * fs / N / C_SOUND * xyz[c, 0] * np.cos(doa + np.pi / 2)
+        out += X[c] * np.exp(1j * slope * k)
+    return out / M
+
+
+def irfft_ccs(Y, N):
+    Y = Y.copy()
+    Y[..., 0] = Y[..., 0].real
+    Y[..., -1] = Y[..., -1].real
+    return np.fft.irfft(Y, n=N, axis=-1)
+
+
+def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0):
+    xyz = xyz_of(xyz)
+    M = len(xyz)
+    hop = N // 2
+    X = stft_frames(pcm, N)
+    F = X.shape[0]
+    step = doa_step(step_deg)
+    delays = delay_table(fs, xyz, step_deg)
+    D = delays.shape[1]
+    P = delays.shape[0]
+    E = np.zeros(D)
+    bins = np.empty((F, n_sources), dtype=np.int32)
+    doas = np.empty((F, n_sources))
+    probs = np.empty((F, n_sources))
+    emap = np.empty((F, D))
+    nout = min(M, n_sources)
+    out = np.zeros((nout, F * hop))
+    tail = np.zeros((nout, hop))
+    for t in range(F):
+        R = srp_map(X[t], delays)
+        E = energy_update(E, R)
+        emap[t] = E
+        doas[t], probs[t], bins[t] = select_doa(E.copy(), P, step, n_sources)
+        for s in range(nout):
+            y = irfft_ccs(beamformer(fs, xyz, X[t], doas[t, s]), N)
+            out[s, t * hop:(t + 1) * hop] = tail[s] + y[:hop]
+            tail[s] = y[hop:]
+    return dict(bin=bins, doa=doas, prob=probs, out=out, energy=emap)
+
+
+# ---- masking -------------------------------------------------
+def hz2mel(f):
+    return 2595.0 * np.log10(1.0 + f / 700.0)
+
+
+def mel2hz(m):
+    return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+
+
+def mel_filterbank(N, nbins, fs, fmin, fmax):
+    K = N // 2 + 1
+    edges = mel2hz(hz2mel(fmin) + (hz2mel(fmax) - hz2mel(fmin)) * np.arange(nbins + 2) / (nbins + 1))
+    f = np.arange(K) * fs / N
+    H = np.zeros((nbins, K))
+    for b in range(nbins):
+        f0, f1, f2 = edges[b], edges[b + 1], edges[b + 2]
+        up = (f > f0) & (f <= f1)
+        dn = (f > f1) & (f < f2)
+        H[b, up] = (f[up] - f0) / (f1 - f0)
+        H[b, dn] = (f2 - f[dn]) / (f2 - f1)
+    return H, edges[1:-1] / fs
+
+
+class Masking:
+    LAM = float(f32(0.04))
+    ONE_MINUS_LAM = float(f32(1) - f32(0.04))
+    REJECT = float(f32(0.999))
+    RHO = float(f32(0.01))
+
+    def __init__(self, fs, N, d, flo, fhi, method=1, alg=0):
+        self.fs, self.N, self.K = fs, N, N // 2 + 1
+        self.method, self.alg = method, alg
+        self.H, self.center = mel_filterbank(N, 45, fs, float(f32(flo)), float(f32(fhi)))
+        self.thr = np.cos(self.center * fs * 2 * np.pi * d * np.sin(10 * np.pi / 180) / C_SOUND)
+        self.Q = np.zeros(45)
+        self.noise = np.zeros(45)
+        self.first = 0
+
+    def _mask(self, F, b, factor):
+        Kh = self.N // 2  # "first N doubles" = N/2 complex bins
+        if self.method == 3:
+            F[:Kh] /= 1000
+        elif self.method == 1:
+            f = np.mean(np.abs(F) ** 2) * self.RHO
+            f = self.RHO if self.Q[b] < 1e-10 else f / self.Q[b]
+            F[:Kh] *= np.sqrt(f)
+        elif self.method == 0:
+            F[:Kh] /= factor
+        elif self.method == 4:
+            pw = np.sqrt(np.mean(np.abs(F[:Kh]) ** 2))
+            f = self.noise[b] / pw if pw > 0 else 1.0
+            if self.first >= 2:
+                F[:Kh] *= f
+        return F
+
+    def process(self, L, R):
+        """L, R complex [K] -> (outL, outR, decisions[45])"""
+        if self.method == 5:
+            return L, R, np.zeros(45, dtype=np.int32)
+        Kh = self.N // 2
+        oL = np.zeros(self.K, dtype=complex)
+        oR = np.zeros(self.K, dtype=complex)
+        dec = np.zeros(45, dtype=np.int32)
+        for b in range(45):
+            Lb = L * self.H[b]
+            Rb = R * self.H[b]
+            mix = Lb[:Kh] / 2 + Rb[:Kh] / 2
+            P = np.sqrt(np.mean(np.abs(mix) ** 2))
+            self.Q[b] = self.Q[b] * self.LAM + self.ONE_MINUS_LAM * P
+            temp = P < self.REJECT * self.Q[b]
+            spat = False
+            if self.alg in (0, 1):
+                num = np.mean((np.conj(Lb) * Rb).real)
+                if num == 0:
+                    nc = 0.0
+                else:
+                    den = np.sqrt(np.mean(np.abs(Lb) ** 2) * np.mean(np.abs(Rb) ** 2))
+                    nc = 1.0 if den == 0 else num / den
+                spat = nc < self.thr[b]
+                if self.alg == 1:
+                    temp = False
+            if spat:
+                Lb = self._mask(Lb, b, 10.0)
+                Rb = self._mask(Rb, b, 10.0)
+                dec[b] = 2
+            elif temp:
+                Lb = self._mask(Lb, b, 3.0)
+                Rb = self._mask(Rb, b, 3.0)
+                dec[b] = 1
+            oL += Lb
+            oR += Rb
+        self.first += 1
+        if self.first < 2:
+            self.noise = self.Q.copy()
+        return oL, oR, dec

@@ -1,0 +1,150 @@
+"""Pins the CPU oracle to every known answer / property the reference's own tests hold
+for the hot path.  CPU only.
+
+* ArrayDescription known-answer table  -- test/test_mcarray.cpp:518-580
+* SRP-PHAT DOA within +-7 deg on 1 kHz sines, 4-mic Reem-C, -80..80 deg -- :384-423
+* delay-and-sum inter-source attenuation >= 5.5 dB, 3 two-tone scenes    -- :631-800
+* masking band-power windows 70+-10 dB, 2+-0.5 dB -> 5+-1 dB              -- :892-1065
+"""
+import numpy as np
+import pytest
+from scipy import signal
+
+from mcarray_amd import synth
+from oracle import pyoracle as po
+
+
+def test_array_description_known_answers():
+    # test/test_mcarray.cpp:524-578
+    xyz = np.array([[0.0, 2, 3], [0.035 * 2, 2, 3], [0.035 * 5, 2, 3], [0.035 * 6, 2, 3]])
+    expect = [[0.000, 0.070, 0.175, 0.210],
+              [0.070, 0.000, 0.105, 0.140],
+              [0.175, 0.105, 0.000, 0.035],
+              [0.210, 0.140, 0.035, 0.000]]
+    for i in range(4):
+        for j in range(4):
+            # EXPECT_DOUBLE_EQ = within 4 ulp
+            assert po.distance(xyz, i, j) == pytest.approx(expect[i][j], rel=0, abs=4 * np.spacing(0.21))
+    assert po.max_distance(xyz) == pytest.approx(0.210, abs=4 * np.spacing(0.21))
+
+
+def test_grid_sizes():
+    # SteeringBeamforming.cpp:39-40 (5 deg -> 37), BinauralLocalisation.cpp:328-329 (3 deg -> 61)
+    assert po.num_steps(5.0) == 37
+    assert po.num_steps(3.0) == 61
+    assert po.num_steps(0.5) == 361
+    assert po.doaidx2angle(18, 5.0) == pytest.approx(0.0, abs=1e-6)
+    assert po.doaidx2angle(0, 5.0) == pytest.approx(-np.pi / 2, abs=1e-6)
+
+
+@pytest.mark.parametrize("doa_deg", list(range(-80, 81, 10)))
+def test_srp_doa_within_7_degrees(doa_deg):
+    # testBeamformingSoundLocalisation: 4-mic Reem-C, @48 kHz, 1 source, no power floor, tolerance 7 degrees,
+    # DOA -80..80 step 10 (test/test_mcarray.cpp:387-417).  N from calculateOrderFromSampleRate(48000, 0.025).
+    # The reference reads 1 kHz sine recordings that are not in its tree, and its core never feeds data
+    # (test/test_mcarray.cpp:611), so that test never ran.  A noiseless pure tone carries one coherent phase
+    # in every bin, which PHAT weighting (north_star: GCC-PHAT) cannot localise -- for ANY implementation --
+    # so the property is checked on a far-field broadband source from the same angles and geometry.
+    fs = 48000
+    N = 1 << 10
+    assert po.lib().mca_or_order_from_sample_rate(fs, 0.025) == 10
+    F = 12
+    pcm = synth.noise_source_stream(synth.REEM_C, np.deg2rad(doa_deg), fs, (F + 1) * N // 2, seed=doa_deg + 1000)
+    r = po.ssl_stream(fs, N, synth.REEM_C, pcm.astype(np.float64), 1, 5.0, want_audio=False)
+    deg = np.rad2deg(r["doa"][:, 0])
+    assert np.all(np.abs(deg - doa_deg) <= 7.0), deg
+
+
+SCENES = [  # test/test_mcarray.cpp:640-656
+    (800.0, 45.0, 2000.0, -45.0),
+    (1000.0, 20.0, 4000.0, -20.0),
+    (1000.0, 80.0, 1500.0, 10.0),
+]
+
+
+@pytest.mark.parametrize("f1,d1,f2,d2", SCENES)
+def test_delay_and_sum_attenuation(f1, d1, f2, d2):
+    # dead test testBeamformingSeparation (test/test_mcarray.cpp:631-800): Reem-C, fs 48 kHz, N = 2048,
+    # spectral peak = max |X| over bins floor(f/fs*N)-4 .. +3 (:727-729); attenuation >= 5.5 dB (:757,:785)
+    fs, N = 48000, 2048
+    xs = synth.REEM_C
+    x = (synth.sine_stream(xs, np.deg2rad(d1), fs, N, f1, amplitude=5000.0)
+         + synth.sine_stream(xs, np.deg2rad(d2), fs, N, f2, amplitude=5000.0))
+    frames = np.stack([po.rfft_ccs(x[c]) for c in range(4)])
+
+    def peak(ccs, f):
+        mag = np.hypot(ccs[0::2], ccs[1::2])
+        b = int(f / fs * N)
+        return mag[b - 4:b + 4].max()
+
+    in1 = np.mean([peak(frames[c], f1) for c in range(4)])
+    in2 = np.mean([peak(frames[c], f2) for c in range(4)])
+    out = po.beamformer_process_frame(fs, xs, frames, np.deg2rad(d1))
+    att1 = 20 * np.log10((peak(out, f1) / in1) / (peak(out, f2) / in2))
+    out = po.beamformer_process_frame(fs, xs, frames, np.deg2rad(d2))
+    att2 = 20 * np.log10((peak(out, f2) / in2) / (peak(out, f1) / in1))
+    assert att1 >= 5.5 and att2 >= 5.5, (att1, att2)
+
+
+def _bandpass(lo, hi):
+    # dsp::BandPassFIRFilter(256, lo, hi) stand-in [BUILD-DEFINES]: firwin(257), frequencies in cycles/sample
+    return signal.firwin(257, [lo, hi], pass_zero=False, fs=1.0)
+
+
+def test_spatial_masking_power_windows():
+    # testSpatialMaskingCore (test/test_mcarray.cpp:892-958); FastBinauralMasking(16000, 0.086, 500, 5000, FULL)
+    fs, N = 16000, 1024
+    n = 5 * 1024
+    magn, delay = 5000, 6
+    interest = synth.tone16(n, magn, 0.1).astype(np.float64)
+    interf_l = synth.tone16(n, magn, 0.3).astype(np.float64)
+    interf_r = np.zeros(n)
+    interf_r[:n - delay] = interf_l[delay:]
+    L = interest + interf_l
+    R = interest + interf_r
+    m = po.Masking(fs, N, 0.086, 500, 5000, po.FULL, po.BOTH)
+    ol, orr = m.stream(L, R)
+    sigf = _bandpass(0.05, 0.15)
+    intf = _bandpass(0.25, 0.35)
+    p_sig = po.log_power(signal.lfilter(sigf, 1.0, ol))
+    p_int = po.log_power(signal.lfilter(intf, 1.0, ol))
+    assert abs(70 - p_sig) <= 10   # :943
+    assert abs(70 - p_int) <= 10   # :956 (passes although the interferer is not attenuated, as in the reference)
+
+
+def test_temporal_masking_power_windows():
+    # testTemporalMaskingCore (test/test_mcarray.cpp:960-1065)
+    fs, N = 16000, 1024
+    magn = 5000
+    delay = int(0.1 * fs)
+    tonestep = int(0.1 * fs)
+    freqstep = np.float32(0.01)
+    n = 50 * 1024
+    tone = np.zeros(n)
+    i, sfreq, interest_start = 0, np.float32(0.01), 0
+    interest_freq = np.float32(0.2)
+    while i < n - tonestep and sfreq < 0.5:
+        if interest_freq - freqstep / 2 < sfreq < interest_freq + freqstep / 2:
+            interest_start = i
+        tone[i:i + tonestep] = synth.tone16(tonestep, magn, float(sfreq))
+        i += tonestep
+        sfreq = np.float32(sfreq + freqstep)
+    sig = np.zeros(n)
+    tb = tone.copy()
+    for k in range(6):                      # i = 0..nreverb (:1014-1018), int16 halving
+        tb = np.trunc(tb / 2)
+        sig[delay * k:] += tb[:n - delay * k]
+    m = po.Masking(fs, N, 0.086, 500, 5000, po.FULL, po.BOTH)
+    ol, orr = m.stream(sig, sig)
+    out_len = len(ol)
+    sigf = _bandpass(0.19, 0.21)
+    intf = _bandpass(0.15, 0.20)
+    sl = slice(interest_start, interest_start + tonestep)
+
+    def diff(x):
+        return po.log_power(signal.lfilter(sigf, 1.0, x[:out_len])[sl]) - po.log_power(signal.lfilter(intf, 1.0, x[:out_len])[sl])
+
+    before = diff(sig)
+    after = diff(ol)
+    assert abs(before - 2) < 0.5, before     # :1039-1045
+    assert abs(after - 5) < 1.0, after       # :1061-1064
