@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum path on MI355X.
+
+One "step" = one pass of the whole hot path (STFT analysis -> GCC-PHAT over all pairs -> SRP scan
+-> IIR + peak pick -> delay-and-sum -> ISTFT/overlap-add) over one batch of synthetic input that
+is already resident in HBM: `--arrays` independent 8-mic arrays x `--frames` STFT frames per GPU
+(BASELINE.json configs[2] geometry: 48 kHz, 1024-pt, hop 512, 361 steering angles; 8 x 4096 frames
+per GPU = the per-GPU frame count of configs[4]).  Arrays are independent units: with N GPUs every
+rank owns its own arrays (weak scaling), no collective inside the compute, one RCCL all_gather of
+the DOA bins + prob per step.
+
+Prints ONE JSON line (rank 0).  `value` = frames of all ranks / max-over-ranks time of K steps.
+`roofline` is for the dominant kernel, timed with HIP events recorded by the library on the
+launch stream inside the timed region.  `cpu_baseline` = the CPU oracle (a scalar double-precision
+restatement of the reference, oracle/) on a bounded sample of the same input, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FS, NFFT, HOP, M, STEP_DEG, D, P, K = 48000, 1024, 512, 8, 0.5, 361, 28, 513
+BYTES_PER_FRAME = M * HOP * 4 + HOP * 4 + 8          # 18 440 B (PCM in once, audio out, DOA idx + prob)
+HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0 TB/s spec
+PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0}   # dense MFMA peaks, same guide
+PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2}
+
+
+def synth_batch(n_arrays, n_frames, device, seed):
+    """Far-field white source per array + 20 dB sensor noise, generated on the GPU."""
+    from mcarray_amd import synth
+    L = (n_frames + 1) * HOP
+    gen = torch.Generator(device=device).manual_seed(seed)
+    xs = torch.tensor(synth.ULA8, device=device, dtype=torch.float64)
+    theta = (torch.rand(n_arrays, device=device, dtype=torch.float64, generator=gen) * 160.0 - 80.0) * (np.pi / 180.0)
+    out = torch.empty(n_arrays, M, L, device=device, dtype=torch.float32)
+    f = torch.fft.rfftfreq(L, d=1.0 / FS).to(device=device, dtype=torch.float64)
+    for a in range(n_arrays):   # one array at a time keeps the fp64 temporaries small
+        s = torch.randn(L, device=device, dtype=torch.float64, generator=gen) * 0.1
+        S = torch.fft.rfft(s)
+        adv = xs * torch.sin(theta[a]) / 346.1
+        x = torch.fft.irfft(S[None, :] * torch.exp(2j * np.pi * f[None, :] * adv[:, None]), n=L, dim=1)
+        x = x + torch.randn(M, L, device=device, dtype=torch.float64, generator=gen) * 0.01
+        out[a] = x.clamp_(-1.0, 1.0).to(torch.float32)
+    return out, theta
+
+
+def cpu_baseline(pcm_host, n_frames):
+    from oracle import pyoracle as po
+    from mcarray_amd import synth
+    po.lib()
+    L = (n_frames + 1) * HOP
+    x = pcm_host[:, :L].astype(np.float64)
+    t0 = time.perf_counter()
+    r = po.ssl_stream(FS, NFFT, synth.ULA8, x, 1, STEP_DEG, want_map=False, want_audio=True)
+    dt = time.perf_counter() - t0
+    return n_frames / dt, dt, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--arrays", type=int, default=8, help="independent 8-mic arrays per GPU")
+    ap.add_argument("--frames", type=int, default=4096, help="STFT frames per array per step")
+    ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "fp32"))
+    ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of array 0 timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from mcarray_amd import api, synth
+    A, F = args.arrays, args.frames
+    pcm, theta = synth_batch(A, F, dev, 0x5EED0000 + rank)
+    ctx = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=A, device=local_rank)
+    assert ctx.D == D and ctx.P == P
+    ctx.reserve(A, F)
+    doa_bin = torch.empty(A, F, 1, dtype=torch.int32, device=dev)
+    doa_rad = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+    prob = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+    out = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
+    gathered_bin = [torch.empty_like(doa_bin) for _ in range(world)] if world > 1 else None
+    gathered_prob = [torch.empty_like(prob) for _ in range(world)] if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=stream)
+        if world > 1:   # the only exchange of the path: gather DOA buffers (RCCL over xGMI)
+            dist.all_gather(gathered_bin, doa_bin)
+            dist.all_gather(gathered_prob, prob)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.set_timing(True)
+    ctx.reset_timing()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_per_step = A * F * world
+    value = frames_per_step * args.steps / elapsed
+
+    # per-kernel times recorded by the library with hipEvents on the launch stream
+    kt = {}
+    for kid, name in api.KERNEL_NAMES.items():
+        n, ms = ctx.get_timing(kid)
+        kt[name] = {"launches": n, "avg_ms": (ms / n if n else 0.0), "total_ms": ms}
+    dom = max(kt, key=lambda k: kt[k]["total_ms"])
+    frames_per_launch = A * F
+    if dom == "k_srp_gemm":
+        # algorithmic flops of this kernel per frame: real contraction [G*2K] x D, G = 7 delay groups of the ULA
+        flops = 2.0 * ctx.G * 2 * K * D * frames_per_launch
+        ach = flops / (kt[dom]["avg_ms"] * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None}
+    else:
+        per_frame = {"k_stft_phat": M * HOP * 4, "k_beamform_ola": M * HOP * 4 + HOP * 4, "k_scan_pick": D * 4 + 8}[dom]
+        ach = per_frame * frames_per_launch / (kt[dom]["avg_ms"] * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            nf = min(args.cpu_frames, F)
+            fps, dt, ref = cpu_baseline(pcm[0].cpu().numpy(), nf)
+            gb = doa_bin[0, :nf, 0].cpu().numpy()
+            mism = int((gb != ref["bin"][:, 0]).sum())
+            cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "array 0, first %d frames of the same input, %.1f s, double-precision scalar C restatement "
+                             "(oracle/mca_oracle.c, -O3); GPU/oracle DOA-bin mismatches on the sample: %d" % (nf, dt, mism)}
+        line = {
+            "metric": "STFT frames/sec, 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum beamform @48kHz/1024-pt",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (SRP operands %s)" % args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] geometry (8-mic ULA 0.04 m, 48 kHz, N=1024, hop 512, 361 angles, "
+                                   "1 source, no power floor), %d arrays x %d frames per GPU per step" % (A, F),
+                       "arrays_per_gpu": A, "frames_per_array": F, "srp_precision": args.precision,
+                       "parallelism": "arrays sharded over %d GPU(s), all_gather of DOA bins+prob" % world},
+            "algorithmic_GBps": value * BYTES_PER_FRAME / 1e9,
+            "hbm_roofline_frac": value * BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world),
+            "kernels": kt, "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

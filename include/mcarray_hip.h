@@ -1,0 +1,167 @@
+/*
+ * mcarray_hip.h -- C ABI of libmcarray_hip.so: the MI355X (gfx950) implementation of
+ * mcarray's per-frame localisation + beamforming hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no C++
+ * or torch types cross it.  Every entry point names the reference interface it
+ * replaces (paths relative to the reference root, jordi-adell/mcarray v0.3.0-alpha).
+ * The C++ classes in include/mcarray/ (same names and signatures as the reference's)
+ * are thin callers of these functions; INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - return value: 0 = MCA_HIP_OK, < 0 = error (mca_hip_status); the message is
+ *     available from mca_hip_last_error().  The C++ wrappers rethrow it as
+ *     mca::MCArrayException (include/mcarray/mcarray_exception.h:51 in the reference).
+ *   - "_dev" pointers are device (HBM) pointers, work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) and the call does
+ *     not synchronise.  Functions without "_dev" pointers take host pointers and
+ *     return after the result is on the host.
+ *   - A context is stateful like the reference's module objects (E_prev of
+ *     SteeringBeamforming.h:69, current DOA, overlap-add tails) and is not
+ *     thread-safe; use one context per stream of arrays (SURVEY 8b "Ownership").
+ *   - PCM layout (stream API): fp32, channel-major: sample n of microphone m of
+ *     array a at pcm[a*array_stride + m*mic_stride + n]; a call that processes F
+ *     frames reads (F+1)*hop samples per microphone (frame t = samples
+ *     [t*hop, t*hop+N), hop = N/2, periodic Hann analysis window).
+ *   - Spectrum layout (frame API): the reference's CCS layout, double[N+2], bin k at
+ *     [2k],[2k+1], k = 0..N/2 (Beamformer.cpp:59, test_mcarray.cpp:662).
+ */
+#ifndef MCARRAY_HIP_H
+#define MCARRAY_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MCA_HIP_OK = 0,
+    MCA_HIP_ERR_INVALID_ARGUMENT = -1,
+    MCA_HIP_ERR_HIP = -2,            /* a HIP runtime call failed */
+    MCA_HIP_ERR_OUT_OF_MEMORY = -3,
+    MCA_HIP_ERR_UNSUPPORTED = -4,    /* configuration outside what the kernels cover */
+    MCA_HIP_ERR_NO_DEVICE = -5       /* no gfx950 device visible: there is NO CPU fallback */
+} mca_hip_status;
+
+typedef enum {
+    MCA_HIP_SRP_FP32 = 0,    /* v_mfma_f32_32x32x2_f32, exact fp32 (parity anchor) */
+    MCA_HIP_SRP_FP16X3 = 1,  /* fp16 hi/lo split operands, 3 MFMAs per k-step, ~fp32 accuracy */
+    MCA_HIP_SRP_FP16 = 2     /* single fp16 MFMA per k-step (fast; energy map rel. error ~3e-5) */
+} mca_hip_srp_precision;
+
+typedef struct mca_hip_ctx mca_hip_ctx;
+
+/* Configuration = the constructor arguments of the reference's modules
+ * (SourceSeparationAndLocalisation.h:47, BeamformingSeparationAndLocalistaion.h:40,
+ * SteeringBeamforming.h:43, Beamformer.h:39) plus the constants the reference
+ * hard-codes and BASELINE.json needs as parameters (SURVEY section 5 "config"). */
+typedef struct {
+    int struct_size;           /* sizeof(mca_hip_config), for ABI evolution */
+    int device;                /* HIP device ordinal */
+    int sample_rate;           /* Hz */
+    int fft_size;              /* N; the reference derives it with calculateOrderFromSampleRate
+                                  (SourceSeparationAndLocalisation.cpp:52); the stream API supports N = 1024,
+                                  the frame API any even N with N/2+1 <= 4097 */
+    int n_mics;                /* M, 2..16 */
+    const double *mic_xyz;     /* [M][3] metres, ArrayDescription coordinates (ArrayDescription.h:31-92) */
+    double doa_step_deg;       /* SteeringBeamforming.cpp:39 hard-codes 5.0; BASELINE uses 0.5 */
+    int n_sources;             /* numOfSources, 1..4 */
+    int use_power_floor;       /* usePowerFloor (frame API only; the stream API runs ungated like mcabeamf.cpp:194) */
+    int srp_precision;         /* mca_hip_srp_precision */
+    int max_arrays;            /* number of independent arrays whose state the context holds (>= 1) */
+} mca_hip_config;
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* Replaces the constructors SteeringBeamforming::SteeringBeamforming + generateLookupTable
+ * (SteeringBeamforming.cpp:34-94), Beamformer::Beamformer (Beamformer.cpp:33-49) and
+ * BeamformingSeparationAndLocalisation's (BeamformingSeparationAndLocalisation.cpp:29-53). */
+int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out);
+void mca_hip_destroy(mca_hip_ctx *ctx);
+/* message of the last failure on this context (ctx == NULL: last failed create) */
+const char *mca_hip_last_error(const mca_hip_ctx *ctx);
+
+/* ---- introspection --------------------------------------------------------- */
+int mca_hip_num_steps(const mca_hip_ctx *ctx);   /* D = _numSteps (SteeringBeamforming.cpp:40) */
+int mca_hip_num_pairs(const mca_hip_ctx *ctx);   /* P = M(M-1)/2 */
+int mca_hip_num_groups(const mca_hip_ctx *ctx);  /* pairs sharing a bit-identical delay table are merged */
+/* delaysForMicroPair (SteeringBeamforming.cpp:69-73): out[P][D], the float delays in samples */
+int mca_hip_get_pair_delays(const mca_hip_ctx *ctx, float *out);
+/* doaIdx2angle for every grid point (microhponeArrayHelpers.cpp:117-120): out[D] radians */
+int mca_hip_get_doa_grid(const mca_hip_ctx *ctx, float *out);
+
+/* ---- state ----------------------------------------------------------------- */
+/* zero E_prev / DOA / overlap-add tails of every array (a freshly constructed module) */
+int mca_hip_reset(mca_hip_ctx *ctx, void *stream);
+/* pre-size the internal workspace so later *_dev calls allocate nothing (graph capture) */
+int mca_hip_reserve(mca_hip_ctx *ctx, int n_arrays, int n_frames);
+
+/* ---- stream API: batched frames, device pointers ---------------------------- */
+/* STFT analysis + SteeringBeamforming::processFrame (SteeringBeamforming.cpp:96-195) for
+ * n_frames consecutive frames of n_arrays independent arrays: GCC-PHAT over all pairs,
+ * SRP scan, 0.8 IIR over frames (continuing from the context state), selectDOA.
+ * Outputs (any may be NULL except doa_bin_dev):
+ *   doa_bin_dev [A][F][S] int32   maxIdx+1 of selectDOA (:191) -- the "DOA bin"
+ *   doa_rad_dev [A][F][S] float   doaIdx2angle(maxIdx+1) (:191), radians
+ *   prob_dev    [A][F][S] float   the max (:193)
+ *   energy_dev  [A][F][D] float   un-normalised smoothed _energyInDOA (before :155) */
+int mca_hip_localise_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,
+                                long long mic_stride, int n_arrays, int n_frames,
+                                int *doa_bin_dev, float *doa_rad_dev, float *prob_dev,
+                                float *energy_dev, void *stream);
+
+/* STFT analysis + BeamformingSeparationAndLocalisation::processFrameSeparation
+ * (BeamformingSeparationAndLocalisation.cpp:103-119 -> Beamformer::processFrame,
+ * Beamformer.cpp:51-71) + inverse FFT and overlap-add, steering frame t of array a at
+ * doa_rad_dev[a][t][s].  out_pcm_dev [A][S][F*hop] fp32. */
+int mca_hip_separate_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,
+                                long long mic_stride, int n_arrays, int n_frames,
+                                const float *doa_rad_dev, float *out_pcm_dev, void *stream);
+
+/* Both of the above in sequence = SourceSeparationAndLocalisation::processParametrisation
+ * (SourceSeparationAndLocalisation.cpp:79-94) for every frame. */
+int mca_hip_process_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,
+                               long long mic_stride, int n_arrays, int n_frames,
+                               int *doa_bin_dev, float *doa_rad_dev, float *prob_dev,
+                               float *energy_dev, float *out_pcm_dev, void *stream);
+
+/* Host-buffer variant of mca_hip_process_frames_dev (copies in, runs, copies out, synchronises);
+ * pcm is [A][M][(F+1)*hop] contiguous; outputs as above, any of doa_rad/prob/energy/out_pcm may be NULL. */
+int mca_hip_process_frames_host(mca_hip_ctx *ctx, const float *pcm, int n_arrays, int n_frames,
+                                int *doa_bin, float *doa_rad, float *prob, float *energy, float *out_pcm);
+
+/* ---- frame API: one frame of CCS spectra, host pointers, double precision ------ */
+/* SteeringBeamforming::processFrame(const SignalVector&, SignalPtr DOA, SignalPtr prob,
+ * int numOfSources, SignalVector& wienerCoefs) (SteeringBeamforming.h:54).  frames[c] ->
+ * double[ccs_len]; DOA[S] radians, prob[S]; doa_bin (may be NULL) [S].  State of array 0. */
+int mca_hip_steering_process_frame(mca_hip_ctx *ctx, const double *const *frames, int ccs_len,
+                                   double *DOA, double *prob, int *doa_bin, int n_sources);
+/* Beamformer::processFrame(SignalVector&, SignalPtr outputFrame, double DOA) (Beamformer.h:49) */
+int mca_hip_beamformer_process_frame(mca_hip_ctx *ctx, const double *const *frames, int ccs_len,
+                                     double *out, double DOA);
+/* dsp::SignalPower::FFTLogPower as used by the power gate
+ * (BeamformingSeparationAndLocalisation.cpp:83); *power_db = 10 log10(mean-square) */
+int mca_hip_fft_log_power(mca_hip_ctx *ctx, const double *const *frames, int ccs_len, double *power_db);
+/* copy of the current un-normalised _prevEnergyInDOA of array 0: out[D] */
+int mca_hip_get_energy(mca_hip_ctx *ctx, double *out);
+
+/* ---- measurement ------------------------------------------------------------ */
+typedef enum {
+    MCA_HIP_K_STFT_PHAT = 0,   /* STFT + PHAT whitening + pair-group sums */
+    MCA_HIP_K_SRP_GEMM = 1,    /* steering contraction (MFMA) */
+    MCA_HIP_K_SCAN_PICK = 2,   /* IIR over frames + selectDOA */
+    MCA_HIP_K_BEAMFORM = 3,    /* STFT + delay-and-sum + inverse FFT + overlap-add */
+    MCA_HIP_K_COUNT = 4
+} mca_hip_kernel_id;
+/* enable = 1: bracket every launch of the stream API with hipEvents on its stream */
+int mca_hip_set_timing(mca_hip_ctx *ctx, int enable);
+/* synchronises the recorded events; *launches and *total_ms accumulate since the last reset */
+int mca_hip_get_timing(mca_hip_ctx *ctx, int kernel_id, int *launches, double *total_ms);
+int mca_hip_reset_timing(mca_hip_ctx *ctx);
+
+/* library version string */
+const char *mca_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCARRAY_HIP_H */

@@ -1,0 +1,228 @@
+"""Python mirror of the reference's module API on top of the C ABI (libmcarray_hip.so).
+
+Class and method names follow the reference (mca::SteeringBeamforming, mca::Beamformer,
+mca::BeamformingSeparationAndLocalisation, mca::SourceSeparationAndLocalisation), so the parity
+tests read like the reference's tests.  Everything numerical happens in the HIP library; numpy is
+used only to marshal buffers.  torch is optional here and only used by the *_dev helpers
+(device tensors in, device tensors out).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MCArrayHipError
+
+SRP_FP32, SRP_FP16X3, SRP_FP16 = 0, 1, 2
+K_STFT_PHAT, K_SRP_GEMM, K_SCAN_PICK, K_BEAMFORM = 0, 1, 2, 3
+KERNEL_NAMES = {K_STFT_PHAT: "k_stft_phat", K_SRP_GEMM: "k_srp_gemm", K_SCAN_PICK: "k_scan_pick", K_BEAMFORM: "k_beamform_ola"}
+
+
+def _xyz(x):
+    a = np.asarray(x, dtype=np.float64)
+    if a.ndim == 1:   # ArrayDescription::make_linear_array_description (ArrayDescription.cpp:41-49)
+        a = np.stack([a, np.zeros_like(a), np.zeros_like(a)], axis=1)
+    return np.ascontiguousarray(a)
+
+
+class Context:
+    """Owns one mca_hip_ctx (the state of max_arrays independent module objects)."""
+
+    def __init__(self, sample_rate, mic_positions, fft_size=1024, doa_step_deg=5.0, n_sources=1, use_power_floor=False,
+                 srp_precision=SRP_FP32, max_arrays=1, device=0):
+        self._lib = _lib.load()
+        self.xyz = _xyz(mic_positions)
+        self.M = len(self.xyz)
+        self.N = fft_size
+        self.hop = fft_size // 2
+        self.S = n_sources
+        self.fs = sample_rate
+        cfg = _lib.Config()
+        cfg.struct_size = C.sizeof(_lib.Config)
+        cfg.device = device
+        cfg.sample_rate = sample_rate
+        cfg.fft_size = fft_size
+        cfg.n_mics = self.M
+        cfg.mic_xyz = self.xyz.ctypes.data_as(_lib.c_dp)
+        cfg.doa_step_deg = doa_step_deg
+        cfg.n_sources = n_sources
+        cfg.use_power_floor = int(use_power_floor)
+        cfg.srp_precision = srp_precision
+        cfg.max_arrays = max_arrays
+        h = C.c_void_p()
+        rc = self._lib.mca_hip_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise MCArrayHipError("mca_hip_create failed (%d): %s" % (rc, self._lib.mca_hip_last_error(None).decode()))
+        self.h = h
+        self.D = self._lib.mca_hip_num_steps(h)
+        self.P = self._lib.mca_hip_num_pairs(h)
+        self.G = self._lib.mca_hip_num_groups(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.mca_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MCArrayHipError("libmcarray_hip error %d: %s" % (rc, self._lib.mca_hip_last_error(self.h).decode()))
+
+    # ---- introspection ----
+    def pair_delays(self):
+        out = np.empty((self.P, self.D), dtype=np.float32)
+        self._check(self._lib.mca_hip_get_pair_delays(self.h, out.ctypes.data_as(_lib.c_fp)))
+        return out
+
+    def doa_grid(self):
+        out = np.empty(self.D, dtype=np.float32)
+        self._check(self._lib.mca_hip_get_doa_grid(self.h, out.ctypes.data_as(_lib.c_fp)))
+        return out
+
+    def reset(self, stream=None):
+        self._check(self._lib.mca_hip_reset(self.h, stream))
+
+    def reserve(self, n_arrays, n_frames):
+        self._check(self._lib.mca_hip_reserve(self.h, n_arrays, n_frames))
+
+    # ---- stream API, host buffers ----
+    def process_frames_host(self, pcm, want_energy=False, want_audio=True):
+        """pcm float32 [A][M][(F+1)*hop] -> dict(bin [A][F][S], doa, prob, energy [A][F][D], out [A][S][F*hop])"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if pcm.ndim == 2:
+            pcm = pcm[None]
+        A, M, L = pcm.shape
+        if M != self.M:
+            raise MCArrayHipError("pcm has %d channels, context has %d microphones" % (M, self.M))
+        F = L // self.hop - 1
+        if F < 1 or (F + 1) * self.hop != L:
+            raise MCArrayHipError("pcm length must be (F+1)*hop samples")
+        S, D = self.S, self.D
+        bins = np.empty((A, F, S), dtype=np.int32)
+        doa = np.empty((A, F, S), dtype=np.float32)
+        prob = np.empty((A, F, S), dtype=np.float32)
+        energy = np.empty((A, F, D), dtype=np.float32) if want_energy else None
+        out = np.empty((A, S, F * self.hop), dtype=np.float32) if want_audio else None
+        fp = _lib.c_fp
+        self._check(self._lib.mca_hip_process_frames_host(
+            self.h, pcm.ctypes.data_as(fp), A, F, bins.ctypes.data_as(_lib.c_ip), doa.ctypes.data_as(fp),
+            prob.ctypes.data_as(fp), energy.ctypes.data_as(fp) if want_energy else None,
+            out.ctypes.data_as(fp) if want_audio else None))
+        return dict(bin=bins, doa=doa, prob=prob, energy=energy, out=out)
+
+    # ---- stream API, device tensors (torch used for memory only) ----
+    def process_frames_dev(self, pcm, n_frames, doa_bin, doa_rad, prob, energy=None, out_pcm=None, stream=None,
+                           localise=True, separate=True):
+        """pcm: torch float32 cuda tensor [A][M][>= (F+1)*hop]; outputs preallocated cuda tensors."""
+        A, M, L = pcm.shape
+        if M != self.M:
+            raise MCArrayHipError("pcm has %d channels, context has %d microphones" % (M, self.M))
+        if not pcm.is_contiguous():
+            raise MCArrayHipError("pcm must be contiguous")
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        if localise:
+            self._check(self._lib.mca_hip_localise_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_bin),
+                                                              ptr(doa_rad), ptr(prob), ptr(energy), stream))
+        if separate and out_pcm is not None:
+            self._check(self._lib.mca_hip_separate_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_rad),
+                                                              ptr(out_pcm), stream))
+
+    # ---- frame API ----
+    def _rows(self, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.float64)
+        if frames.shape[0] != self.M:
+            raise MCArrayHipError("expected %d channel spectra" % self.M)
+        arr = (_lib.c_dp * self.M)()
+        for c in range(self.M):
+            arr[c] = frames[c].ctypes.data_as(_lib.c_dp)
+        return frames, arr
+
+    def steering_process_frame(self, frames, n_sources=1):
+        frames, arr = self._rows(frames)
+        doa = np.empty(n_sources)
+        prob = np.empty(n_sources)
+        bins = np.empty(n_sources, dtype=np.int32)
+        self._check(self._lib.mca_hip_steering_process_frame(self.h, arr, frames.shape[1], doa.ctypes.data_as(_lib.c_dp),
+                                                             prob.ctypes.data_as(_lib.c_dp), bins.ctypes.data_as(_lib.c_ip),
+                                                             n_sources))
+        return doa, prob, bins
+
+    def beamformer_process_frame(self, frames, doa):
+        frames, arr = self._rows(frames)
+        out = np.empty(frames.shape[1])
+        self._check(self._lib.mca_hip_beamformer_process_frame(self.h, arr, frames.shape[1], out.ctypes.data_as(_lib.c_dp), float(doa)))
+        return out
+
+    def fft_log_power(self, frames):
+        frames, arr = self._rows(frames)
+        p = C.c_double(0)
+        self._check(self._lib.mca_hip_fft_log_power(self.h, arr, frames.shape[1], C.byref(p)))
+        return p.value
+
+    def energy(self):
+        out = np.empty(self.D)
+        self._check(self._lib.mca_hip_get_energy(self.h, out.ctypes.data_as(_lib.c_dp)))
+        return out
+
+    # ---- measurement ----
+    def set_timing(self, enable):
+        self._check(self._lib.mca_hip_set_timing(self.h, int(enable)))
+
+    def reset_timing(self):
+        self._check(self._lib.mca_hip_reset_timing(self.h))
+
+    def get_timing(self, kernel_id):
+        n = C.c_int(0)
+        ms = C.c_double(0)
+        self._check(self._lib.mca_hip_get_timing(self.h, kernel_id, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class SteeringBeamforming:
+    """mca::SteeringBeamforming(int sampleRate, ArrayDescription, int fftCCSLength, unsigned nchannels)
+    (SteeringBeamforming.h:43); processFrame (:54) returns (DOA[S] rad, prob[S], bin[S])."""
+
+    def __init__(self, sample_rate, mic_positions, fft_ccs_length, nchannels=None, doa_step_deg=5.0, device=0):
+        self.ctx = Context(sample_rate, mic_positions, fft_ccs_length - 2, doa_step_deg, n_sources=4, device=device)
+        if nchannels is not None and nchannels != self.ctx.M:
+            raise MCArrayHipError("nchannels does not match the array description")
+
+    def process_frame(self, analysis_frames, n_sources=1):
+        return self.ctx.steering_process_frame(analysis_frames, n_sources)
+
+
+class Beamformer:
+    """mca::Beamformer(int sampleRate, ArrayDescription, int fftCCSLength, unsigned nchannels) (Beamformer.h:39)."""
+
+    def __init__(self, sample_rate, mic_positions, fft_ccs_length, nchannels=None, device=0):
+        self.ctx = Context(sample_rate, mic_positions, fft_ccs_length - 2, device=device)
+
+    def process_frame(self, analysis_frames, doa):
+        return self.ctx.beamformer_process_frame(analysis_frames, doa)
+
+
+class SourceSeparationAndLocalisation:
+    """mca::SourceSeparationAndLocalisation(int sampleRate, ArrayDescription, unsigned numOfSources,
+    bool usePowerFloor) (SourceSeparationAndLocalisation.h:47) driven over whole buffers: process()
+    takes channel-major PCM, returns the beamformed audio and calls the callback once per frame
+    like LocalisationCallback::setDOA(doaDegrees, prob, power, numOfSources) (SoundLocalisationCallback.h:53)."""
+
+    def __init__(self, sample_rate, mic_positions, n_sources=1, use_power_floor=False, doa_step_deg=5.0, fft_size=1024,
+                 srp_precision=SRP_FP32, device=0):
+        if use_power_floor:
+            raise MCArrayHipError("the stream API runs ungated (usePowerFloor=false, as mcabeamf.cpp:194)")
+        self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, n_sources, False, srp_precision, 1, device)
+        self.callback = None
+
+    def set_callback(self, cb):
+        self.callback = cb
+
+    def process(self, pcm):
+        r = self.ctx.process_frames_host(np.asarray(pcm, dtype=np.float32)[None], want_energy=False, want_audio=True)
+        if self.callback is not None:
+            deg = r["doa"][0].astype(np.float64) * (180.0 / np.pi)   # toDegrees (microhponeArrayHelpers.cpp:91-98)
+            for t in range(deg.shape[0]):
+                self.callback(deg[t], r["prob"][0, t], None, self.ctx.S)
+        return r["out"][0], r

@@ -1,0 +1,642 @@
+// api.hip -- the extern "C" layer of libmcarray_hip.so (see include/mcarray_hip.h).
+// Host side only: validates arguments (every shape a kernel or its grid assumes is checked here
+// before a launch), builds the tables the reference builds in its constructors, owns the
+// per-context state and workspace, and enqueues the kernels.  No compute happens on the host
+// and there is no CPU fallback: without a gfx950 device mca_hip_create fails.
+#include "../../include/mcarray_hip.h"
+#include "fft512.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mca;
+
+namespace {
+
+std::string g_create_error;
+
+struct TimedEvent { int id; hipEvent_t a, b; };
+
+}  // namespace
+
+struct mca_hip_ctx {
+    mca_hip_config cfg{};
+    std::vector<double> xyz;
+    int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, Kp = 0, S = 1, prec = 0;
+    bool ula = false, stream_ok = false;
+    float step = 0.f;
+    std::vector<float> delays, grid;
+    std::vector<int2> pairs;
+    // device tables
+    float *d_window = nullptr, *d_grid = nullptr, *d_delays = nullptr;
+    double *d_micx = nullptr;
+    int2 *d_pairs = nullptr;
+    void *d_B = nullptr;
+    // stream state (double buffered: kernels read [cur], write [cur^1])
+    float *d_E[2] = {nullptr, nullptr};
+    float *d_tail[2] = {nullptr, nullptr};
+    int e_cur = 0, tail_cur = 0;
+    // workspace
+    void *d_A = nullptr; size_t a_bytes = 0;
+    float *d_C = nullptr; size_t c_bytes = 0;
+    int a_row_elems = 0, a_planes = 1, a_elem = 4;
+    // frame API (double)
+    double *d_fr = nullptr; size_t fr_elems = 0;
+    double *d_E64[2] = {nullptr, nullptr}; int e64_cur = 0;
+    double *d_res = nullptr;      // [S] doa, [S] prob, power
+    int *d_bins = nullptr;
+    double *d_out64 = nullptr; size_t out64_elems = 0;
+    std::vector<double> h_stage;
+    // timing
+    bool timing = false;
+    std::vector<TimedEvent> events;
+    std::vector<hipEvent_t> pool;
+    int t_launches[MCA_HIP_K_COUNT] = {0, 0, 0, 0};
+    double t_ms[MCA_HIP_K_COUNT] = {0, 0, 0, 0};
+    std::string err;
+};
+
+namespace {
+
+int fail(mca_hip_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(ctx, _e == hipErrorOutOfMemory ? MCA_HIP_ERR_OUT_OF_MEMORY : MCA_HIP_ERR_HIP,   \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+    } while (0)
+
+// ---- the reference's helper chain, host side (exact float/double sequence of
+//      src/mcarray/microhponeArrayHelpers.cpp:38-120; [BUILD-DEFINES] double sin) ----
+double speed_of_sound() { return 346.1; }                                           // :38-43
+float doa_idx2angle(int idx, float step) { float pr = (float)idx * step; return (float)((double)pr - M_PI_2); }   // :117-120
+float doa_to_delay_far_field(float doa, float microDist)                            // :46-67
+{
+    return (float)(((double)microDist * std::sin((double)doa)) / speed_of_sound());
+}
+float doa_to_delay_samples(float doa, float microDist, int fs) { return doa_to_delay_far_field(doa, microDist) * (float)fs; }   // :69-72
+double distance(const std::vector<double> &xyz, int i, int j)                        // ArrayDescription.cpp:57-64
+{
+    return std::sqrt(std::pow(xyz[3 * j] - xyz[3 * i], 2) + std::pow(xyz[3 * j + 1] - xyz[3 * i + 1], 2) +
+                     std::pow(xyz[3 * j + 2] - xyz[3 * i + 2], 2));
+}
+
+void free_ctx(mca_hip_ctx *c)
+{
+    if (!c) return;
+    auto F = [](void *p) { if (p) (void)hipFree(p); };
+    F(c->d_window); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B);
+    F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C);
+    F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
+    for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : c->pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// steering table B of the SRP contraction = precomputeTauMatrix (SteeringBeamforming.cpp:87-88)
+// for the first pair of every delay group, laid out for the MFMA kernels.
+int build_steering_table(mca_hip_ctx *c)
+{
+    const int K = c->K, D = c->D, Dp = c->Dp, Kp = c->Kp;
+    std::vector<int> first_pair(c->G);
+    if (c->ula) { for (int g = 0; g < c->G; ++g) first_pair[g] = g; /* pair (0, g+1) has index g */ }
+    else for (int g = 0; g < c->G; ++g) first_pair[g] = g;
+    const double N = 2.0 * (K - 1);
+    if (c->prec == MCA_HIP_SRP_FP32) {
+        std::vector<float> B((size_t)Kp * Dp, 0.f);
+        for (int g = 0; g < c->G; ++g)
+            for (int k = 0; k < K; ++k)
+                for (int d = 0; d < D; ++d) {
+                    double ph = 2.0 * M_PI * (double)k * (double)c->delays[(size_t)first_pair[g] * D + d] / N;
+                    size_t r = ((size_t)g * K + k) * 2;
+                    B[r * Dp + d] = (float)std::cos(ph);
+                    B[(r + 1) * Dp + d] = (float)(-std::sin(ph));
+                }
+        HIP_TRY(c, hipMalloc(&c->d_B, B.size() * sizeof(float)));
+        HIP_TRY(c, hipMemcpy(c->d_B, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        const int planes = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
+        std::vector<_Float16> B((size_t)planes * Dp * Kp, (_Float16)0.f);
+        for (int g = 0; g < c->G; ++g)
+            for (int d = 0; d < D; ++d)
+                for (int k = 0; k < K; ++k) {
+                    double ph = 2.0 * M_PI * (double)k * (double)c->delays[(size_t)first_pair[g] * D + d] / N;
+                    float v[2] = {(float)std::cos(ph), (float)(-std::sin(ph))};
+                    for (int q = 0; q < 2; ++q) {
+                        size_t kk = ((size_t)g * K + k) * 2 + q;
+                        _Float16 hi = (_Float16)v[q];
+                        B[(size_t)d * Kp + kk] = hi;
+                        if (planes == 2) B[((size_t)Dp + d) * Kp + kk] = (_Float16)(v[q] - (float)hi);
+                    }
+                }
+        HIP_TRY(c, hipMalloc(&c->d_B, B.size() * sizeof(_Float16)));
+        HIP_TRY(c, hipMemcpy(c->d_B, B.data(), B.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    }
+    return MCA_HIP_OK;
+}
+
+void time_begin(mca_hip_ctx *c, int id, hipStream_t st)
+{
+    if (!c->timing) return;
+    TimedEvent ev; ev.id = id;
+    auto get = [&]() { hipEvent_t e; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    ev.a = get(); ev.b = get();
+    (void)hipEventRecord(ev.a, st);
+    c->events.push_back(ev);
+}
+void time_end(mca_hip_ctx *c, hipStream_t st)
+{
+    if (!c->timing) return;
+    (void)hipEventRecord(c->events.back().b, st);
+}
+
+int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
+{
+    size_t need_a = (size_t)rows_chunk * c->a_row_elems * c->a_elem;
+    if (need_a > c->a_bytes) {
+        if (c->d_A) (void)hipFree(c->d_A);
+        c->d_A = nullptr; c->a_bytes = 0;
+        HIP_TRY(c, hipMalloc(&c->d_A, need_a));
+        HIP_TRY(c, hipMemset(c->d_A, 0, need_a));       // the Kp padding columns stay zero forever
+        c->a_bytes = need_a;
+    }
+    size_t need_c = (size_t)rows_total * c->Dp * sizeof(float);
+    if (need_c > c->c_bytes) {
+        if (c->d_C) (void)hipFree(c->d_C);
+        c->d_C = nullptr; c->c_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_C, need_c));
+        c->c_bytes = need_c;
+    }
+    return MCA_HIP_OK;
+}
+
+constexpr long long WS_MAX_BYTES = 4LL << 30;   // A-operand workspace budget per chunk
+
+long long chunk_frames_for(const mca_hip_ctx *c, int n_arrays, int n_frames)
+{
+    long long row_bytes = (long long)c->a_row_elems * c->a_elem;
+    long long rows_cap = WS_MAX_BYTES / row_bytes;
+    long long fc = rows_cap / n_arrays;
+    if (fc >= n_frames) return n_frames;
+    fc = fc / 8 * 8;
+    if (fc < 8) fc = 8;
+    return fc < n_frames ? fc : n_frames;
+}
+
+template <typename OutT>
+int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, hipStream_t st)
+{
+    const int M = c->M; const bool ula = c->ula;
+#define LAUNCH(MT, U)                                                                                        \
+    do {                                                                                                     \
+        if (smem > 64 * 1024)                                                                                \
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat<MT, U, OutT>),        \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));          \
+        hipLaunchKernelGGL((k_stft_phat<MT, U, OutT>), grid, dim3(512), smem, st, a);                        \
+    } while (0)
+    if (M == 2 && !ula) LAUNCH(2, false);
+    else if (M == 4 && ula) LAUNCH(4, true);
+    else if (M == 4) LAUNCH(4, false);
+    else if (M == 8 && ula) LAUNCH(8, true);
+    else if (M == 8) LAUNCH(8, false);
+    else if (M == 16 && ula) LAUNCH(16, true);
+    else if (ula) LAUNCH(0, true);
+    else LAUNCH(0, false);
+#undef LAUNCH
+    HIP_TRY(c, hipGetLastError());
+    return MCA_HIP_OK;
+}
+
+int check_stream_args(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride, int n_arrays, int n_frames)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!c->stream_ok) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "the stream API needs fft_size == 1024 (the frame API takes any size)");
+    if (!pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev is NULL");
+    if (n_arrays < 1 || n_arrays > c->cfg.max_arrays) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays outside [1, max_arrays]");
+    if (n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_frames < 1");
+    const long long need = (long long)(n_frames + 1) * FFT_H;
+    if (mic_stride < need) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "mic_stride shorter than (n_frames+1)*hop samples");
+    if (n_arrays > 1 && array_stride < (long long)(c->M - 1) * mic_stride + need) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "array_stride too short");
+    if ((mic_stride & 1) || (array_stride & 1) || (reinterpret_cast<uintptr_t>(pcm) & 7))
+        return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev must be 8-byte aligned with even strides (float2 loads)");
+    return MCA_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mca_hip_version(void) { return "mcarray-hip 0.1.0 (gfx950)"; }
+
+const char *mca_hip_last_error(const mca_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->struct_size != (int)sizeof(mca_hip_config)) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "struct_size mismatch");
+    if (cfg->n_mics < 2 || cfg->n_mics > MCA_MAX_MICS) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "n_mics must be in [2,16]");
+    if (!cfg->mic_xyz) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "mic_xyz is NULL");
+    if (cfg->n_sources < 1 || cfg->n_sources > MCA_MAX_SOURCES) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "n_sources must be in [1,4]");
+    if (cfg->fft_size < 16 || (cfg->fft_size & 1) || cfg->fft_size > 8192) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "fft_size must be even, 16..8192");
+    if (cfg->sample_rate <= 0) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "sample_rate <= 0");
+    if (!(cfg->doa_step_deg > 0) || cfg->doa_step_deg > 45) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_step_deg must be in (0,45]");
+    if (cfg->srp_precision < 0 || cfg->srp_precision > 2) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "bad srp_precision");
+    if (cfg->max_arrays < 1) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "max_arrays < 1");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, MCA_HIP_ERR_NO_DEVICE, "no HIP device visible; libmcarray_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, MCA_HIP_ERR_HIP, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, MCA_HIP_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MCA_HIP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+
+    mca_hip_ctx *c = new mca_hip_ctx();
+    c->cfg = *cfg;
+    c->M = cfg->n_mics; c->S = cfg->n_sources; c->N = cfg->fft_size; c->K = c->N / 2 + 1; c->prec = cfg->srp_precision;
+    c->xyz.assign(cfg->mic_xyz, cfg->mic_xyz + 3 * c->M);
+    c->cfg.mic_xyz = nullptr;
+    c->step = (float)(cfg->doa_step_deg * M_PI / 180.0);                    // SteeringBeamforming.cpp:39
+    c->D = (int)(std::round(M_PI / (double)c->step) + 1);                   // :40
+    if (c->D < 3 || c->D > 512) { free_ctx(c); return fail(nullptr, MCA_HIP_ERR_UNSUPPORTED, "number of steering angles must be in [3,512]"); }
+    c->P = c->M * (c->M - 1) / 2;
+    c->Dp = round_up(c->D, 192);
+    c->stream_ok = (c->N == FFT_N);
+
+    // generateLookupTable (SteeringBeamforming.cpp:58-94): pairs i<j lexicographic, float delays
+    c->delays.resize((size_t)c->P * c->D);
+    std::vector<float> fdist(c->P);
+    {
+        int p = 0;
+        for (int i = 0; i < c->M; ++i)
+            for (int j = i + 1; j < c->M; ++j, ++p) {
+                double dist = distance(c->xyz, i, j);                         // :67
+                fdist[p] = (float)dist;                                       // `float microDist` parameter
+                for (int d = 0; d < c->D; ++d)                                // :71-73
+                    c->delays[(size_t)p * c->D + d] = doa_to_delay_samples(doa_idx2angle(d, c->step), (float)dist, cfg->sample_rate);
+                c->pairs.push_back(make_int2(i, j));
+            }
+    }
+    c->grid.resize(c->D);
+    for (int d = 0; d < c->D; ++d) c->grid[d] = doa_idx2angle(d, c->step);
+    // delay-group merging: legal iff all pairs with equal (j - i) have bit-identical float distances
+    // (then their D delays are bit-identical too) -- true for uniform linear arrays.
+    c->ula = c->M > 2;
+    {
+        int p = 0;
+        for (int i = 0; i < c->M && c->ula; ++i)
+            for (int j = i + 1; j < c->M; ++j, ++p)
+                if (std::memcmp(&fdist[p], &fdist[j - i - 1], sizeof(float)) != 0) { c->ula = false; break; }
+    }
+    c->G = c->ula ? c->M - 1 : c->P;
+    c->Kp = round_up(c->G * c->K * 2, 32);
+    c->a_planes = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
+    c->a_elem = c->prec == MCA_HIP_SRP_FP32 ? 4 : 2;
+    c->a_row_elems = c->Kp * c->a_planes;
+
+    int rc = MCA_HIP_OK;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        HIP_TRY(c, hipMalloc(dst, bytes));
+        HIP_TRY(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return MCA_HIP_OK;
+    };
+    auto zalloc = [&](void **dst, size_t bytes) -> int {
+        HIP_TRY(c, hipMalloc(dst, bytes));
+        HIP_TRY(c, hipMemset(*dst, 0, bytes));
+        return MCA_HIP_OK;
+    };
+    std::vector<double> micx(c->M);
+    for (int m = 0; m < c->M; ++m) micx[m] = c->xyz[3 * m];
+    std::vector<float> win(FFT_N);
+    for (int n = 0; n < FFT_N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / FFT_N));   // periodic Hann
+    const size_t na = (size_t)cfg->max_arrays;
+    if ((rc = up((void **)&c->d_window, win.data(), win.size() * 4)) || (rc = up((void **)&c->d_grid, c->grid.data(), c->grid.size() * 4)) ||
+        (rc = up((void **)&c->d_delays, c->delays.data(), c->delays.size() * 4)) || (rc = up((void **)&c->d_micx, micx.data(), micx.size() * 8)) ||
+        (rc = up((void **)&c->d_pairs, c->pairs.data(), c->pairs.size() * sizeof(int2))) ||
+        (rc = zalloc((void **)&c->d_E[0], na * c->D * 4)) || (rc = zalloc((void **)&c->d_E[1], na * c->D * 4)) ||
+        (rc = zalloc((void **)&c->d_tail[0], na * c->S * FFT_H * 4)) || (rc = zalloc((void **)&c->d_tail[1], na * c->S * FFT_H * 4)) ||
+        (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
+        (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
+        g_create_error = c->err; free_ctx(c); return rc;
+    }
+    if (c->stream_ok && (rc = build_steering_table(c))) { g_create_error = c->err; free_ctx(c); return rc; }
+    *out = c;
+    return MCA_HIP_OK;
+}
+
+void mca_hip_destroy(mca_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipDeviceSynchronize();
+    free_ctx(ctx);
+}
+
+int mca_hip_num_steps(const mca_hip_ctx *c) { return c ? c->D : MCA_HIP_ERR_INVALID_ARGUMENT; }
+int mca_hip_num_pairs(const mca_hip_ctx *c) { return c ? c->P : MCA_HIP_ERR_INVALID_ARGUMENT; }
+int mca_hip_num_groups(const mca_hip_ctx *c) { return c ? c->G : MCA_HIP_ERR_INVALID_ARGUMENT; }
+
+int mca_hip_get_pair_delays(const mca_hip_ctx *c, float *out)
+{
+    if (!c || !out) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    std::memcpy(out, c->delays.data(), c->delays.size() * sizeof(float));
+    return MCA_HIP_OK;
+}
+
+int mca_hip_get_doa_grid(const mca_hip_ctx *c, float *out)
+{
+    if (!c || !out) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    std::memcpy(out, c->grid.data(), c->grid.size() * sizeof(float));
+    return MCA_HIP_OK;
+}
+
+int mca_hip_reset(mca_hip_ctx *c, void *stream)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t na = (size_t)c->cfg.max_arrays;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(c, hipMemsetAsync(c->d_E[i], 0, na * c->D * 4, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_tail[i], 0, na * c->S * FFT_H * 4, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_E64[i], 0, (size_t)c->D * 8, st));
+    }
+    return MCA_HIP_OK;
+}
+
+int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
+{
+    if (!c || n_arrays < 1 || n_frames < 1) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    long long fc = chunk_frames_for(c, n_arrays, n_frames);
+    return ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames);
+}
+
+int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
+                                float *energy, void *stream)
+{
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
+    if (rc) return rc;
+    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const long long fc = chunk_frames_for(c, n_arrays, n_frames);
+    if ((rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames))) return rc;
+
+    for (int f0 = 0; f0 < n_frames; f0 += (int)fc) {
+        const int nf = (int)std::min<long long>(fc, n_frames - f0);
+        StftPhatArgs sa{};
+        sa.pcm = pcm; sa.array_stride = array_stride; sa.mic_stride = mic_stride;
+        sa.M = c->M; sa.n_frames = nf; sa.frame0 = f0; sa.fpb = 8;
+        sa.window = c->d_window; sa.A = c->d_A; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
+        dim3 g1((nf + sa.fpb - 1) / sa.fpb, n_arrays);
+        const size_t smem1 = (size_t)c->M * FFT_SCRATCH * sizeof(float2);
+        time_begin(c, MCA_HIP_K_STFT_PHAT, st);
+        rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft<float>(c, sa, g1, smem1, st) : launch_stft<_Float16>(c, sa, g1, smem1, st);
+        time_end(c, st);
+        if (rc) return rc;
+
+        GemmArgs ga{};
+        ga.A = c->d_A; ga.B = c->d_B; ga.C = c->d_C;
+        ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
+        ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
+        dim3 g2((ga.rows + 127) / 128, c->Dp / 192);
+        time_begin(c, MCA_HIP_K_SRP_GEMM, st);
+        if (c->prec == MCA_HIP_SRP_FP32) hipLaunchKernelGGL(k_srp_gemm_f32, g2, dim3(256), 0, st, ga);
+        else if (c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL(k_srp_gemm_f16<true>, g2, dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL(k_srp_gemm_f16<false>, g2, dim3(256), 0, st, ga);
+        time_end(c, st);
+        HIP_TRY(c, hipGetLastError());
+    }
+
+    ScanPickArgs pa{};
+    pa.C = c->d_C; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S; pa.chunk = 128;
+    pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
+    pa.state_in = c->d_E[c->e_cur]; pa.state_out = c->d_E[c->e_cur ^ 1];
+    pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
+    dim3 g3((n_frames + pa.chunk - 1) / pa.chunk, n_arrays);
+    time_begin(c, MCA_HIP_K_SCAN_PICK, st);
+    hipLaunchKernelGGL(k_scan_pick, g3, dim3(round_up(c->D, 64)), 0, st, pa);
+    time_end(c, st);
+    HIP_TRY(c, hipGetLastError());
+    c->e_cur ^= 1;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, void *stream)
+{
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
+    if (rc) return rc;
+    if (!doa_rad || !out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    BeamformArgs ba{};
+    ba.pcm = pcm; ba.array_stride = array_stride; ba.mic_stride = mic_stride;
+    ba.M = c->M; ba.Mpad = c->M; ba.S = c->S; ba.n_frames = n_frames; ba.ft = 16; ba.fs = c->cfg.sample_rate;
+    ba.window = c->d_window; ba.mic_x = c->d_micx; ba.doa_rad = doa_rad; ba.out = out_pcm;
+    ba.tail_in = c->d_tail[c->tail_cur]; ba.tail_out = c->d_tail[c->tail_cur ^ 1];
+    const size_t smem = ((size_t)ba.Mpad + 8 * c->S) * FFT_SCRATCH * sizeof(float2) + MCA_MAX_SOURCES * sizeof(double);
+    if (smem > 160 * 1024) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "n_mics/n_sources combination exceeds the 160 KiB LDS of a CU");
+    if (smem > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_beamform_ola), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    dim3 g((n_frames + ba.ft - 1) / ba.ft, n_arrays);
+    time_begin(c, MCA_HIP_K_BEAMFORM, st);
+    hipLaunchKernelGGL(k_beamform_ola, g, dim3(512), smem, st, ba);
+    time_end(c, st);
+    HIP_TRY(c, hipGetLastError());
+    c->tail_cur ^= 1;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                               int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
+                               float *energy, float *out_pcm, void *stream)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!doa_rad) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev is NULL (the separation stage steers with it)");
+    int rc = mca_hip_localise_frames_dev(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, stream);
+    if (rc) return rc;
+    return mca_hip_separate_frames_dev(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, stream);
+}
+
+int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int n_frames, int *doa_bin,
+                                float *doa_rad, float *prob, float *energy, float *out_pcm)
+{
+    if (!c || !pcm || !doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const long long ms = (long long)(n_frames + 1) * FFT_H, as = ms * c->M;
+    const size_t n_pcm = (size_t)as * n_arrays, n_fs = (size_t)n_arrays * n_frames * c->S;
+    float *d_pcm = nullptr, *d_rad = nullptr, *d_prob = nullptr, *d_en = nullptr, *d_out = nullptr;
+    int *d_bin = nullptr;
+    int rc = MCA_HIP_OK;
+    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_rad); (void)hipFree(d_prob); (void)hipFree(d_en); (void)hipFree(d_out); (void)hipFree(d_bin); };
+#define TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(c, MCA_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    TRY2(hipMalloc((void **)&d_pcm, n_pcm * 4));
+    TRY2(hipMalloc((void **)&d_bin, n_fs * 4));
+    TRY2(hipMalloc((void **)&d_rad, n_fs * 4));
+    TRY2(hipMalloc((void **)&d_prob, n_fs * 4));
+    if (energy) TRY2(hipMalloc((void **)&d_en, (size_t)n_arrays * n_frames * c->D * 4));
+    if (out_pcm) TRY2(hipMalloc((void **)&d_out, (size_t)n_arrays * c->S * n_frames * FFT_H * 4));
+    TRY2(hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
+    rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
+    if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
+    if (rc) { cleanup(); return rc; }
+    TRY2(hipDeviceSynchronize());
+    TRY2(hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
+    if (doa_rad) TRY2(hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
+    if (prob) TRY2(hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
+    if (energy) TRY2(hipMemcpy(energy, d_en, (size_t)n_arrays * n_frames * c->D * 4, hipMemcpyDeviceToHost));
+    if (out_pcm) TRY2(hipMemcpy(out_pcm, d_out, (size_t)n_arrays * c->S * n_frames * FFT_H * 4, hipMemcpyDeviceToHost));
+#undef TRY2
+    cleanup();
+    return MCA_HIP_OK;
+}
+
+// ---- frame API ---------------------------------------------------------------------------
+static int upload_frames(mca_hip_ctx *c, const double *const *frames, int ccs_len)
+{
+    if (!frames) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "frames is NULL");
+    if (ccs_len != c->N + 2) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "ccs_len != fft_size + 2");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t n = (size_t)c->M * ccs_len;
+    if (c->fr_elems < n) {
+        if (c->d_fr) (void)hipFree(c->d_fr);
+        c->d_fr = nullptr; c->fr_elems = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_fr, n * 8));
+        c->fr_elems = n;
+    }
+    // SignalVector = one separate allocation per channel (mcadefs.h:86-88): gather, then one copy
+    c->h_stage.resize(n);
+    for (int m = 0; m < c->M; ++m) {
+        if (!frames[m]) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "frames[c] is NULL");
+        std::memcpy(c->h_stage.data() + (size_t)m * ccs_len, frames[m], (size_t)ccs_len * 8);
+    }
+    HIP_TRY(c, hipMemcpy(c->d_fr, c->h_stage.data(), n * 8, hipMemcpyHostToDevice));
+    return MCA_HIP_OK;
+}
+
+int mca_hip_steering_process_frame(mca_hip_ctx *c, const double *const *frames, int ccs_len, double *DOA,
+                                   double *prob, int *doa_bin, int n_sources)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (n_sources < 1 || n_sources > MCA_MAX_SOURCES) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_sources must be in [1,4]");
+    if (!DOA || !prob) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "DOA/prob is NULL");
+    int rc = upload_frames(c, frames, ccs_len);
+    if (rc) return rc;
+    const float memf = 0.8f;                                                  // SteeringBeamforming.h:70
+    const double mu = (double)memf, omu = (double)(1 - memf);
+    double *Ein = c->d_E64[c->e64_cur], *Eout = c->d_E64[c->e64_cur ^ 1];
+    hipLaunchKernelGGL(k_frame_srp<double>, dim3(c->D), dim3(256), 0, 0, reinterpret_cast<const C2<double> *>(c->d_fr), c->K, c->D,
+                       c->P, c->d_pairs, c->d_delays, Ein, Eout, mu, omu);
+    hipLaunchKernelGGL(k_frame_pick<double>, dim3(1), dim3(512), 0, 0, Eout, c->D, c->P, n_sources, c->d_grid, c->d_res,
+                       c->d_res + MCA_MAX_SOURCES, c->d_bins);
+    HIP_TRY(c, hipGetLastError());
+    c->e64_cur ^= 1;
+    double res[2 * MCA_MAX_SOURCES]; int bins[MCA_MAX_SOURCES];
+    HIP_TRY(c, hipMemcpy(res, c->d_res, sizeof(res), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(bins, c->d_bins, sizeof(bins), hipMemcpyDeviceToHost));
+    for (int s = 0; s < n_sources; ++s) {
+        DOA[s] = res[s]; prob[s] = res[MCA_MAX_SOURCES + s];
+        if (doa_bin) doa_bin[s] = bins[s];
+    }
+    return MCA_HIP_OK;
+}
+
+int mca_hip_beamformer_process_frame(mca_hip_ctx *c, const double *const *frames, int ccs_len, double *out, double DOA)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
+    int rc = upload_frames(c, frames, ccs_len);
+    if (rc) return rc;
+    if (c->out64_elems < (size_t)ccs_len) {
+        if (c->d_out64) (void)hipFree(c->d_out64);
+        c->d_out64 = nullptr; c->out64_elems = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_out64, (size_t)ccs_len * 8));
+        c->out64_elems = ccs_len;
+    }
+    hipLaunchKernelGGL(k_frame_beamform<double>, dim3((c->K + 255) / 256), dim3(256), 0, 0,
+                       reinterpret_cast<const C2<double> *>(c->d_fr), c->M, c->K, c->cfg.sample_rate, c->d_micx, DOA,
+                       reinterpret_cast<C2<double> *>(c->d_out64));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(out, c->d_out64, (size_t)ccs_len * 8, hipMemcpyDeviceToHost));
+    return MCA_HIP_OK;
+}
+
+int mca_hip_fft_log_power(mca_hip_ctx *c, const double *const *frames, int ccs_len, double *power_db)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!power_db) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "power_db is NULL");
+    int rc = upload_frames(c, frames, ccs_len);
+    if (rc) return rc;
+    double *dp = c->d_res + 2 * MCA_MAX_SOURCES;
+    hipLaunchKernelGGL(k_frame_power<double>, dim3(1), dim3(256), 0, 0, reinterpret_cast<const C2<double> *>(c->d_fr), c->M, c->K, dp);
+    HIP_TRY(c, hipGetLastError());
+    double lin = 0;
+    HIP_TRY(c, hipMemcpy(&lin, dp, 8, hipMemcpyDeviceToHost));
+    *power_db = 10.0 * std::log10(lin);
+    return MCA_HIP_OK;
+}
+
+int mca_hip_get_energy(mca_hip_ctx *c, double *out)
+{
+    if (!c || !out) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpy(out, c->d_E64[c->e64_cur], (size_t)c->D * 8, hipMemcpyDeviceToHost));
+    return MCA_HIP_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------
+int mca_hip_set_timing(mca_hip_ctx *c, int enable)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    c->timing = enable != 0;
+    return MCA_HIP_OK;
+}
+
+static int drain_events(mca_hip_ctx *c)
+{
+    for (auto &e : c->events) {
+        HIP_TRY(c, hipEventSynchronize(e.b));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
+        c->t_ms[e.id] += ms; c->t_launches[e.id] += 1;
+        c->pool.push_back(e.a); c->pool.push_back(e.b);
+    }
+    c->events.clear();
+    return MCA_HIP_OK;
+}
+
+int mca_hip_get_timing(mca_hip_ctx *c, int kernel_id, int *launches, double *total_ms)
+{
+    if (!c || kernel_id < 0 || kernel_id >= MCA_HIP_K_COUNT) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    int rc = drain_events(c);
+    if (rc) return rc;
+    if (launches) *launches = c->t_launches[kernel_id];
+    if (total_ms) *total_ms = c->t_ms[kernel_id];
+    return MCA_HIP_OK;
+}
+
+int mca_hip_reset_timing(mca_hip_ctx *c)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    int rc = drain_events(c);
+    for (int i = 0; i < MCA_HIP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_launches[i] = 0; }
+    return rc;
+}
+
+}  // extern "C"

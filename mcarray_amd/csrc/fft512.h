@@ -1,0 +1,227 @@
+// fft512.h -- wave-level 1024-point real FFT / inverse for gfx950 (one 64-lane wave per transform).
+//
+// A 1024-point real transform is done as a 512-point complex transform of the packed
+// sequence z[m] = x[2m] + j x[2m+1] plus a split step.  512 = 8*8*8: every lane owns 8
+// complex points and does three radix-8 butterflies in registers; between them the wave
+// exchanges data through its own LDS scratch (two transposes).  The LDS layouts
+// (row stride 72 complex words, inner stride 9 in the second exchange) make every
+// ds_write_b64 / ds_read_b64 of the exchanges bank-conflict free (MI355X LDS: 64 banks x 4 B;
+// b64 reads are serviced in two 32-lane groups, b64 writes in four 16-lane groups).
+//
+// Replaces the FFT that DSPONE's dsp::STFT performs before handing frames to
+// processParametrisation (call sites SourceSeparationAndLocalisation.cpp:52,
+// FastBinauralMasking.cpp:57); conventions per SURVEY A.1: unnormalised forward,
+// 1/N inverse, CCS bin order k = 0..N/2.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mca {
+
+constexpr int FFT_N = 1024;          // real transform length
+constexpr int FFT_H = 512;           // complex half-length
+constexpr int FFT_K = 513;           // one-sided bins
+constexpr int FFT_SCRATCH = 576;     // float2 words of LDS scratch per wave (8 rows x 72)
+constexpr int FFT_ROW = 72;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b)  // a * conj(b)
+{
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// exp(-j*2*pi*num/den) for forward (INV = false), conjugate for inverse.
+__device__ __forceinline__ float2 twiddle(int num, int den, bool inv)
+{
+    float s, c;
+    sincospif(2.0f * (float)num / (float)den, &s, &c);
+    return make_float2(c, inv ? s : -s);
+}
+
+// In-register 8-point DFT (decimation in frequency).  Output index of register i is
+// bitrev3(i): {0,4,2,6,1,5,3,7}.
+template <bool INV>
+__device__ __forceinline__ void fft8(float2 (&v)[8])
+{
+    constexpr float R = 0.70710678118654752440f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float2 a = cadd(v[r], v[r + 4]);
+        float2 b = csub(v[r], v[r + 4]);
+        v[r] = a;
+        if (r == 0) v[r + 4] = b;
+        else if (r == 1) v[r + 4] = INV ? make_float2((b.x - b.y) * R, (b.x + b.y) * R)
+                                        : make_float2((b.x + b.y) * R, (b.y - b.x) * R);
+        else if (r == 2) v[r + 4] = INV ? make_float2(-b.y, b.x) : make_float2(b.y, -b.x);
+        else v[r + 4] = INV ? make_float2((-b.x - b.y) * R, (b.x - b.y) * R)
+                            : make_float2((b.y - b.x) * R, (-b.x - b.y) * R);
+    }
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+        float2 a0 = cadd(v[h], v[h + 2]), b0 = csub(v[h], v[h + 2]);
+        float2 a1 = cadd(v[h + 1], v[h + 3]), b1 = csub(v[h + 1], v[h + 3]);
+        v[h] = a0; v[h + 1] = a1; v[h + 2] = b0;
+        v[h + 3] = INV ? make_float2(-b1.y, b1.x) : make_float2(b1.y, -b1.x);
+    }
+#pragma unroll
+    for (int h = 0; h < 8; h += 2) {
+        float2 a = cadd(v[h], v[h + 1]), b = csub(v[h], v[h + 1]);
+        v[h] = a; v[h + 1] = b;
+    }
+}
+
+__device__ __forceinline__ constexpr int br3(int i) { return ((i & 1) << 2) | (i & 2) | ((i >> 2) & 1); }
+
+// Per-lane twiddle set (forward values; the inverse uses their conjugates), computed once per
+// kernel and kept in registers.
+struct FftTw {
+    float2 t1[8];   // W512^(lane*q)
+    float2 t2[8];   // W64^((lane&7)*s)
+    float2 ts[5];   // split step: W1024^(lane + 64 i), i = 0..4 (i = 4 only used by lane 0, k = 256)
+    __device__ __forceinline__ void init(int lane)
+    {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t1[q] = twiddle((lane * q) & 511, 512, false);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) t2[s] = twiddle(((lane & 7) * s) & 63, 64, false);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ts[i] = twiddle(lane + 64 * i, 1024, false);
+    }
+};
+
+// wave-level ordering of LDS traffic: LDS instructions of one wave execute in order, so only
+// the compiler has to be kept from reordering across the exchange points.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 512-point complex FFT of v[r] = z[lane + 64 r]; result Z[k] is written in natural order to
+// buf[k], k = 0..511 (buf = this wave's scratch, FFT_SCRATCH words).
+template <bool INV>
+__device__ __forceinline__ void cfft512_to_lds(float2 (&v)[8], float2 *buf, int lane, const FftTw &tw)
+{
+    // stage A: DFT over r, twiddle W512^(lane*q), exchange 1: buf[q*72 + lane]
+    fft8<INV>(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = br3(i);
+        buf[q * FFT_ROW + lane] = (q == 0) ? v[i] : (INV ? cmulc(v[i], tw.t1[q]) : cmul(v[i], tw.t1[q]));
+    }
+    wave_lds_fence();
+    const int qq = lane >> 3, l0 = lane & 7;
+#pragma unroll
+    for (int l1 = 0; l1 < 8; ++l1) v[l1] = buf[qq * FFT_ROW + l0 + 8 * l1];
+    wave_lds_fence();
+    // stage B: DFT over l1, twiddle W64^(l0*s), exchange 2: buf[q*72 + 9*l0 + s]
+    fft8<INV>(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = br3(i);
+        buf[qq * FFT_ROW + 9 * l0 + s] = (s == 0) ? v[i] : (INV ? cmulc(v[i], tw.t2[s]) : cmul(v[i], tw.t2[s]));
+    }
+    wave_lds_fence();
+    const int ss = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = buf[qq * FFT_ROW + 9 * j + ss];
+    wave_lds_fence();
+    // stage C: DFT over l0 -> t ; k = q + 8 s + 64 t
+    fft8<INV>(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[qq + 8 * ss + 64 * br3(i)] = v[i];
+    wave_lds_fence();
+}
+
+// Forward real FFT.  v[r] = (x[2m], x[2m+1]) (already windowed), m = lane + 64 r.
+// On return buf[k], k = 0..512, holds X[k] (buf must have >= FFT_SCRATCH words; word 512 is used).
+__device__ __forceinline__ void rfft1024(float2 (&v)[8], float2 *buf, int lane, const FftTw &tw)
+{
+    cfft512_to_lds<false>(v, buf, lane, tw);
+    // split step, in place on pairs (k, 512-k):  X[k] = a + W b,  X[512-k] = conj(a - W b),
+    // a = (Z[k] + conj Z[512-k])/2,  b = -j (Z[k] - conj Z[512-k])/2,  W = W1024^k.
+    float2 xk[4], xp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        float2 zk = buf[k];
+        float2 zp = buf[(512 - k) & 511];
+        float2 a = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));
+        float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));   // (Z[k] - conj Zp)/2
+        float2 b = make_float2(d.y, -d.x);                                      // -j d
+        float2 wb = cmul(tw.ts[i], b);
+        xk[i] = cadd(a, wb);
+        xp[i] = cconj(csub(a, wb));
+    }
+    float2 z256 = buf[256];
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        buf[k] = xk[i];
+        buf[512 - k] = xp[i];      // k = 0 writes X[512]
+    }
+    if (lane == 0) {
+        // k = 256: Zp = Zk, W = -j:  a = (Re z, 0), b = -j (0, Im z) = (Im z, 0); X = a + W b = (Re z, -Im z)
+        buf[256] = make_float2(z256.x, -z256.y);
+    }
+    wave_lds_fence();
+}
+
+// Inverse real FFT.  buf[k], k = 0..512 holds X[k] (imaginary parts of X[0] and X[512] are
+// ignored, like a CCS->real inverse).  On return buf[m] = (x[2m], x[2m+1]), m = 0..511,
+// scaled by 1/1024 overall.
+__device__ __forceinline__ void irfft1024(float2 *buf, int lane, const FftTw &tw)
+{
+    // build Z[k] = a + j b, Z[512-k] = conj(a) + j conj(b) with a = (X[k] + conj X[512-k])/2,
+    // b = conj(W1024^k) (X[k] - conj X[512-k])/2.
+    float2 zk[4], zp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        float2 xk = buf[k];
+        float2 xp = buf[512 - k];
+        if (k == 0) { xk.y = 0.f; xp.y = 0.f; }
+        float2 a = make_float2(0.5f * (xk.x + xp.x), 0.5f * (xk.y - xp.y));
+        float2 d = make_float2(0.5f * (xk.x - xp.x), 0.5f * (xk.y + xp.y));
+        float2 b = cmulc(d, tw.ts[i]);
+        zk[i] = make_float2(a.x - b.y, a.y + b.x);          // a + j b
+        zp[i] = make_float2(a.x + b.y, -a.y + b.x);         // conj(a) + j conj(b)
+    }
+    float2 x256 = buf[256];
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        if (k != 0) buf[512 - k] = zp[i];
+        buf[k] = zk[i];
+    }
+    if (lane == 0) {
+        // k = 256: a = (Re x, 0), d = (0, Im x), b = conj(W) d = (+j)(0, Im x) = (-Im x, 0); Z = a + j b = (Re x, -Im x)
+        buf[256] = make_float2(x256.x, -x256.y);
+    }
+    wave_lds_fence();
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
+    wave_lds_fence();
+    cfft512_to_lds<true>(v, buf, lane, tw);
+    const float sc = 1.0f / 512.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float2 z = buf[lane + 64 * r];
+        v[r] = make_float2(z.x * sc, z.y * sc);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
+    wave_lds_fence();
+}
+
+}  // namespace mca

@@ -1,0 +1,24 @@
+// kernels.h -- declarations of the kernels defined in kernels_*.hip (explicitly instantiated there).
+#pragma once
+#include "mca_internal.h"
+
+namespace mca {
+
+template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat(StftPhatArgs p);
+__global__ void k_scan_pick(ScanPickArgs p);
+__global__ void k_beamform_ola(BeamformArgs p);
+
+__global__ void k_srp_gemm_f32(GemmArgs p);
+template <bool SPLIT> __global__ void k_srp_gemm_f16(GemmArgs p);
+
+template <typename T> struct C2;
+template <typename T>
+__global__ void k_frame_srp(const C2<T> *X, int K, int D, int P, const int2 *pairs, const float *delays,
+                            const T *E_in, T *E_out, T mu, T omu);
+template <typename T>
+__global__ void k_frame_pick(const T *E, int D, int P, int S, const float *grid, T *doa, T *prob, int *bins);
+template <typename T>
+__global__ void k_frame_beamform(const C2<T> *X, int M, int K, int fs, const double *mic_x, double doa, C2<T> *Y);
+template <typename T> __global__ void k_frame_power(const C2<T> *X, int M, int K, T *out);
+
+}  // namespace mca

@@ -1,0 +1,202 @@
+// kernels_gemm.hip -- the SRP-PHAT steering scan as a dense contraction on the matrix cores.
+//
+//   C[f][d] = sum_{g,k} ( Re Ghat_g[f][k] cos(phi_{g,d,k}) - Im Ghat_g[f][k] sin(phi_{g,d,k}) )
+//           = A[f][:] . B[:][d]          A: [frames][Kp]  (k_stft_phat),  B: steering table (host)
+//
+// which is sum_p R_p[d] of SteeringBeamforming::computeCorrelations (SteeringBeamforming.cpp:104-130)
+// with pairs of identical delay tables pre-summed.  D = 361 angles x depth 7182 (8-mic ULA) makes
+// this >95 % of the path's flops and compute-bound, so it is the one stage on MFMA.
+//
+//   k_srp_gemm_f32   v_mfma_f32_32x32x2_f32: bit-exact fp32 fma chain, parity anchor
+//   k_srp_gemm_f16   v_mfma_f32_32x32x16_f16 with 1 (fp16) or 3 (fp16x3 hi/lo split) products
+#include "mca_internal.h"
+
+namespace mca {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------
+// fp32: block tile 128 frames x 192 angles, 4 waves as 2 x 2, wave tile 64 x 96 = 2 x 3 MFMA
+// tiles (96 accumulator VGPRs).  BK = 16; global -> registers -> LDS with the next tile's
+// loads in flight during the MFMAs.  A is stored transposed in LDS ([k][row]) so that both
+// operand reads are conflict-free ds_read_b32.
+// ---------------------------------------------------------------------------------------
+constexpr int G32_BM = 128, G32_BN = 192, G32_BK = 16;
+
+__global__ __launch_bounds__(256) void k_srp_gemm_f32(GemmArgs p)
+{
+    __shared__ float As[G32_BK][G32_BM + 4];
+    __shared__ float Bs[G32_BK][G32_BN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0 = blockIdx.x * G32_BM, col0 = blockIdx.y * G32_BN;
+    const float *A = reinterpret_cast<const float *>(p.A);
+    const float *B = reinterpret_cast<const float *>(p.B);
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ar = tid >> 2, akq = tid & 3;
+    const int arow_a = min(row0 + ar, p.rows - 1), arow_b = min(row0 + ar + 64, p.rows - 1);
+    const float *pa0 = A + (long long)arow_a * p.a_row_elems + akq * 4;
+    const float *pa1 = A + (long long)arow_b * p.a_row_elems + akq * 4;
+    const int bkr[3] = {tid / 48, (tid + 256) / 48, (tid + 512) / 48};
+    const int bc4[3] = {tid % 48, (tid + 256) % 48, (tid + 512) % 48};
+
+    float4 ra0, ra1, rb0, rb1, rb2;
+    const float *pb0 = B + (long long)bkr[0] * p.Dp + col0 + bc4[0] * 4;
+    const float *pb1 = B + (long long)bkr[1] * p.Dp + col0 + bc4[1] * 4;
+    const float *pb2 = B + (long long)bkr[2] * p.Dp + col0 + bc4[2] * 4;
+#define G32_GLOAD(k0)                                                        \
+    do {                                                                     \
+        ra0 = *reinterpret_cast<const float4 *>(pa0 + (k0));                 \
+        ra1 = *reinterpret_cast<const float4 *>(pa1 + (k0));                 \
+        rb0 = *reinterpret_cast<const float4 *>(pb0 + (long long)(k0) * p.Dp); \
+        rb1 = *reinterpret_cast<const float4 *>(pb1 + (long long)(k0) * p.Dp); \
+        rb2 = *reinterpret_cast<const float4 *>(pb2 + (long long)(k0) * p.Dp); \
+    } while (0)
+    G32_GLOAD(0);
+    const int nk = p.Kp / G32_BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        As[akq * 4 + 0][ar] = ra0.x; As[akq * 4 + 1][ar] = ra0.y; As[akq * 4 + 2][ar] = ra0.z; As[akq * 4 + 3][ar] = ra0.w;
+        As[akq * 4 + 0][ar + 64] = ra1.x; As[akq * 4 + 1][ar + 64] = ra1.y; As[akq * 4 + 2][ar + 64] = ra1.z; As[akq * 4 + 3][ar + 64] = ra1.w;
+        *reinterpret_cast<float4 *>(&Bs[bkr[0]][bc4[0] * 4]) = rb0;
+        *reinterpret_cast<float4 *>(&Bs[bkr[1]][bc4[1] * 4]) = rb1;
+        *reinterpret_cast<float4 *>(&Bs[bkr[2]][bc4[2] * 4]) = rb2;
+        __syncthreads();
+        if (kt + 1 < nk) G32_GLOAD((kt + 1) * G32_BK);
+#pragma unroll
+        for (int kk = 0; kk < G32_BK; kk += 2) {
+            const int kl = kk + (lane >> 5);
+            float af[2], bf[3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[kl][wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bf[j] = Bs[kl][wn * 96 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int frow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (frow < p.rows) {
+                const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
+                float *crow = p.C + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * 96 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) crow[j * 32] = acc[i][j][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// fp16 operands, fp32 accumulate: v_mfma_f32_32x32x16_f16.  A: [rows][planes*Kp] halves
+// (k contiguous, lo plane after hi plane), B: [planes][Dp][Kp] halves (k contiguous).
+// Block tile 128 x 192, 4 waves as 2 x 2, BK = 32 halves.  Fragments: lane l holds
+// A[row l&31][k = 8 (l>>5) + 0..7] (one 16-byte LDS read).  LDS rows are 64 B + 16 B pad
+// (stride 80 B): ds_read_b128 of 16-lane groups then covers all 64 banks without conflict
+// (rows r..r+15 at stride 20 dwords hit distinct 4-bank slots).
+// SPLIT = false: C += Ahi Bhi.   SPLIT = true: C += Ahi Bhi + Alo Bhi + Ahi Blo  (~fp32 accuracy).
+// ---------------------------------------------------------------------------------------
+constexpr int G16_BM = 128, G16_BN = 192, G16_BK = 32, G16_LD = 40;   // LD in halves (80 B)
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
+{
+    constexpr int NP = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) _Float16 As[NP][G16_BM][G16_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[NP][G16_BN][G16_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0 = blockIdx.x * G16_BM, col0 = blockIdx.y * G16_BN;
+    const _Float16 *A = reinterpret_cast<const _Float16 *>(p.A);
+    const _Float16 *B = reinterpret_cast<const _Float16 *>(p.B);
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // global loads: 16 B = 8 halves per thread; a BK=32 row is 64 B = 4 chunks.
+    // A tile: 128 rows x 4 chunks = 512 chunks -> 2 per thread; B tile: 192 x 4 = 768 -> 3 per thread.
+    const int lr = tid >> 2, lc = tid & 3;
+    f16x8 ra[NP][2], rb[NP][3];
+    const int ar0 = min(row0 + lr, p.rows - 1), ar1 = min(row0 + lr + 64, p.rows - 1);
+#define G16_GLOAD(k0)                                                                                                          \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                                                        \
+        ra[pl][0] = *reinterpret_cast<const f16x8 *>(A + (long long)ar0 * p.a_row_elems + pl * p.Kp + (k0) + lc * 8);          \
+        ra[pl][1] = *reinterpret_cast<const f16x8 *>(A + (long long)ar1 * p.a_row_elems + pl * p.Kp + (k0) + lc * 8);          \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                                          \
+            rb[pl][i] = *reinterpret_cast<const f16x8 *>(B + ((long long)pl * p.Dp + col0 + lr + 64 * i) * p.Kp + (k0) + lc * 8); \
+    }
+    G16_GLOAD(0)
+    const int nk = p.Kp / G16_BK;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            *reinterpret_cast<f16x8 *>(&As[pl][lr][lc * 8]) = ra[pl][0];
+            *reinterpret_cast<f16x8 *>(&As[pl][lr + 64][lc * 8]) = ra[pl][1];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<f16x8 *>(&Bs[pl][lr + 64 * i][lc * 8]) = rb[pl][i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) { G16_GLOAD((kt + 1) * G16_BK) }
+#pragma unroll
+        for (int kk = 0; kk < G16_BK; kk += 16) {
+            const int ko = kk + 8 * (lane >> 5);
+            f16x8 af[NP][2], bf[NP][3];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[pl][i] = *reinterpret_cast<const f16x8 *>(&As[pl][wm * 64 + i * 32 + (lane & 31)][ko]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bf[pl][j] = *reinterpret_cast<const f16x8 *>(&Bs[pl][wn * 96 + j * 32 + (lane & 31)][ko]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if constexpr (SPLIT) {
+                        // small terms first so they are not absorbed by the large partial sum
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int frow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (frow < p.rows) {
+                const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
+                float *crow = p.C + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * 96 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) crow[j * 32] = acc[i][j][r];
+            }
+        }
+}
+
+template __global__ void k_srp_gemm_f16<false>(GemmArgs);
+template __global__ void k_srp_gemm_f16<true>(GemmArgs);
+
+}  // namespace mca
