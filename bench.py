@@ -34,16 +34,19 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0}   # dense MFMA p
 PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2}
 
 
-def synth_batch(n_arrays, n_frames, device, seed):
-    """Far-field white source per array + 20 dB sensor noise, generated on the GPU."""
+def synth_batch(seeds, n_frames, device):
+    """Far-field white source per array + 20 dB sensor noise, generated on the GPU.
+    One seed per array, derived from the array's GLOBAL index, so its data does not depend on the rank count."""
     from mcarray_amd import synth
+    n_arrays = len(seeds)
     L = (n_frames + 1) * HOP
-    gen = torch.Generator(device=device).manual_seed(seed)
     xs = torch.tensor(synth.ULA8, device=device, dtype=torch.float64)
-    theta = (torch.rand(n_arrays, device=device, dtype=torch.float64, generator=gen) * 160.0 - 80.0) * (np.pi / 180.0)
+    theta = torch.empty(n_arrays, device=device, dtype=torch.float64)
     out = torch.empty(n_arrays, M, L, device=device, dtype=torch.float32)
     f = torch.fft.rfftfreq(L, d=1.0 / FS).to(device=device, dtype=torch.float64)
     for a in range(n_arrays):   # one array at a time keeps the fp64 temporaries small
+        gen = torch.Generator(device=device).manual_seed(seeds[a])
+        theta[a] = (torch.rand(1, device=device, dtype=torch.float64, generator=gen)[0] * 160.0 - 80.0) * (np.pi / 180.0)
         s = torch.randn(L, device=device, dtype=torch.float64, generator=gen) * 0.1
         S = torch.fft.rfft(s)
         adv = xs * torch.sin(theta[a]) / 346.1
@@ -91,8 +94,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from mcarray_amd import api, synth
+    from mcarray_amd import dist as mdist
     A, F = args.arrays, args.frames
-    pcm, theta = synth_batch(A, F, dev, 0x5EED0000 + rank)
+    mine = mdist.local_range(A * world, rank, world)          # this rank's block of the global array list
+    pcm, theta = synth_batch([mdist.array_seed(0x5EED0000, g) for g in mine], F, dev)
     ctx = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=A, device=local_rank)
     assert ctx.D == D and ctx.P == P
     ctx.reserve(A, F)
@@ -100,15 +105,15 @@ def main():
     doa_rad = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
     prob = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
     out = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
-    gathered_bin = [torch.empty_like(doa_bin) for _ in range(world)] if world > 1 else None
-    gathered_prob = [torch.empty_like(prob) for _ in range(world)] if world > 1 else None
+    all_bin = torch.empty(A * world, F, 1, dtype=torch.int32, device=dev) if world > 1 else None
+    all_prob = torch.empty(A * world, F, 1, dtype=torch.float32, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=stream)
         if world > 1:   # the only exchange of the path: gather DOA buffers (RCCL over xGMI)
-            dist.all_gather(gathered_bin, doa_bin)
-            dist.all_gather(gathered_prob, prob)
+            dist.all_gather_into_tensor(all_bin, doa_bin)
+            dist.all_gather_into_tensor(all_prob, prob)
 
     for _ in range(args.warmup):
         step()

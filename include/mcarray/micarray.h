@@ -1,0 +1,13 @@
+// umbrella header (reference include/mcarray/micarray.h)
+#ifndef MCA_HIP_MICARRAY_H
+#define MCA_HIP_MICARRAY_H
+#include "ArrayDescription.h"
+#include "Beamformer.h"
+#include "BeamformingSeparationAndLocalistaion.h"
+#include "SoundLocalisationCallback.h"
+#include "SourceSeparationAndLocalisation.h"
+#include "SteeringBeamforming.h"
+#include "mcadefs.h"
+#include "mcarray_exception.h"
+#include "microhponeArrayHelpers.h"
+#endif
