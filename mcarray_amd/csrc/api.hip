@@ -404,7 +404,7 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         sa.M = c->M; sa.n_frames = nf; sa.frame0 = f0; sa.fpb = 8;
         sa.window = c->d_window; sa.A = c->d_A; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
         dim3 g1((nf + sa.fpb - 1) / sa.fpb, n_arrays);
-        const size_t smem1 = (size_t)c->M * FFT_SCRATCH * sizeof(float2);
+        const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2);
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft<float>(c, sa, g1, smem1, st) : launch_stft<_Float16>(c, sa, g1, smem1, st);
         time_end(c, st);
@@ -424,13 +424,13 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     }
 
     ScanPickArgs pa{};
-    pa.C = c->d_C; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S; pa.chunk = 128;
+    pa.C = c->d_C; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S; pa.chunk = c->Dp > 384 ? 16 : 32;
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
     pa.state_in = c->d_E[c->e_cur]; pa.state_out = c->d_E[c->e_cur ^ 1];
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
     dim3 g3((n_frames + pa.chunk - 1) / pa.chunk, n_arrays);
     time_begin(c, MCA_HIP_K_SCAN_PICK, st);
-    hipLaunchKernelGGL(k_scan_pick, g3, dim3(round_up(c->D, 64)), 0, st, pa);
+    hipLaunchKernelGGL(k_scan_pick, g3, dim3(round_up(c->D, 64)), (size_t)pa.chunk * (c->Dp + 8) * sizeof(float), st, pa);
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
     c->e_cur ^= 1;
@@ -449,13 +449,21 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     ba.M = c->M; ba.Mpad = c->M; ba.S = c->S; ba.n_frames = n_frames; ba.ft = 16; ba.fs = c->cfg.sample_rate;
     ba.window = c->d_window; ba.mic_x = c->d_micx; ba.doa_rad = doa_rad; ba.out = out_pcm;
     ba.tail_in = c->d_tail[c->tail_cur]; ba.tail_out = c->d_tail[c->tail_cur ^ 1];
-    const size_t smem = ((size_t)ba.Mpad + 8 * c->S) * FFT_SCRATCH * sizeof(float2) + MCA_MAX_SOURCES * sizeof(double);
+    const size_t smem = ((size_t)ba.M + BF_NB * c->S) * FFT_SCRATCH * sizeof(float2) + (size_t)c->S * c->M * 49 * sizeof(float2) +
+                        TW_WORDS * sizeof(float2) + (size_t)BF_NB * c->M * (1 + c->S) * sizeof(float2) +
+                        (size_t)(ba.ft + 1) * c->S * sizeof(double);
     if (smem > 160 * 1024) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "n_mics/n_sources combination exceeds the 160 KiB LDS of a CU");
-    if (smem > 64 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_beamform_ola), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 g((n_frames + ba.ft - 1) / ba.ft, n_arrays);
     time_begin(c, MCA_HIP_K_BEAMFORM, st);
-    hipLaunchKernelGGL(k_beamform_ola, g, dim3(512), smem, st, ba);
+    if (c->M <= 8) {
+        if (smem > 64 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_ola<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k_beamform_ola<1>, g, dim3(512), smem, st, ba);
+    } else {
+        if (smem > 64 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_ola<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k_beamform_ola<2>, g, dim3(512), smem, st, ba);
+    }
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
     c->tail_cur ^= 1;

@@ -77,22 +77,36 @@ __device__ __forceinline__ void fft8(float2 (&v)[8])
 
 __device__ __forceinline__ constexpr int br3(int i) { return ((i & 1) << 2) | (i & 2) | ((i >> 2) & 1); }
 
-// Per-lane twiddle set (forward values; the inverse uses their conjugates), computed once per
-// kernel and kept in registers.
+// Twiddle + window table shared by all waves of a workgroup, in LDS (read-only after init):
+//   t1[q][lane] = W512^(lane*q)        q = 0..7   (index q*64 + lane)
+//   t2[s][l0]   = W64^(l0*s)           s, l0 = 0..7 (index 512 + s*8 + l0)
+//   ts[i][lane] = W1024^(lane + 64 i)  i = 0..3   (index 576 + i*64 + lane)
+//   win[r][lane] = (w[2m], w[2m+1]), m = lane + 64 r (index 832 + r*64 + lane), periodic Hann
+// Forward values; the inverse transform uses their conjugates.  Every read is lane-contiguous
+// (conflict-free) or a broadcast.  Keeping them here instead of in registers frees ~58 VGPRs per
+// lane, which is what lets two 512-thread workgroups share a CU.
+constexpr int TW_T1 = 0, TW_T2 = 512, TW_TS = 576, TW_WIN = 832, TW_WORDS = 1344;   // float2 words
+
 struct FftTw {
-    float2 t1[8];   // W512^(lane*q)
-    float2 t2[8];   // W64^((lane&7)*s)
-    float2 ts[5];   // split step: W1024^(lane + 64 i), i = 0..4 (i = 4 only used by lane 0, k = 256)
-    __device__ __forceinline__ void init(int lane)
-    {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t1[q] = twiddle((lane * q) & 511, 512, false);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) t2[s] = twiddle(((lane & 7) * s) & 63, 64, false);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) ts[i] = twiddle(lane + 64 * i, 1024, false);
-    }
+    const float2 *tab;
+    __device__ __forceinline__ float2 t1(int q, int lane) const { return tab[TW_T1 + q * 64 + lane]; }
+    __device__ __forceinline__ float2 t2(int s, int lane) const { return tab[TW_T2 + s * 8 + (lane & 7)]; }
+    __device__ __forceinline__ float2 ts(int i, int lane) const { return tab[TW_TS + i * 64 + lane]; }
+    __device__ __forceinline__ float2 win(int r, int lane) const { return tab[TW_WIN + r * 64 + lane]; }
 };
+
+// fill the table (all threads of the block; caller must __syncthreads() afterwards)
+__device__ __forceinline__ void fft_table_init(float2 *tab, const float *window, int tid, int nthreads)
+{
+    for (int e = tid; e < TW_WIN; e += nthreads) {
+        float2 v;
+        if (e < TW_T2) { const int q = e >> 6, l = e & 63; v = twiddle((l * q) & 511, 512, false); }
+        else if (e < TW_TS) { const int s = (e - TW_T2) >> 3, l0 = (e - TW_T2) & 7; v = twiddle((l0 * s) & 63, 64, false); }
+        else { const int i = (e - TW_TS) >> 6, l = (e - TW_TS) & 63; v = twiddle(l + 64 * i, 1024, false); }
+        tab[e] = v;
+    }
+    for (int e = tid; e < 512; e += nthreads) tab[TW_WIN + e] = reinterpret_cast<const float2 *>(window)[e];
+}
 
 // wave-level ordering of LDS traffic: LDS instructions of one wave execute in order, so only
 // the compiler has to be kept from reordering across the exchange points.
@@ -113,7 +127,7 @@ __device__ __forceinline__ void cfft512_to_lds(float2 (&v)[8], float2 *buf, int 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int q = br3(i);
-        buf[q * FFT_ROW + lane] = (q == 0) ? v[i] : (INV ? cmulc(v[i], tw.t1[q]) : cmul(v[i], tw.t1[q]));
+        buf[q * FFT_ROW + lane] = (q == 0) ? v[i] : (INV ? cmulc(v[i], tw.t1(q, lane)) : cmul(v[i], tw.t1(q, lane)));
     }
     wave_lds_fence();
     const int qq = lane >> 3, l0 = lane & 7;
@@ -125,7 +139,7 @@ __device__ __forceinline__ void cfft512_to_lds(float2 (&v)[8], float2 *buf, int 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int s = br3(i);
-        buf[qq * FFT_ROW + 9 * l0 + s] = (s == 0) ? v[i] : (INV ? cmulc(v[i], tw.t2[s]) : cmul(v[i], tw.t2[s]));
+        buf[qq * FFT_ROW + 9 * l0 + s] = (s == 0) ? v[i] : (INV ? cmulc(v[i], tw.t2(s, lane)) : cmul(v[i], tw.t2(s, lane)));
     }
     wave_lds_fence();
     const int ss = lane & 7;
@@ -155,7 +169,7 @@ __device__ __forceinline__ void rfft1024(float2 (&v)[8], float2 *buf, int lane, 
         float2 a = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));
         float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));   // (Z[k] - conj Zp)/2
         float2 b = make_float2(d.y, -d.x);                                      // -j d
-        float2 wb = cmul(tw.ts[i], b);
+        float2 wb = cmul(tw.ts(i, lane), b);
         xk[i] = cadd(a, wb);
         xp[i] = cconj(csub(a, wb));
     }
@@ -190,7 +204,7 @@ __device__ __forceinline__ void irfft1024(float2 *buf, int lane, const FftTw &tw
         if (k == 0) { xk.y = 0.f; xp.y = 0.f; }
         float2 a = make_float2(0.5f * (xk.x + xp.x), 0.5f * (xk.y - xp.y));
         float2 d = make_float2(0.5f * (xk.x - xp.x), 0.5f * (xk.y + xp.y));
-        float2 b = cmulc(d, tw.ts[i]);
+        float2 b = cmulc(d, tw.ts(i, lane));
         zk[i] = make_float2(a.x - b.y, a.y + b.x);          // a + j b
         zp[i] = make_float2(a.x + b.y, -a.y + b.x);         // conj(a) + j conj(b)
     }

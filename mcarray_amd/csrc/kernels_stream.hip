@@ -16,36 +16,87 @@ namespace mca {
 // --------------------------------------------------------------------------------------
 // k_stft_phat
 // --------------------------------------------------------------------------------------
-// One 512-thread workgroup walks FPB consecutive frames of one array.  Wave w transforms
-// channels w, w+8; the raw second half of a frame stays in registers and becomes the first
-// half of the next frame (each PCM sample is loaded once per workgroup).  After the FFTs the
-// M spectra sit in LDS; thread k whitens bin k of every channel and forms the pair products.
+// One 512-thread workgroup (8 waves) walks FPB consecutive frames of one array.  Wave w transforms
+// channels w, w+8; the raw second half of a frame stays in registers and becomes the first half
+// of the next frame (each PCM sample is loaded once per workgroup) and the next frame's new half is
+// loaded one iteration ahead.  After the FFTs the M spectra sit in LDS; thread k whitens bin
+// k < 512 of every channel and forms the pair products.  The 513th (Nyquist) bin would make one
+// wave run the pair stage twice per frame, so its whitened values are parked in LDS and the
+// Nyquist bins of all FPB frames are finished in one extra pass at the end (lane = frame).
 //
 // MT > 0: compile-time channel count (pair products from registers); MT == 0: runtime M, pair
 // operands re-read from LDS.  ULA: pairs with equal (j - i) share one delay table
 // (host-verified, bitwise-equal float delays), so their PHAT spectra are summed: G = M - 1
 // groups instead of P = M(M-1)/2 -- the contraction depth of the SRP GEMM drops by M/2.
+__device__ __forceinline__ float2 whiten(float2 z)
+{
+    const float pw = z.x * z.x + z.y * z.y;
+    const float s = pw > 1e-30f ? rsqrtf(pw) : 0.f;
+    return make_float2(z.x * s, z.y * s);
+}
+
+// pair products of one bin.  x: whitened spectra of the bin, element m at x[m * xstride].
+template <int MT, bool ULA, bool WHITEN, typename OutT>
+__device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, OutT *arow, const StftPhatArgs &p, int k)
+{
+    if constexpr (MT > 0) {
+        float2 r[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) r[m] = WHITEN ? whiten(x[m * xstride]) : x[m * xstride];
+        if constexpr (ULA) {
+            float2 acc[MT - 1];
+#pragma unroll
+            for (int g = 0; g < MT - 1; ++g) acc[g] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = i + 1; j < MT; ++j) acc[j - i - 1] = cadd(acc[j - i - 1], cmulc(r[i], r[j]));
+#pragma unroll
+            for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * FFT_K + k, acc[g]);
+        } else {
+            int pi = 0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = i + 1; j < MT; ++j) { store_a(arow, p, pi * FFT_K + k, cmulc(r[i], r[j])); ++pi; }
+        }
+    } else {
+        if (ULA) {
+            for (int g = 0; g < M - 1; ++g) {
+                float2 acc = make_float2(0.f, 0.f);
+                for (int i = 0; i + g + 1 < M; ++i) acc = cadd(acc, cmulc(x[i * xstride], x[(i + g + 1) * xstride]));
+                store_a(arow, p, g * FFT_K + k, acc);
+            }
+        } else {
+            int pi = 0;
+            for (int i = 0; i < M; ++i)
+                for (int j = i + 1; j < M; ++j) { store_a(arow, p, pi * FFT_K + k, cmulc(x[i * xstride], x[j * xstride])); ++pi; }
+        }
+    }
+}
+
 template <int MT, bool ULA, typename OutT>
 __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2 *smem = reinterpret_cast<float2 *>(smem_raw);
+    float2 *smem = reinterpret_cast<float2 *>(smem_raw);                // [M][FFT_SCRATCH] spectra
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = MT > 0 ? MT : p.M;
+    float2 *tab = smem + M * FFT_SCRATCH;                                 // [TW_WORDS] twiddles + window
+    float2 *nyq = tab + TW_WORDS;                                         // [fpb][M] whitened Nyquist bins
     const int a = blockIdx.y;
     const int f_begin = blockIdx.x * p.fpb;
     const int f_end = min(f_begin + p.fpb, p.n_frames);
-    constexpr int CPW = 2;   // channels per wave (M <= 16)
+    constexpr int CPW = (MT > 0 && MT <= 8) ? 1 : 2;   // channels per FFT wave
 
-    FftTw tw;
-    tw.init(lane);
-    float2 win[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) win[r] = reinterpret_cast<const float2 *>(p.window)[lane + 64 * r];
+    fft_table_init(tab, p.window, tid, 512);
+    __syncthreads();
+    FftTw tw{tab};
 
-    float2 raw[CPW][8];
+    // raw[cc][0..3]: first half of the current frame; nxt[cc][0..3]: its second half, loaded one
+    // iteration ahead so the HBM latency hides behind the FFTs and the pair stage of the previous frame.
+    float2 raw[CPW][4], nxt[CPW][4];
     const float *base = p.pcm + (long long)a * p.array_stride;
-    // first half of the first frame
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
         const int c = wave + 8 * cc;
@@ -53,6 +104,8 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
             const float2 *src = reinterpret_cast<const float2 *>(base + (long long)c * p.mic_stride + (long long)(p.frame0 + f_begin) * FFT_H);
 #pragma unroll
             for (int r = 0; r < 4; ++r) raw[cc][r] = src[lane + 64 * r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nxt[cc][r] = src[lane + 64 * (r + 4)];
         }
     }
 
@@ -61,73 +114,38 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
         for (int cc = 0; cc < CPW; ++cc) {
             const int c = wave + 8 * cc;
             if (c < M) {
-                const float2 *src = reinterpret_cast<const float2 *>(base + (long long)c * p.mic_stride + (long long)(p.frame0 + f) * FFT_H);
-#pragma unroll
-                for (int r = 4; r < 8; ++r) raw[cc][r] = src[lane + 64 * r];
                 float2 v[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = make_float2(raw[cc][r].x * win[r].x, raw[cc][r].y * win[r].y);
-                rfft1024(v, smem + c * FFT_SCRATCH, lane, tw);
+                for (int r = 0; r < 4; ++r) {
+                    const float2 w0 = tw.win(r, lane), w1 = tw.win(r + 4, lane);
+                    v[r] = make_float2(raw[cc][r].x * w0.x, raw[cc][r].y * w0.y);
+                    v[r + 4] = make_float2(nxt[cc][r].x * w1.x, nxt[cc][r].y * w1.y);
+                    raw[cc][r] = nxt[cc][r];
+                }
+                if (f + 1 < f_end) {
+                    const float2 *src = reinterpret_cast<const float2 *>(base + (long long)c * p.mic_stride + (long long)(p.frame0 + f + 1) * FFT_H);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) raw[cc][r] = raw[cc][r + 4];
+                    for (int r = 0; r < 4; ++r) nxt[cc][r] = src[lane + 64 * (r + 4)];
+                }
+                rfft1024(v, smem + c * FFT_SCRATCH, lane, tw);
             }
         }
         __syncthreads();
 
         OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f) * (long long)p.a_row_elems;
-        for (int k = tid; k < FFT_K; k += 512) {
-            if constexpr (MT > 0) {
-                float2 x[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    float2 z = smem[m * FFT_SCRATCH + k];
-                    float pw = z.x * z.x + z.y * z.y;
-                    float s = pw > 1e-30f ? rsqrtf(pw) : 0.f;
-                    x[m] = make_float2(z.x * s, z.y * s);
-                }
-                if constexpr (ULA) {
-                    float2 acc[MT - 1];
-#pragma unroll
-                    for (int g = 0; g < MT - 1; ++g) acc[g] = make_float2(0.f, 0.f);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = i + 1; j < MT; ++j) acc[j - i - 1] = cadd(acc[j - i - 1], cmulc(x[i], x[j]));
-#pragma unroll
-                    for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * FFT_K + k, acc[g]);
-                } else {
-                    int pi = 0;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = i + 1; j < MT; ++j) { store_a(arow, p, pi * FFT_K + k, cmulc(x[i], x[j])); ++pi; }
-                }
-            } else {
-                // runtime M: whiten in place first (each thread owns its bin), then pairs from LDS
-                for (int m = 0; m < M; ++m) {
-                    float2 z = smem[m * FFT_SCRATCH + k];
-                    float pw = z.x * z.x + z.y * z.y;
-                    float s = pw > 1e-30f ? rsqrtf(pw) : 0.f;
-                    smem[m * FFT_SCRATCH + k] = make_float2(z.x * s, z.y * s);
-                }
-                if (ULA) {
-                    for (int g = 0; g < M - 1; ++g) {
-                        float2 acc = make_float2(0.f, 0.f);
-                        for (int i = 0; i + g + 1 < M; ++i)
-                            acc = cadd(acc, cmulc(smem[i * FFT_SCRATCH + k], smem[(i + g + 1) * FFT_SCRATCH + k]));
-                        store_a(arow, p, g * FFT_K + k, acc);
-                    }
-                } else {
-                    int pi = 0;
-                    for (int i = 0; i < M; ++i)
-                        for (int j = i + 1; j < M; ++j) {
-                            store_a(arow, p, pi * FFT_K + k, cmulc(smem[i * FFT_SCRATCH + k], smem[j * FFT_SCRATCH + k]));
-                            ++pi;
-                        }
-                }
-            }
+        if (tid < M) nyq[(f - f_begin) * M + tid] = whiten(smem[tid * FFT_SCRATCH + FFT_H]);
+        {
+            const int k = tid;   // bins 0..511
+            if constexpr (MT == 0)   // runtime M: whiten the thread's own column in place, pairs re-read it from LDS
+                for (int m = 0; m < M; ++m) smem[m * FFT_SCRATCH + k] = whiten(smem[m * FFT_SCRATCH + k]);
+            pair_stage<MT, ULA, true, OutT>(smem + k, FFT_SCRATCH, M, arow, p, k);
         }
         __syncthreads();
+    }
+    // Nyquist bins of the block's frames: lane = frame
+    if (tid < f_end - f_begin) {
+        OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
+        pair_stage<MT, ULA, false, OutT>(nyq + tid * M, 1, M, arow, p, FFT_H);
     }
 }
 
@@ -146,10 +164,13 @@ INST_STFT(16, true, _Float16)
 // --------------------------------------------------------------------------------------
 // k_scan_pick
 // --------------------------------------------------------------------------------------
-// grid (chunks, arrays); thread d owns steering angle d and carries E[d] in a register across
-// the frames of its chunk.  A chunk that does not start at frame 0 warms the recursion up over
-// the preceding SCAN_WARM frames from zero: 0.8^128 = 4e-13, below fp32 rounding of E, so every
-// chunk is independent and the whole batch is peak-picked in parallel.
+// grid (chunks, arrays).  Phase 1: thread d owns steering angle d, carries E[d] in a register
+// through the frames of its chunk and leaves the normalised energies of the chunk in LDS.  A chunk
+// that does not start at frame 0 warms the recursion up over the preceding SCAN_WARM frames from
+// zero (0.8^128 = 4e-13, below fp32 rounding of E), so chunks are independent.  Phase 2: one WAVE
+// per frame does selectDOA with no block barrier: lane l evaluates sd[d] for d = l + 64 i straight
+// from five neighbouring energies (sign of the first derivative, median-3, second derivative x
+// energy) and the argmax is a wave shuffle reduction with first-index tie-break.
 __device__ __forceinline__ float median3f(float a, float b, float c)
 {
     float lo = fminf(a, b), hi = fmaxf(a, b);
@@ -158,93 +179,132 @@ __device__ __forceinline__ float median3f(float a, float b, float c)
 
 __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 {
-    __shared__ float sEn[520], sFd[520], sFm[520];
-    __shared__ float sRedV[8];
-    __shared__ int sRedI[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sEn = reinterpret_cast<float *>(smem_raw);                   // [chunk][Dl]
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
-    const int a = blockIdx.y, D = p.D;
+    const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
     const int t_start = blockIdx.x * p.chunk;
     const int t_end = min(t_start + p.chunk, p.n_frames);
     const int warm_start = max(0, t_start - SCAN_WARM);
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
-    float E = 0.f;
-    if (warm_start == 0 && act) E = p.state_in[(long long)a * D + d];
-    for (int t = warm_start; t < t_start; ++t)
-        if (act) E = mu * E + omu * C[(long long)t * p.Dp + d];
     const float mn = -15.f * (float)p.P;
-    for (int t = t_start; t < t_end; ++t) {
-        if (act) {
+    if (act) {
+        float E = warm_start == 0 ? p.state_in[(long long)a * D + d] : 0.f;
+        int t = warm_start;
+        for (; t + 8 <= t_start; t += 8) {              // 8 independent loads in flight per thread
+            float c8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c8[i] = C[(long long)(t + i) * p.Dp + d];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) E = mu * E + omu * c8[i];
+        }
+        for (; t < t_start; ++t) E = mu * E + omu * C[(long long)t * p.Dp + d];
+        for (; t + 8 <= t_end; t += 8) {
+            float c8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c8[i] = C[(long long)(t + i) * p.Dp + d];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                E = mu * E + omu * c8[i];                                   // :134-140
+                if (p.energy) p.energy[((long long)a * p.n_frames + t + i) * D + d] = E;
+                sEn[(t + i - t_start) * Dl + d] = (E - mn) / (-2.f * mn);   // :155-156
+            }
+        }
+        for (; t < t_end; ++t) {
             E = mu * E + omu * C[(long long)t * p.Dp + d];
             if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
-            sEn[d] = (E - mn) / (-2.f * mn);                         // :155-156
+            sEn[(t - t_start) * Dl + d] = (E - mn) / (-2.f * mn);
         }
-        __syncthreads();
-        if (d < D - 1) {
-            float df = sEn[d + 1] - sEn[d];                            // :159
-            sFd[d] = df < 0.f ? 1.f : 0.f;                             // :161 (df == 0 stays 0)
+        if (t_end == p.n_frames) p.state_out[(long long)a * D + d] = E;     // _prevEnergyInDOA (:143)
+    }
+    __syncthreads();
+
+    for (int tl = wave; tl < t_end - t_start; tl += nwaves) {
+        const float *En = sEn + tl * Dl;
+        float sdv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int dd = lane + 64 * i;
+            float sd = -INFINITY;
+            if (dd < D - 2) {
+                // fd(j) = 1 if En[j+1] - En[j] < 0 else 0, j in [0, D-2]; edges replicate (median_filter)
+                const int j0 = max(dd - 1, 0), j3 = min(dd + 2, D - 2);
+                const float e0 = En[j0], e1 = En[j0 + 1];
+                const float ed = En[dd], ed1 = En[dd + 1], ed2 = En[dd + 2];
+                const float e3 = En[j3], e4 = En[j3 + 1];
+                const float fm1 = (e1 - e0) < 0.f ? 1.f : 0.f;        // fd(d-1) (or fd(0) at the edge)
+                const float f0 = (ed1 - ed) < 0.f ? 1.f : 0.f;        // fd(d)
+                const float f1 = (ed2 - ed1) < 0.f ? 1.f : 0.f;       // fd(d+1)
+                const float f2 = (e4 - e3) < 0.f ? 1.f : 0.f;         // fd(d+2) (or fd(D-2) at the edge)
+                const float m0 = median3f(fm1, f0, f1);               // filtered fd(d)     :164
+                const float m1 = median3f(f0, f1, f2);                // filtered fd(d+1)
+                sd = (m1 - m0) * ed1;                                  // :170-173
+            }
+            sdv[i] = sd;
         }
-        __syncthreads();
-        if (d < D - 1) sFm[d] = median3f(sFd[max(d - 1, 0)], sFd[d], sFd[min(d + 1, D - 2)]);   // :164
-        __syncthreads();
-        float sd = -INFINITY;
-        if (d < D - 2) sd = (sFm[d + 1] - sFm[d]) * sEn[d + 1];      // :170-173
         for (int s = 0; s < p.S; ++s) {                                // :185-194
-            float bv = sd; int bi = d;
+            float bv = sdv[0]; int bi = lane;
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+                if (sdv[i] > bv) { bv = sdv[i]; bi = lane + 64 * i; }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                float ov = __shfl_down(bv, off); int oi = __shfl_down(bi, off);
+                float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off);
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
-            if (lane == 0) { sRedV[wave] = bv; sRedI[wave] = bi; }
-            __syncthreads();
-            bv = sRedV[0]; bi = sRedI[0];
-            for (int w = 1; w < nwaves; ++w) {
-                float ov = sRedV[w]; int oi = sRedI[w];
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (d == bi) sd = 0.f;                                     // _secondDerivative[maxIdx] = 0
-            if (d == 0) {
-                const long long o = ((long long)a * p.n_frames + t) * p.S + s;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (bi == lane + 64 * i) sdv[i] = 0.f;                 // _secondDerivative[maxIdx] = 0
+            if (lane == 0) {
+                const long long o = ((long long)a * p.n_frames + t_start + tl) * p.S + s;
                 p.doa_bin[o] = bi + 1;
                 if (p.doa_rad) p.doa_rad[o] = p.grid[bi + 1];          // doaIdx2angle(maxIdx+1)
                 if (p.prob) p.prob[o] = bv;
             }
-            __syncthreads();
         }
     }
-    if (t_end == p.n_frames && act) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143)
 }
 
 // --------------------------------------------------------------------------------------
 // k_beamform_ola
 // --------------------------------------------------------------------------------------
 // grid (frame runs, arrays), 512 threads.  A run is FT frames plus the frame before it (whose
-// second half is the overlap-add carry).  Frames are handled in batches of 8: per frame the 8
-// waves transform the channels and all threads apply the delay-and-sum; then wave w inverse
-// transforms the beamformed spectrum of batch slot w; then the 512 threads emit hop samples
-// per frame with the carry in a register.
-__global__ __launch_bounds__(512) void k_beamform_ola(BeamformArgs p)
+// second half is the overlap-add carry).  Frames are handled in batches of BF_NB: per frame the 8
+// waves transform the channels and thread k applies the delay-and-sum to bin k < 512 with the
+// steering phasors factored as exp(j k s) = hi[k >> 5] * lo[k & 31] (49 sincos per channel and
+// frame instead of 513; the reference regenerates the whole ramp per frame, Beamformer.cpp:59-60);
+// the Nyquist bins of the batch are finished in one pass (lane = slot); then wave w inverse
+// transforms the beamformed spectrum of batch slot w; then the 512 threads emit hop samples per
+// frame with the carry in a register.  LDS per workgroup ~69 KB (M = 8, S = 1): two per CU.
+template <int CPW>
+__global__ __launch_bounds__(512, CPW == 1 ? 4 : 2) void k_beamform_ola(BeamformArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2 *xs = reinterpret_cast<float2 *>(smem_raw);                 // [Mpad][FFT_SCRATCH] channel spectra
-    float2 *ys = xs + p.Mpad * FFT_SCRATCH;                             // [8*S][FFT_SCRATCH] beamformed slots
-    double *steer = reinterpret_cast<double *>(ys + 8 * p.S * FFT_SCRATCH);   // [S] cos(DOA + pi/2)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = p.M, S = p.S, a = blockIdx.y;
+    float2 *xs = reinterpret_cast<float2 *>(smem_raw);                 // [M][FFT_SCRATCH] channel spectra
+    float2 *ys = xs + M * FFT_SCRATCH;                                  // [BF_NB*S][FFT_SCRATCH] beamformed slots
+    float2 *steer = ys + BF_NB * S * FFT_SCRATCH;                       // [S][M][49] steering phasors (lo 0..31, hi 32..48)
+    float2 *tab = steer + S * M * 49;                                   // [TW_WORDS]
+    float2 *xn = tab + TW_WORDS;                                        // [BF_NB][M] Nyquist bins of the batch
+    float2 *pn = xn + BF_NB * M;                                        // [BF_NB][S][M] their steering phasors
+    double *cdoa = reinterpret_cast<double *>(pn + BF_NB * S * M);      // [ft+1][S] cos(DOA + pi/2) of the run
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = blockIdx.x * p.ft;
     const int t1 = min(t0 + p.ft, p.n_frames);
     const int tfirst = t0 > 0 ? t0 - 1 : 0;
-    constexpr int CPW = 2;
 
-    FftTw tw; tw.init(lane);
-    float2 win[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) win[r] = reinterpret_cast<const float2 *>(p.window)[lane + 64 * r];
+    fft_table_init(tab, p.window, tid, 512);
+    for (int e = tid; e < (t1 - tfirst) * S; e += 512) {
+        const double doa = (double)p.doa_rad[((long long)a * p.n_frames + tfirst) * S + e];
+        cdoa[e] = cos(doa + 1.57079632679489661923);                    // cos(DOA + M_PI/2), Beamformer.cpp:59
+    }
+    __syncthreads();
+    FftTw tw{tab};
 
     const float *base = p.pcm + (long long)a * p.array_stride;
-    float2 raw[CPW][8];
+    float2 raw[CPW][4], nxt[CPW][4];
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
         const int c = wave + 8 * cc;
@@ -252,6 +312,8 @@ __global__ __launch_bounds__(512) void k_beamform_ola(BeamformArgs p)
             const float2 *src = reinterpret_cast<const float2 *>(base + (long long)c * p.mic_stride + (long long)tfirst * FFT_H);
 #pragma unroll
             for (int r = 0; r < 4; ++r) raw[cc][r] = src[lane + 64 * r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nxt[cc][r] = src[lane + 64 * (r + 4)];
         }
     }
     float carry[MCA_MAX_SOURCES];
@@ -264,50 +326,68 @@ __global__ __launch_bounds__(512) void k_beamform_ola(BeamformArgs p)
     }
 
     const double unit = (double)p.fs / (double)FFT_N / 346.1;          // Beamformer.cpp:59 without 2 pi
+    const float inv = 1.0f / (float)M;
 
-    for (int tb = tfirst; tb < t1; tb += 8) {
-        const int nb = min(8, t1 - tb);
+    for (int tb = tfirst; tb < t1; tb += BF_NB) {
+        const int nb = min(BF_NB, t1 - tb);
         for (int j = 0; j < nb; ++j) {
             const int t = tb + j;
+            for (int e = tid; e < S * M * 49; e += 512) {
+                const int s = e / (M * 49), rem = e - s * (M * 49), c = rem / 49, q = rem - c * 49;
+                const int kk = q < 32 ? q : (q - 32) * 32;
+                double turns = (double)kk * (unit * p.mic_x[c] * cdoa[(t - tfirst) * S + s]);
+                turns -= rint(turns);
+                float sn, cs;
+                sincospif(2.0f * (float)turns, &sn, &cs);
+                steer[e] = make_float2(cs, sn);
+            }
             // analysis of frame t
 #pragma unroll
             for (int cc = 0; cc < CPW; ++cc) {
                 const int c = wave + 8 * cc;
                 if (c < M) {
-                    const float2 *src = reinterpret_cast<const float2 *>(base + (long long)c * p.mic_stride + (long long)t * FFT_H);
-#pragma unroll
-                    for (int r = 4; r < 8; ++r) raw[cc][r] = src[lane + 64 * r];
                     float2 v[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = make_float2(raw[cc][r].x * win[r].x, raw[cc][r].y * win[r].y);
-                    rfft1024(v, xs + c * FFT_SCRATCH, lane, tw);
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 w0 = tw.win(r, lane), w1 = tw.win(r + 4, lane);
+                        v[r] = make_float2(raw[cc][r].x * w0.x, raw[cc][r].y * w0.y);
+                        v[r + 4] = make_float2(nxt[cc][r].x * w1.x, nxt[cc][r].y * w1.y);
+                        raw[cc][r] = nxt[cc][r];
+                    }
+                    if (t + 1 < t1) {
+                        const float2 *src = reinterpret_cast<const float2 *>(base + (long long)c * p.mic_stride + (long long)(t + 1) * FFT_H);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) raw[cc][r] = raw[cc][r + 4];
+                        for (int r = 0; r < 4; ++r) nxt[cc][r] = src[lane + 64 * (r + 4)];
+                    }
+                    rfft1024(v, xs + c * FFT_SCRATCH, lane, tw);
                 }
-            }
-            if (tid < S) {
-                const double doa = (double)p.doa_rad[((long long)a * p.n_frames + t) * S + tid];
-                steer[tid] = cos(doa + 1.57079632679489661923);         // cos(DOA + M_PI/2), :59
             }
             __syncthreads();
             // delay-and-sum: Y[k] = (1/M) sum_c X_c[k] exp(j k s_c), s_c = 2 pi unit x_c cos(DOA+pi/2)
-            for (int s = 0; s < S; ++s) {
-                const double cd = steer[s];
-                for (int k = tid; k < FFT_K; k += 512) {
+            {
+                const int k = tid;   // bins 0..511
+                for (int s = 0; s < S; ++s) {
                     float2 acc = make_float2(0.f, 0.f);
                     for (int c = 0; c < M; ++c) {
-                        double turns = (double)k * (unit * p.mic_x[c] * cd);
-                        turns -= rint(turns);
-                        float sn, cs;
-                        sincospif(2.0f * (float)turns, &sn, &cs);
-                        acc = cadd(acc, cmul(xs[c * FFT_SCRATCH + k], make_float2(cs, sn)));
+                        const float2 *tb2 = steer + (s * M + c) * 49;
+                        const float2 ph = cmul(tb2[32 + (k >> 5)], tb2[k & 31]);
+                        acc = cadd(acc, cmul(xs[c * FFT_SCRATCH + k], ph));
                     }
-                    const float inv = 1.0f / (float)M;
                     ys[(j * S + s) * FFT_SCRATCH + k] = make_float2(acc.x * inv, acc.y * inv);   // divC :70
                 }
+                if (tid < M) xn[j * M + tid] = xs[tid * FFT_SCRATCH + FFT_H];
+                if (tid < S * M) pn[j * S * M + tid] = steer[tid * 49 + 48];     // k = 512 = 32 * 16 + 0
             }
             __syncthreads();
         }
+        // Nyquist bins of the batch: lane = slot
+        if (tid < nb * S) {
+            const int j = tid / S, s = tid - j * S;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int c = 0; c < M; ++c) acc = cadd(acc, cmul(xn[j * M + c], pn[(j * S + s) * M + c]));
+            ys[tid * FFT_SCRATCH + FFT_H] = make_float2(acc.x * inv, acc.y * inv);
+        }
+        __syncthreads();
         // synthesis: wave w inverse-transforms slots w, w+8, ...
         for (int q = wave; q < nb * S; q += 8) irfft1024(ys + q * FFT_SCRATCH, lane, tw);
         __syncthreads();
@@ -331,5 +411,8 @@ __global__ __launch_bounds__(512) void k_beamform_ola(BeamformArgs p)
             if (s < S) p.tail_out[((long long)a * S + s) * FFT_H + tid] = carry[s];
     }
 }
+
+template __global__ void k_beamform_ola<1>(BeamformArgs);
+template __global__ void k_beamform_ola<2>(BeamformArgs);
 
 }  // namespace mca

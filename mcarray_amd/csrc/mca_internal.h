@@ -7,6 +7,7 @@
 
 namespace mca {
 
+constexpr int BF_NB = 4;           // frames per inverse-FFT batch of k_beamform_ola
 constexpr int SCAN_WARM = 128;    // frames of IIR warm-up per scan chunk (0.8^128 = 4e-13)
 
 struct StftPhatArgs {
