@@ -2,6 +2,9 @@
 #ifndef MCA_HIP_MICARRAY_H
 #define MCA_HIP_MICARRAY_H
 #include "ArrayDescription.h"
+#include "ArrayModules.h"
+#include "BinauralLocalisation.h"
+#include "FastBinauralMasking.h"
 #include "Beamformer.h"
 #include "BeamformingSeparationAndLocalistaion.h"
 #include "SoundLocalisationCallback.h"

@@ -144,13 +144,70 @@ int mca_hip_fft_log_power(mca_hip_ctx *ctx, const double *const *frames, int ccs
 /* copy of the current un-normalised _prevEnergyInDOA of array 0: out[D] */
 int mca_hip_get_energy(mca_hip_ctx *ctx, double *out);
 
+/* ---- 2-microphone GCC-PHAT localisation (FreqGCCBinauralLocalisation) ----------------- */
+/* Deterministic part of FreqGCCBinauralLocalisation::processParametrisation
+ * (BinauralLocalisation.cpp:406-567) for n_frames consecutive frames of n_arrays independent
+ * 2-microphone arrays, on a context created with n_mics == 2 (the reference grid is
+ * doa_step_deg = 3, BinauralLocalisation.cpp:328): GCC-PHAT at the D steering delays (:438-444),
+ * correlation smoothing corr = (1-mu) corr + mu prev with mu = 0 on a stream's first frame and
+ * 0.8f afterwards (:445-448, :523), first-max argmax and the author's deterministic DOA smoothing
+ * DOA = m DOA + (1-m) angle, m = 0 then 0.6f (the #else branch :502-504; the particle filter of
+ * :456-473 is a stochastic DSPONE component and stays out of scope), and setProbability of the
+ * previous DOA (:454, :569-631).  Runs ungated (usePowerFloor = false).
+ *   argmax_dev [A][F] int32, doa_rad_dev [A][F] float (smoothed), prob_dev [A][F] float,
+ *   corr_dev [A][F][D] float smoothed correlation (any but argmax_dev may be NULL). */
+int mca_hip_gcc2_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,
+                            long long mic_stride, int n_arrays, int n_frames, int *argmax_dev,
+                            float *doa_rad_dev, float *prob_dev, float *corr_dev, void *stream);
+int mca_hip_gcc2_frames_host(mca_hip_ctx *ctx, const float *pcm, int n_arrays, int n_frames,
+                             int *argmax, float *doa_rad, float *prob, float *corr);
+
+/* ---- binaural masking (FastBinauralMasking) --------------------------------------------- */
+typedef struct mca_hip_mask_ctx mca_hip_mask_ctx;
+/* BinauralMasking::MaskingMethod / MaskingAlg (ArrayModules.h:81,89) */
+typedef enum { MCA_HIP_MASK_FACTOR = 0, MCA_HIP_MASK_RELATIVE = 1, MCA_HIP_MASK_FULL = 3, MCA_HIP_MASK_NOISY = 4, MCA_HIP_MASK_NOTHING = 5 } mca_hip_mask_method;
+typedef enum { MCA_HIP_MASK_BOTH = 0, MCA_HIP_MASK_SPATIAL = 1, MCA_HIP_MASK_TEMPORAL = 2 } mca_hip_mask_alg;
+/* constructor arguments of FastBinauralMasking(int samplerate, double microDistance, float lowFreq,
+ * float highFreq, MaskingMethod, MaskingAlg) (FastBinauralMasking.h:71-76) */
+typedef struct {
+    int struct_size;
+    int device;
+    int sample_rate;
+    int fft_size;            /* N = 2^calculateOrderFromSampleRate(fs, 0.050); the stream API needs 1024 */
+    double micro_distance;
+    float low_freq, high_freq;
+    int method;              /* mca_hip_mask_method */
+    int algorithm;           /* mca_hip_mask_alg */
+    int max_streams;
+} mca_hip_mask_config;
+/* FastBinauralMasking::FastBinauralMasking + init + calculateThresholds (FastBinauralMasking.cpp:51-123, :342-366) */
+int mca_hip_mask_create(const mca_hip_mask_config *cfg, mca_hip_mask_ctx **out);
+void mca_hip_mask_destroy(mca_hip_mask_ctx *ctx);
+const char *mca_hip_mask_last_error(const mca_hip_mask_ctx *ctx);
+int mca_hip_mask_reset(mca_hip_mask_ctx *ctx);
+/* _thresholds (:361-362) and getBinCenterFrequency (cycles/sample): out[45] each */
+int mca_hip_mask_get_thresholds(const mca_hip_mask_ctx *ctx, double *thresholds, double *center_freqs);
+/* STFT + FastBinauralMasking::processParametrisation (FastBinauralMasking.cpp:126-210) + inverse FFT +
+ * overlap-add for n_frames frames of n_streams independent 2-channel streams.
+ * pcm_dev: sample n of channel c of stream s at pcm[s*stream_stride + c*ch_stride + n], (F+1)*hop samples;
+ * out_pcm_dev [streams][2][F*hop]; decisions_dev (may be NULL) [streams][F][45] int32:
+ * 0 enhance, 1 temporal mask, 2 spatial mask. */
+int mca_hip_mask_frames_dev(mca_hip_mask_ctx *ctx, const float *pcm_dev, long long stream_stride, long long ch_stride,
+                            int n_streams, int n_frames, float *out_pcm_dev, int *decisions_dev, void *stream);
+int mca_hip_mask_frames_host(mca_hip_mask_ctx *ctx, const float *pcm, int n_streams, int n_frames, float *out_pcm,
+                             int *decisions);
+/* the DSPONE hook itself: one frame, left/right CCS double[N+2] modified in place (:199-200), double on the GPU */
+int mca_hip_mask_process_frame(mca_hip_mask_ctx *ctx, double *left, double *right, int ccs_len, int *decisions);
+
 /* ---- measurement ------------------------------------------------------------ */
 typedef enum {
     MCA_HIP_K_STFT_PHAT = 0,   /* STFT + PHAT whitening + pair-group sums */
     MCA_HIP_K_SRP_GEMM = 1,    /* steering contraction (MFMA) */
     MCA_HIP_K_SCAN_PICK = 2,   /* IIR over frames + selectDOA */
     MCA_HIP_K_BEAMFORM = 3,    /* STFT + delay-and-sum + inverse FFT + overlap-add */
-    MCA_HIP_K_COUNT = 4
+    MCA_HIP_K_GCC2_SCAN = 4,   /* 2-mic correlation smoothing + argmax + probability */
+    MCA_HIP_K_MASK = 5,        /* binaural masking */
+    MCA_HIP_K_COUNT = 6
 } mca_hip_kernel_id;
 /* enable = 1: bracket every launch of the stream API with hipEvents on its stream */
 int mca_hip_set_timing(mca_hip_ctx *ctx, int enable);

@@ -34,6 +34,21 @@ class Config(C.Structure):
     ]
 
 
+class MaskConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int),
+        ("device", C.c_int),
+        ("sample_rate", C.c_int),
+        ("fft_size", C.c_int),
+        ("micro_distance", C.c_double),
+        ("low_freq", C.c_float),
+        ("high_freq", C.c_float),
+        ("method", C.c_int),
+        ("algorithm", C.c_int),
+        ("max_streams", C.c_int),
+    ]
+
+
 # every symbol include/mcarray_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mca_hip_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
@@ -61,6 +76,19 @@ SYMBOLS = [
     ("mca_hip_beamformer_process_frame", C.c_int, [C.c_void_p, C.POINTER(c_dp), C.c_int, c_dp, C.c_double]),
     ("mca_hip_fft_log_power", C.c_int, [C.c_void_p, C.POINTER(c_dp), C.c_int, c_dp]),
     ("mca_hip_get_energy", C.c_int, [C.c_void_p, c_dp]),
+    ("mca_hip_gcc2_frames_dev", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+      C.c_void_p, C.c_void_p]),
+    ("mca_hip_gcc2_frames_host", C.c_int, [C.c_void_p, c_fp, C.c_int, C.c_int, c_ip, c_fp, c_fp, c_fp]),
+    ("mca_hip_mask_create", C.c_int, [C.POINTER(MaskConfig), C.POINTER(C.c_void_p)]),
+    ("mca_hip_mask_destroy", None, [C.c_void_p]),
+    ("mca_hip_mask_last_error", C.c_char_p, [C.c_void_p]),
+    ("mca_hip_mask_reset", C.c_int, [C.c_void_p]),
+    ("mca_hip_mask_get_thresholds", C.c_int, [C.c_void_p, c_dp, c_dp]),
+    ("mca_hip_mask_frames_dev", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mca_hip_mask_frames_host", C.c_int, [C.c_void_p, c_fp, C.c_int, C.c_int, c_fp, c_ip]),
+    ("mca_hip_mask_process_frame", C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, c_ip]),
     ("mca_hip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("mca_hip_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
     ("mca_hip_reset_timing", C.c_int, [C.c_void_p]),

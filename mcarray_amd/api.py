@@ -129,6 +129,26 @@ class Context:
             self._check(self._lib.mca_hip_separate_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_rad),
                                                               ptr(out_pcm), stream))
 
+    # ---- 2-microphone GCC-PHAT path ----
+    def gcc2_frames_host(self, pcm, want_corr=False):
+        """pcm float32 [A][2][(F+1)*hop] -> dict(argmax [A][F], doa [A][F] (smoothed, rad), prob [A][F], corr [A][F][D])"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if pcm.ndim == 2:
+            pcm = pcm[None]
+        A, M, L = pcm.shape
+        F = L // self.hop - 1
+        if M != 2 or F < 1 or (F + 1) * self.hop != L:
+            raise MCArrayHipError("pcm must be [A][2][(F+1)*hop]")
+        idx = np.empty((A, F), dtype=np.int32)
+        doa = np.empty((A, F), dtype=np.float32)
+        prob = np.empty((A, F), dtype=np.float32)
+        corr = np.empty((A, F, self.D), dtype=np.float32) if want_corr else None
+        fp = _lib.c_fp
+        self._check(self._lib.mca_hip_gcc2_frames_host(self.h, pcm.ctypes.data_as(fp), A, F, idx.ctypes.data_as(_lib.c_ip),
+                                                       doa.ctypes.data_as(fp), prob.ctypes.data_as(fp),
+                                                       corr.ctypes.data_as(fp) if want_corr else None))
+        return dict(argmax=idx, doa=doa, prob=prob, corr=corr)
+
     # ---- frame API ----
     def _rows(self, frames):
         frames = np.ascontiguousarray(frames, dtype=np.float64)
@@ -226,3 +246,96 @@ class SourceSeparationAndLocalisation:
             for t in range(deg.shape[0]):
                 self.callback(deg[t], r["prob"][0, t], None, self.ctx.S)
         return r["out"][0], r
+
+
+class FreqGCCBinauralLocalisation:
+    """mca::FreqGCCBinauralLocalisation(int sampleRate, ArrayDescription, bool usePowerFloor)
+    (BinauralLocalisation.h:191), deterministic part: smoothed GCC-PHAT correlation, first-max argmax,
+    DOA smoothing and setProbability.  The reference's grid is 3 degrees (BinauralLocalisation.cpp:328)."""
+
+    def __init__(self, sample_rate, mic_positions, use_power_floor=False, doa_step_deg=3.0, fft_size=1024,
+                 srp_precision=SRP_FP32, max_arrays=1, device=0):
+        if use_power_floor:
+            raise MCArrayHipError("the stream API runs ungated (usePowerFloor=false)")
+        self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, 1, False, srp_precision, max_arrays, device)
+        if self.ctx.M != 2:
+            raise MCArrayHipError("FreqGCCBinauralLocalisation needs exactly 2 microphones")
+
+    def process(self, pcm, want_corr=False):
+        return self.ctx.gcc2_frames_host(pcm, want_corr)
+
+
+FACTOR, RELATIVE, FULL, NOISY, NOTHING = 0, 1, 3, 4, 5      # BinauralMasking::MaskingMethod (ArrayModules.h:81)
+BOTH, SPATIAL, TEMPORAL = 0, 1, 2                           # BinauralMasking::MaskingAlg (ArrayModules.h:89)
+
+
+class FastBinauralMasking:
+    """mca::FastBinauralMasking(int samplerate, double microDistance, float lowFreq, float highFreq,
+    MaskingMethod = RELATIVE, MaskingAlg = BOTH) (FastBinauralMasking.h:71-76)."""
+
+    def __init__(self, samplerate, micro_distance, low_freq, high_freq, method=RELATIVE, algorithm=BOTH, fft_size=1024,
+                 max_streams=1, device=0):
+        self._lib = _lib.load()
+        cfg = _lib.MaskConfig()
+        cfg.struct_size = C.sizeof(_lib.MaskConfig)
+        cfg.device = device
+        cfg.sample_rate = samplerate
+        cfg.fft_size = fft_size
+        cfg.micro_distance = micro_distance
+        cfg.low_freq = low_freq
+        cfg.high_freq = high_freq
+        cfg.method = method
+        cfg.algorithm = algorithm
+        cfg.max_streams = max_streams
+        h = C.c_void_p()
+        rc = self._lib.mca_hip_mask_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise MCArrayHipError("mca_hip_mask_create failed (%d): %s" % (rc, self._lib.mca_hip_mask_last_error(None).decode()))
+        self.h = h
+        self.N = fft_size
+        self.hop = fft_size // 2
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.mca_hip_mask_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MCArrayHipError("libmcarray_hip error %d: %s" % (rc, self._lib.mca_hip_mask_last_error(self.h).decode()))
+
+    def reset(self):
+        self._check(self._lib.mca_hip_mask_reset(self.h))
+
+    def thresholds(self):
+        thr = np.empty(45)
+        cen = np.empty(45)
+        self._check(self._lib.mca_hip_mask_get_thresholds(self.h, thr.ctypes.data_as(_lib.c_dp), cen.ctypes.data_as(_lib.c_dp)))
+        return thr, cen
+
+    def process(self, pcm, want_decisions=True):
+        """pcm float32 [streams][2][(F+1)*hop] -> (out [streams][2][F*hop], decisions [streams][F][45])"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if pcm.ndim == 2:
+            pcm = pcm[None]
+        ns, ch, L = pcm.shape
+        F = L // self.hop - 1
+        if ch != 2 or F < 1 or (F + 1) * self.hop != L:
+            raise MCArrayHipError("pcm must be [streams][2][(F+1)*hop]")
+        out = np.empty((ns, 2, F * self.hop), dtype=np.float32)
+        dec = np.empty((ns, F, 45), dtype=np.int32) if want_decisions else None
+        self._check(self._lib.mca_hip_mask_frames_host(self.h, pcm.ctypes.data_as(_lib.c_fp), ns, F, out.ctypes.data_as(_lib.c_fp),
+                                                       dec.ctypes.data_as(_lib.c_ip) if want_decisions else None))
+        return out, dec
+
+    def process_parametrisation(self, left, right):
+        """The DSPONE hook for one frame: CCS double[N+2] spectra, returns the modified copies + decisions."""
+        left = np.array(left, dtype=np.float64, order="C")
+        right = np.array(right, dtype=np.float64, order="C")
+        dec = np.zeros(45, dtype=np.int32)
+        self._check(self._lib.mca_hip_mask_process_frame(self.h, left.ctypes.data_as(_lib.c_dp), right.ctypes.data_as(_lib.c_dp),
+                                                         len(left), dec.ctypes.data_as(_lib.c_ip)))
+        return left, right, dec

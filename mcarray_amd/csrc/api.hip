@@ -40,6 +40,9 @@ struct mca_hip_ctx {
     float *d_E[2] = {nullptr, nullptr};
     float *d_tail[2] = {nullptr, nullptr};
     int e_cur = 0, tail_cur = 0;
+    float *d_doa[2] = {nullptr, nullptr};   // 2-mic path: smoothed _currentDOA per array
+    int doa_cur = 0;
+    long long gcc2_frames_done = 0;
     // workspace
     void *d_A = nullptr; size_t a_bytes = 0;
     float *d_C = nullptr; size_t c_bytes = 0;
@@ -55,8 +58,8 @@ struct mca_hip_ctx {
     bool timing = false;
     std::vector<TimedEvent> events;
     std::vector<hipEvent_t> pool;
-    int t_launches[MCA_HIP_K_COUNT] = {0, 0, 0, 0};
-    double t_ms[MCA_HIP_K_COUNT] = {0, 0, 0, 0};
+    int t_launches[MCA_HIP_K_COUNT] = {};
+    double t_ms[MCA_HIP_K_COUNT] = {};
     std::string err;
 };
 
@@ -96,7 +99,7 @@ void free_ctx(mca_hip_ctx *c)
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_window); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B);
-    F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C);
+    F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -330,6 +333,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = up((void **)&c->d_pairs, c->pairs.data(), c->pairs.size() * sizeof(int2))) ||
         (rc = zalloc((void **)&c->d_E[0], na * c->D * 4)) || (rc = zalloc((void **)&c->d_E[1], na * c->D * 4)) ||
         (rc = zalloc((void **)&c->d_tail[0], na * c->S * FFT_H * 4)) || (rc = zalloc((void **)&c->d_tail[1], na * c->S * FFT_H * 4)) ||
+        (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
@@ -374,7 +378,9 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
         HIP_TRY(c, hipMemsetAsync(c->d_E[i], 0, na * c->D * 4, st));
         HIP_TRY(c, hipMemsetAsync(c->d_tail[i], 0, na * c->S * FFT_H * 4, st));
         HIP_TRY(c, hipMemsetAsync(c->d_E64[i], 0, (size_t)c->D * 8, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_doa[i], 0, na * 4, st));
     }
+    c->gcc2_frames_done = 0;
     return MCA_HIP_OK;
 }
 
@@ -386,17 +392,13 @@ int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
     return ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames);
 }
 
-int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
-                                int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
-                                float *energy, void *stream)
+// STFT + PHAT + steering contraction for every frame: fills c->d_C [arrays][n_frames][Dp]
+static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                               int n_arrays, int n_frames, hipStream_t st)
 {
-    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
-    if (rc) return rc;
-    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
-    hipStream_t st = (hipStream_t)stream;
+    int rc;
     const long long fc = chunk_frames_for(c, n_arrays, n_frames);
     if ((rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames))) return rc;
-
     for (int f0 = 0; f0 < n_frames; f0 += (int)fc) {
         const int nf = (int)std::min<long long>(fc, n_frames - f0);
         StftPhatArgs sa{};
@@ -422,6 +424,19 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
     }
+
+    return MCA_HIP_OK;
+}
+
+int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
+                                float *energy, void *stream)
+{
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
+    if (rc) return rc;
+    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
 
     ScanPickArgs pa{};
     pa.C = c->d_C; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S; pa.chunk = c->Dp > 384 ? 16 : 32;
@@ -510,6 +525,70 @@ int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, 
     if (prob) TRY2(hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
     if (energy) TRY2(hipMemcpy(energy, d_en, (size_t)n_arrays * n_frames * c->D * 4, hipMemcpyDeviceToHost));
     if (out_pcm) TRY2(hipMemcpy(out_pcm, d_out, (size_t)n_arrays * c->S * n_frames * FFT_H * 4, hipMemcpyDeviceToHost));
+#undef TRY2
+    cleanup();
+    return MCA_HIP_OK;
+}
+
+
+int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                            int n_arrays, int n_frames, int *argmax, float *doa_rad, float *prob, float *corr, void *stream)
+{
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
+    if (rc) return rc;
+    if (c->M != 2) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "the 2-microphone GCC path needs a context with n_mics == 2");
+    if (c->Dp > 192) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "the 2-microphone GCC path supports up to 192 steering delays");
+    if (!argmax) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "argmax_dev is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
+    Gcc2ScanArgs ga{};
+    ga.C = c->d_C; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D; ga.chunk = 32;
+    ga.frames_done = c->gcc2_frames_done;
+    ga.mu = 0.8f; ga.one_minus_mu = 1 - 0.8f;                      // _maxCorrMemoryFactor (BinauralLocalisation.h:198)
+    ga.doa_mem = 0.6f; ga.one_minus_doa_mem = 1 - 0.6f;            // _maxDoaMemoryFactor (:199)
+    ga.step = c->step;
+    ga.corr_in = c->d_E[c->e_cur]; ga.corr_out = c->d_E[c->e_cur ^ 1];
+    ga.doa_in = c->d_doa[c->doa_cur]; ga.doa_out = c->d_doa[c->doa_cur ^ 1];
+    ga.grid = c->d_grid; ga.argmax = argmax; ga.doa_rad = doa_rad; ga.prob = prob; ga.corr = corr;
+    const int nslot = GCC2_DOAWARM + ga.chunk;
+    const size_t smem = (size_t)nslot * (c->Dp + 8) * sizeof(float) + (size_t)nslot * 3 * sizeof(float);
+    if (smem > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcc2_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    dim3 g((n_frames + ga.chunk - 1) / ga.chunk, n_arrays);
+    time_begin(c, MCA_HIP_K_GCC2_SCAN, st);
+    hipLaunchKernelGGL(k_gcc2_scan, g, dim3(round_up(c->D, 64)), smem, st, ga);
+    time_end(c, st);
+    HIP_TRY(c, hipGetLastError());
+    c->e_cur ^= 1; c->doa_cur ^= 1;
+    c->gcc2_frames_done += n_frames;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_gcc2_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int n_frames, int *argmax,
+                             float *doa_rad, float *prob, float *corr)
+{
+    if (!c || !pcm || !argmax) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const long long ms = (long long)(n_frames + 1) * FFT_H, as = ms * c->M;
+    const size_t n_pcm = (size_t)as * n_arrays, n_f = (size_t)n_arrays * n_frames;
+    float *d_pcm = nullptr, *d_rad = nullptr, *d_prob = nullptr, *d_corr = nullptr;
+    int *d_idx = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_rad); (void)hipFree(d_prob); (void)hipFree(d_corr); (void)hipFree(d_idx); };
+#define TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(c, MCA_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    TRY2(hipMalloc((void **)&d_pcm, n_pcm * 4));
+    TRY2(hipMalloc((void **)&d_idx, n_f * 4));
+    TRY2(hipMalloc((void **)&d_rad, n_f * 4));
+    TRY2(hipMalloc((void **)&d_prob, n_f * 4));
+    if (corr) TRY2(hipMalloc((void **)&d_corr, n_f * c->D * 4));
+    TRY2(hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
+    int rc = mca_hip_gcc2_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_idx, d_rad, d_prob, d_corr, nullptr);
+    if (rc) { cleanup(); return rc; }
+    TRY2(hipDeviceSynchronize());
+    TRY2(hipMemcpy(argmax, d_idx, n_f * 4, hipMemcpyDeviceToHost));
+    if (doa_rad) TRY2(hipMemcpy(doa_rad, d_rad, n_f * 4, hipMemcpyDeviceToHost));
+    if (prob) TRY2(hipMemcpy(prob, d_prob, n_f * 4, hipMemcpyDeviceToHost));
+    if (corr) TRY2(hipMemcpy(corr, d_corr, n_f * c->D * 4, hipMemcpyDeviceToHost));
 #undef TRY2
     cleanup();
     return MCA_HIP_OK;

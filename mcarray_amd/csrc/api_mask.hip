@@ -1,0 +1,276 @@
+// api_mask.hip -- C ABI of the binaural masking module (include/mcarray_hip.h, mca_hip_mask_*).
+// Host side only: builds the mel filter bank and thresholds the reference builds in its
+// constructor, owns the per-stream state, enqueues the kernels.  No CPU fallback.
+#include "../../include/mcarray_hip.h"
+#include "fft512.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mca;
+
+struct mca_hip_mask_ctx {
+    mca_hip_mask_config cfg{};
+    int N = 0, K = 0;
+    std::vector<double> H, center, thr;       // [45][K], [45], [45]
+    MaskParams hp{};
+    MaskParams *d_mp = nullptr;
+    float *d_window = nullptr;
+    float *d_Q[2] = {nullptr, nullptr}, *d_noise = nullptr, *d_tail[2] = {nullptr, nullptr};
+    int q_cur = 0, tail_cur = 0;
+    long long frames_done = 0;
+    // frame API (double)
+    double *d_H = nullptr, *d_thr = nullptr, *d_Q64 = nullptr, *d_noise64 = nullptr, *d_io = nullptr;   // d_io: L, R, outL, outR
+    int *d_dec = nullptr;
+    int first_call = 0;
+    std::string err;
+};
+
+namespace {
+
+std::string g_mask_create_error;
+
+int mfail(mca_hip_mask_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_mask_create_error = msg;
+    return code;
+}
+
+#define MHIP_TRY(ctx, expr)                                                                             \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return mfail(ctx, _e == hipErrorOutOfMemory ? MCA_HIP_ERR_OUT_OF_MEMORY : MCA_HIP_ERR_HIP,  \
+                         std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+    } while (0)
+
+double hz2mel(double f) { return 2595.0 * std::log10(1.0 + f / 700.0); }
+double mel2hz(double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); }
+
+// [BUILD-DEFINES] stand-in for dsp::FilterBankFFTWMelScale(order, 45, fs, fmin, fmax) (FastBinauralMasking.cpp:95):
+// 45 unit-peak triangles with HTK-mel spaced edges, sampled on the K = N/2+1 bin frequencies.
+void mel_filterbank(int N, int nb, int fs, double fmin, double fmax, std::vector<double> &H, std::vector<double> &center)
+{
+    const int K = N / 2 + 1;
+    std::vector<double> edge(nb + 2);
+    const double mlo = hz2mel(fmin), mhi = hz2mel(fmax);
+    for (int i = 0; i < nb + 2; ++i) edge[i] = mel2hz(mlo + (mhi - mlo) * (double)i / (double)(nb + 1));
+    H.assign((size_t)nb * K, 0.0);
+    center.resize(nb);
+    for (int b = 0; b < nb; ++b) {
+        const double f0 = edge[b], f1 = edge[b + 1], f2 = edge[b + 2];
+        center[b] = f1 / (double)fs;
+        for (int k = 0; k < K; ++k) {
+            const double f = (double)k * (double)fs / (double)N;
+            double h = 0;
+            if (f > f0 && f <= f1) h = (f - f0) / (f1 - f0);
+            else if (f > f1 && f < f2) h = (f2 - f) / (f2 - f1);
+            H[(size_t)b * K + k] = h;
+        }
+    }
+}
+
+void free_mask(mca_hip_mask_ctx *c)
+{
+    if (!c) return;
+    auto F = [](void *p) { if (p) (void)hipFree(p); };
+    F(c->d_mp); F(c->d_window); F(c->d_Q[0]); F(c->d_Q[1]); F(c->d_noise); F(c->d_tail[0]); F(c->d_tail[1]);
+    F(c->d_H); F(c->d_thr); F(c->d_Q64); F(c->d_noise64); F(c->d_io); F(c->d_dec);
+    delete c;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mca_hip_mask_last_error(const mca_hip_mask_ctx *ctx) { return ctx ? ctx->err.c_str() : g_mask_create_error.c_str(); }
+
+int mca_hip_mask_create(const mca_hip_mask_config *cfg, mca_hip_mask_ctx **out)
+{
+    if (!cfg || !out) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->struct_size != (int)sizeof(mca_hip_mask_config)) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "struct_size mismatch");
+    if (cfg->fft_size < 64 || (cfg->fft_size & (cfg->fft_size - 1)) || cfg->fft_size > 16384) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "fft_size must be a power of two in [64,16384]");
+    if (cfg->sample_rate <= 0 || !(cfg->micro_distance > 0)) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "sample_rate / micro_distance must be positive");
+    if (!(cfg->low_freq >= 0) || !(cfg->high_freq > cfg->low_freq) || cfg->high_freq > 0.5f * cfg->sample_rate) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "need 0 <= low_freq < high_freq <= fs/2");
+    const int m = cfg->method;
+    if (!(m == 0 || m == 1 || m == 3 || m == 4 || m == 5)) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "bad masking method");
+    if (cfg->algorithm < 0 || cfg->algorithm > 2) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "bad masking algorithm");
+    if (cfg->max_streams < 1) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "max_streams < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return mfail(nullptr, MCA_HIP_ERR_NO_DEVICE, "no HIP device visible; libmcarray_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return mfail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    if (hipSetDevice(cfg->device) != hipSuccess) return mfail(nullptr, MCA_HIP_ERR_HIP, "hipSetDevice failed");
+
+    mca_hip_mask_ctx *c = new mca_hip_mask_ctx();
+    c->cfg = *cfg; c->N = cfg->fft_size; c->K = c->N / 2 + 1;
+    mel_filterbank(c->N, 45, cfg->sample_rate, (double)cfg->low_freq, (double)cfg->high_freq, c->H, c->center);
+    c->thr.resize(45);
+    const double phi = 10 * M_PI / 180;                                           // FastBinauralMasking.h:113
+    for (int b = 0; b < 45; ++b) {                                                // calculateThresholds :342-366
+        const double wfreq = c->center[b] * cfg->sample_rate * 2 * M_PI;
+        c->thr[b] = std::cos(wfreq * cfg->micro_distance * std::sin(phi) / 346.1);
+    }
+    const float lam = 0.04f, rej = 0.999f, rho = 0.01f;                           // FastBinauralMasking.h:114,128,124
+    MaskParams &hp = c->hp;
+    hp.lambda = lam; hp.one_minus_lambda = 1 - lam; hp.reject = rej; hp.rho = rho; hp.method = cfg->method; hp.alg = cfg->algorithm;
+    bool compact_ok = c->N == FFT_N;
+    if (compact_ok) {
+        for (int b = 0; b < 45; ++b) { hp.thr[b] = (float)c->thr[b]; hp.lo[b] = 1; hp.hi[b] = 0; }
+        for (int k = 0; k < c->K; ++k) {
+            hp.kb[k] = -1; hp.kw0[k] = 0.f; hp.kw1[k] = 0.f;
+            int nfound = 0;
+            for (int b = 0; b < 45; ++b) {
+                const double h = c->H[(size_t)b * c->K + k];
+                if (h > 0) {
+                    if (nfound == 0) { hp.kb[k] = b; hp.kw0[k] = (float)h; }
+                    else if (nfound == 1 && b == hp.kb[k] + 1) hp.kw1[k] = (float)h;
+                    else compact_ok = false;
+                    ++nfound;
+                    if (hp.lo[b] > hp.hi[b]) hp.lo[b] = k;
+                    hp.hi[b] = k;
+                }
+            }
+        }
+    }
+    if (c->N == FFT_N && !compact_ok) { free_mask(c); return mfail(nullptr, MCA_HIP_ERR_UNSUPPORTED, "a bin is covered by more than two adjacent bands"); }
+
+    const size_t ns = (size_t)cfg->max_streams;
+    std::vector<float> win(FFT_N);
+    for (int n = 0; n < FFT_N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / FFT_N));
+#define MUP(dst, src, bytes) do { MHIP_TRY(c, hipMalloc((void **)&(dst), (bytes))); MHIP_TRY(c, hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice)); } while (0)
+#define MZ(dst, bytes) do { MHIP_TRY(c, hipMalloc((void **)&(dst), (bytes))); MHIP_TRY(c, hipMemset((dst), 0, (bytes))); } while (0)
+    auto body = [&]() -> int {
+        MUP(c->d_mp, &c->hp, sizeof(MaskParams));
+        MUP(c->d_window, win.data(), win.size() * 4);
+        MZ(c->d_Q[0], ns * 45 * 4); MZ(c->d_Q[1], ns * 45 * 4); MZ(c->d_noise, ns * 45 * 4);
+        MZ(c->d_tail[0], ns * 2 * FFT_H * 4); MZ(c->d_tail[1], ns * 2 * FFT_H * 4);
+        MUP(c->d_H, c->H.data(), c->H.size() * 8);
+        MUP(c->d_thr, c->thr.data(), 45 * 8);
+        MZ(c->d_Q64, 45 * 8); MZ(c->d_noise64, 45 * 8);
+        MZ(c->d_io, (size_t)4 * (c->N + 2) * 8);
+        MZ(c->d_dec, 45 * 4);
+        return MCA_HIP_OK;
+    };
+    int rc = body();
+#undef MUP
+#undef MZ
+    if (rc) { g_mask_create_error = c->err; free_mask(c); return rc; }
+    *out = c;
+    return MCA_HIP_OK;
+}
+
+void mca_hip_mask_destroy(mca_hip_mask_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    free_mask(c);
+}
+
+int mca_hip_mask_reset(mca_hip_mask_ctx *c)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    MHIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t ns = (size_t)c->cfg.max_streams;
+    for (int i = 0; i < 2; ++i) { MHIP_TRY(c, hipMemset(c->d_Q[i], 0, ns * 45 * 4)); MHIP_TRY(c, hipMemset(c->d_tail[i], 0, ns * 2 * FFT_H * 4)); }
+    MHIP_TRY(c, hipMemset(c->d_noise, 0, ns * 45 * 4));
+    MHIP_TRY(c, hipMemset(c->d_Q64, 0, 45 * 8)); MHIP_TRY(c, hipMemset(c->d_noise64, 0, 45 * 8));
+    c->frames_done = 0; c->first_call = 0;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_mask_get_thresholds(const mca_hip_mask_ctx *c, double *thresholds, double *center_freqs)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (thresholds) std::memcpy(thresholds, c->thr.data(), 45 * 8);
+    if (center_freqs) std::memcpy(center_freqs, c->center.data(), 45 * 8);
+    return MCA_HIP_OK;
+}
+
+int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long stream_stride, long long ch_stride,
+                            int n_streams, int n_frames, float *out_pcm, int *decisions, void *stream)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (c->N != FFT_N) return mfail(c, MCA_HIP_ERR_UNSUPPORTED, "the stream API needs fft_size == 1024 (the frame hook takes any size)");
+    if (!pcm || !out_pcm) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev/out_pcm_dev is NULL");
+    if (n_streams < 1 || n_streams > c->cfg.max_streams) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_streams outside [1, max_streams]");
+    if (n_frames < 1) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_frames < 1");
+    const long long need = (long long)(n_frames + 1) * FFT_H;
+    if (ch_stride < need || (n_streams > 1 && stream_stride < ch_stride + need)) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "strides shorter than (n_frames+1)*hop samples");
+    if ((ch_stride & 1) || (stream_stride & 1) || (reinterpret_cast<uintptr_t>(pcm) & 7)) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev must be 8-byte aligned with even strides");
+    hipStream_t st = (hipStream_t)stream;
+    MaskArgs a{};
+    a.pcm = pcm; a.stream_stride = stream_stride; a.ch_stride = ch_stride; a.n_frames = n_frames;
+    // NOISY takes its noise estimate from the stream's very first frame (:193-197): that one call runs as a single chunk
+    a.ft = (c->cfg.method == MCA_HIP_MASK_NOISY && c->frames_done == 0) ? n_frames : 64;
+    a.frames_done = c->frames_done; a.window = c->d_window; a.mp = c->d_mp;
+    a.Q_in = c->d_Q[c->q_cur]; a.Q_out = c->d_Q[c->q_cur ^ 1]; a.noise = c->d_noise;
+    a.tail_in = c->d_tail[c->tail_cur]; a.tail_out = c->d_tail[c->tail_cur ^ 1];
+    a.out = out_pcm; a.decisions = decisions;
+    const size_t smem = (size_t)MK_NB * 2 * FFT_SCRATCH * sizeof(float2) + (size_t)MK_NB * 520 * sizeof(float4) +
+                        TW_WORDS * sizeof(float2) + (size_t)MK_NB * 48 * 8 * sizeof(float);
+    if (smem > 64 * 1024)
+        MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);
+    hipLaunchKernelGGL(k_mask_stream, g, dim3(512), smem, st, a);
+    MHIP_TRY(c, hipGetLastError());
+    c->q_cur ^= 1; c->tail_cur ^= 1;
+    c->frames_done += n_frames;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_mask_frames_host(mca_hip_mask_ctx *c, const float *pcm, int n_streams, int n_frames, float *out_pcm, int *decisions)
+{
+    if (!c || !pcm || !out_pcm) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_streams < 1 || n_frames < 1) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_streams/n_frames < 1");
+    MHIP_TRY(c, hipSetDevice(c->cfg.device));
+    const long long cs = (long long)(n_frames + 1) * FFT_H, ss = 2 * cs;
+    float *d_pcm = nullptr, *d_out = nullptr; int *d_dec = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_out); (void)hipFree(d_dec); };
+#define TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return mfail(c, MCA_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    TRY2(hipMalloc((void **)&d_pcm, (size_t)ss * n_streams * 4));
+    TRY2(hipMalloc((void **)&d_out, (size_t)n_streams * 2 * n_frames * FFT_H * 4));
+    if (decisions) TRY2(hipMalloc((void **)&d_dec, (size_t)n_streams * n_frames * 45 * 4));
+    TRY2(hipMemcpy(d_pcm, pcm, (size_t)ss * n_streams * 4, hipMemcpyHostToDevice));
+    int rc = mca_hip_mask_frames_dev(c, d_pcm, ss, cs, n_streams, n_frames, d_out, d_dec, nullptr);
+    if (rc) { cleanup(); return rc; }
+    TRY2(hipDeviceSynchronize());
+    TRY2(hipMemcpy(out_pcm, d_out, (size_t)n_streams * 2 * n_frames * FFT_H * 4, hipMemcpyDeviceToHost));
+    if (decisions) TRY2(hipMemcpy(decisions, d_dec, (size_t)n_streams * n_frames * 45 * 4, hipMemcpyDeviceToHost));
+#undef TRY2
+    cleanup();
+    return MCA_HIP_OK;
+}
+
+int mca_hip_mask_process_frame(mca_hip_mask_ctx *c, double *left, double *right, int ccs_len, int *decisions)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!left || !right) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "left/right is NULL");
+    if (ccs_len != c->N + 2) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "ccs_len != fft_size + 2");
+    if (c->cfg.method == MCA_HIP_MASK_NOTHING) return MCA_HIP_OK;              // :130-134
+    MHIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t nb = (size_t)ccs_len * 8;
+    MHIP_TRY(c, hipMemcpy(c->d_io, left, nb, hipMemcpyHostToDevice));
+    MHIP_TRY(c, hipMemcpy(c->d_io + ccs_len, right, nb, hipMemcpyHostToDevice));
+    MHIP_TRY(c, hipMemset(c->d_io + 2 * ccs_len, 0, 2 * nb));                   // setZeros :142-143
+    MaskFrameArgs a{};
+    a.L = c->d_io; a.R = c->d_io + ccs_len; a.outL = c->d_io + 2 * ccs_len; a.outR = c->d_io + 3 * ccs_len;
+    a.H = c->d_H; a.thr = c->d_thr; a.Q = c->d_Q64; a.noise = c->d_noise64;
+    a.K = c->K; a.method = c->cfg.method; a.alg = c->cfg.algorithm; a.first_call = c->first_call;
+    const float lam = 0.04f, rej = 0.999f, rho = 0.01f;
+    a.lambda = (double)lam; a.one_minus_lambda = (double)(1 - lam); a.reject = (double)rej; a.rho = (double)rho;
+    a.decisions = decisions ? c->d_dec : nullptr;
+    hipLaunchKernelGGL(k_mask_frame, dim3(1), dim3(256), 0, 0, a);
+    MHIP_TRY(c, hipGetLastError());
+    ++c->first_call;                                                             // :192
+    MHIP_TRY(c, hipMemcpy(left, a.outL, nb, hipMemcpyDeviceToHost));            // :199-200
+    MHIP_TRY(c, hipMemcpy(right, a.outR, nb, hipMemcpyDeviceToHost));
+    if (decisions) MHIP_TRY(c, hipMemcpy(decisions, c->d_dec, 45 * 4, hipMemcpyDeviceToHost));
+    return MCA_HIP_OK;
+}
+
+}  // extern "C"

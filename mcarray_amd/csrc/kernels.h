@@ -21,4 +21,8 @@ template <typename T>
 __global__ void k_frame_beamform(const C2<T> *X, int M, int K, int fs, const double *mic_x, double doa, C2<T> *Y);
 template <typename T> __global__ void k_frame_power(const C2<T> *X, int M, int K, T *out);
 
+__global__ void k_gcc2_scan(Gcc2ScanArgs p);
+__global__ void k_mask_stream(MaskArgs p);
+__global__ void k_mask_frame(MaskFrameArgs p);
+
 }  // namespace mca

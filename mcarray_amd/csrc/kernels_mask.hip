@@ -1,0 +1,271 @@
+// kernels_mask.hip -- 2-channel spatial + temporal time-frequency masking
+// (FastBinauralMasking::processParametrisation, FastBinauralMasking.cpp:126-210) on gfx950.
+//
+// The reference loops over 45 mel bands and, per band, multiplies both spectra by the band's
+// filter, takes four reductions over the bins, decides, scales and re-sums.  The filters are
+// triangles, so every bin belongs to at most two (adjacent) bands: the per-bin products
+// |L|^2, |R|^2, Re(conj(L) R), |L+R|^2/4 are formed once and each band sums them over its own
+// support with weight H_b[k]^2; the output is X[k] * sum_b g_b H_b[k] (g_b = the band's gain;
+// the reference scales only the first N doubles, so the Nyquist bin keeps gain 1).
+//
+//   k_mask_stream   batched streams: STFT -> masking -> ISTFT -> overlap-add, fp32
+//   k_mask_frame    one frame of double CCS spectra in place (the DSPONE hook), double
+#include "fft512.h"
+#include "mca_internal.h"
+
+namespace mca {
+
+__device__ __forceinline__ void mask_decide(const MaskParams &mp, int b, float S_mix, float S_LL, float S_RR, float S_LR,
+                                            float S_LL512, float S_RR512, float &Q, float noise_b, long long gframe,
+                                            int &dec, float &gL, float &gR)
+{
+    // temportalMasking :477-493 ; getFramePower/getPower :496-538 (an RMS over the first N/2 bins)
+    const float P = sqrtf(S_mix / (float)FFT_H);
+    Q = Q * mp.lambda + mp.one_minus_lambda * P;
+    bool temp = P < mp.reject * Q;
+    bool spat = false;
+    if (mp.alg == 0 || mp.alg == 1) {                       // BOTH or SPATIAL :159-166
+        const float num = S_LR / (float)FFT_K;             // normaliseFFTCorrelation :410-460
+        float nc;
+        if (num == 0.f) nc = 0.f;
+        else {
+            const float den = sqrtf((S_LL / (float)FFT_K) * (S_RR / (float)FFT_K));
+            nc = den == 0.f ? 1.f : num / den;
+        }
+        spat = nc < mp.thr[b];
+        if (mp.alg == 1) temp = false;
+    }
+    dec = spat ? 2 : (temp ? 1 : 0);
+    gL = 1.f; gR = 1.f;                                     // enhanceFactor = 1 (FastBinauralMasking.h:120)
+    if (dec != 0) {
+        switch (mp.method) {                                // maskFrame :294-313
+        case 3: gL = gR = 1.f / 1000.f; break;              // FULL: zeroFrame :214-217
+        case 0: gL = gR = 1.f / (dec == 2 ? 10.f : 3.f); break;   // FACTOR :289-292 with .h:116-117
+        case 1: {                                           // RELATIVE: maskFrameByScaling :245-287
+            float fl = (S_LL / (float)FFT_K) * mp.rho, fr = (S_RR / (float)FFT_K) * mp.rho;
+            if (Q < 1e-10f) { fl = mp.rho; fr = mp.rho; } else { fl /= Q; fr /= Q; }
+            gL = sqrtf(fl); gR = sqrtf(fr);
+            break;
+        }
+        case 4: {                                           // NOISY: noisyFrame :219-243 (inactive during the first two frames)
+            if (gframe >= 2) {
+                const float pl = sqrtf(S_LL512 / (float)FFT_H), pr = sqrtf(S_RR512 / (float)FFT_H);
+                gL = pl > 0.f ? noise_b / pl : 1.f;
+                gR = pr > 0.f ? noise_b / pr : 1.f;
+            }
+            break;
+        }
+        default: break;
+        }
+    }
+}
+
+
+__global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);                  // [MK_NB][2][FFT_SCRATCH]
+    float4 *binq = reinterpret_cast<float4 *>(spec + MK_NB * 2 * FFT_SCRATCH);   // [MK_NB][520]
+    float2 *tab = reinterpret_cast<float2 *>(binq + MK_NB * 520);          // [TW_WORDS]
+    float *sums = reinterpret_cast<float *>(tab + TW_WORDS);               // [MK_NB][48][6]
+    float *gains = sums + MK_NB * 48 * 6;                                  // [MK_NB][48][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.y;
+    const MaskParams &mp = *p.mp;
+    const int t0 = blockIdx.x * p.ft, t1 = min(t0 + p.ft, p.n_frames);
+    const int tfull = t0 > 0 ? t0 - 1 : 0;                 // first frame that is processed completely (OLA carry)
+    const int tbeg = t0 > 0 ? max(0, tfull - MK_WARM) : 0; // first frame of the Q warm-up
+    const bool passthrough = mp.method == 5;               // NOTHING :130-134
+
+    fft_table_init(tab, p.window, tid, 512);
+    __syncthreads();
+    FftTw tw{tab};
+
+    float Q = 0.f, noise_b = 0.f;
+    if (tid < 45) {
+        if (tbeg == 0) Q = p.Q_in[s * 45 + tid];
+        noise_b = p.noise[s * 45 + tid];
+    }
+    float carry[2] = {0.f, 0.f};
+    if (t0 == 0) { carry[0] = p.tail_in[(s * 2 + 0) * FFT_H + tid]; carry[1] = p.tail_in[(s * 2 + 1) * FFT_H + tid]; }
+    const int jw = wave >> 1, cw = wave & 1;
+    const float *base = p.pcm + (long long)s * p.stream_stride + (long long)cw * p.ch_stride;
+
+    for (int tb = tbeg; tb < t1; tb += MK_NB) {
+        const int nb = min(MK_NB, t1 - tb);
+        // (1) analysis: wave -> (frame jw, channel cw)
+        if (jw < nb) {
+            const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(tb + jw) * FFT_H);
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float2 x = src[lane + 64 * r], w = tw.win(r, lane);
+                v[r] = make_float2(x.x * w.x, x.y * w.y);
+            }
+            rfft1024(v, spec + (jw * 2 + cw) * FFT_SCRATCH, lane, tw);
+        }
+        __syncthreads();
+        // (2) per-bin products
+        for (int e = tid; e < nb * FFT_K; e += 512) {
+            const int j = e / FFT_K, k = e - j * FFT_K;
+            const float2 L = spec[(j * 2) * FFT_SCRATCH + k], R = spec[(j * 2 + 1) * FFT_SCRATCH + k];
+            const float mr = 0.5f * L.x + 0.5f * R.x, mi = 0.5f * L.y + 0.5f * R.y;   // divC(2) + add :510-512
+            binq[j * 520 + k] = make_float4(L.x * L.x + L.y * L.y, R.x * R.x + R.y * R.y, L.x * R.x + L.y * R.y, mr * mr + mi * mi);
+        }
+        __syncthreads();
+        // (3) band sums over the band's support, weight H_b[k]^2
+        {
+            const int j = tid >> 6, b = tid & 63;
+            if (j < nb && b < 45) {
+                float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+                for (int k = mp.lo[b]; k <= mp.hi[b]; ++k) {
+                    const float h = mp.kb[k] == b ? mp.kw0[k] : mp.kw1[k];
+                    const float w = h * h;
+                    const float4 q = binq[j * 520 + k];
+                    a0 += w * q.x; a1 += w * q.y; a2 += w * q.z;
+                    if (k < FFT_H) { a3 += w * q.w; a4 += w * q.x; a5 += w * q.y; }
+                }
+                float *o = sums + (j * 48 + b) * 6;
+                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
+            }
+        }
+        __syncthreads();
+        // (4) the recursion over frames (the only sequential part): thread = band
+        if (tid < 45) {
+            for (int j = 0; j < nb; ++j) {
+                const float *o = sums + (j * 48 + tid) * 6;
+                int dec; float gL, gR;
+                const long long gframe = p.frames_done + tb + j;
+                mask_decide(mp, tid, o[3], o[0], o[1], o[2], o[4], o[5], Q, noise_b, gframe, dec, gL, gR);
+                if (gframe == 0) noise_b = Q;                               // noise <- Q after the first call :193-197
+                gains[(j * 48 + tid) * 2] = gL; gains[(j * 48 + tid) * 2 + 1] = gR;
+                if (p.decisions && tb + j >= t0) p.decisions[((long long)s * p.n_frames + tb + j) * 45 + tid] = dec;
+            }
+        }
+        __syncthreads();
+        if (tb + nb > tfull) {
+            // (5) out[k] = X[k] * sum_b g_b H_b[k]  (Nyquist bin: gain 1)
+            for (int e = tid; e < nb * 2 * FFT_K; e += 512) {
+                const int jc = e / FFT_K, k = e - jc * FFT_K, j = jc >> 1, ch = jc & 1;
+                float m = 1.f;
+                if (!passthrough) {
+                    const int b0 = mp.kb[k];
+                    m = 0.f;
+                    if (b0 >= 0) {
+                        const float g0 = k < FFT_H ? gains[(j * 48 + b0) * 2 + ch] : 1.f;
+                        const float g1 = (k < FFT_H && b0 + 1 < 45) ? gains[(j * 48 + b0 + 1) * 2 + ch] : 1.f;
+                        m = g0 * mp.kw0[k] + g1 * mp.kw1[k];
+                    }
+                }
+                float2 x = spec[jc * FFT_SCRATCH + k];
+                spec[jc * FFT_SCRATCH + k] = make_float2(x.x * m, x.y * m);
+            }
+            __syncthreads();
+            // (6) synthesis
+            if (jw < nb) irfft1024(spec + (jw * 2 + cw) * FFT_SCRATCH, lane, tw);
+            __syncthreads();
+            // (7) overlap-add
+            for (int j = 0; j < nb; ++j) {
+                const int t = tb + j;
+                if (t < tfull) continue;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float *y = reinterpret_cast<const float *>(spec + (j * 2 + ch) * FFT_SCRATCH);
+                    if (t >= t0) p.out[((long long)s * 2 + ch) * (long long)p.n_frames * FFT_H + (long long)t * FFT_H + tid] = carry[ch] + y[tid];
+                    carry[ch] = y[tid + FFT_H];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (t1 == p.n_frames) {
+        p.tail_out[(s * 2 + 0) * FFT_H + tid] = carry[0];
+        p.tail_out[(s * 2 + 1) * FFT_H + tid] = carry[1];
+        if (tid < 45) { p.Q_out[s * 45 + tid] = Q; }
+    }
+    if (tid < 45 && p.frames_done == 0 && tbeg == 0) p.noise[s * 45 + tid] = noise_b;   // only one block per stream has tbeg == 0
+}
+
+// ---------------------------------------------------------------------------------------
+// one frame in double, the reference's own loop order (band by band), dense filter table
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double v, double *sred)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sred[wave] = v;
+    __syncthreads();
+    double r = sred[0];
+    for (int w = 1; w < nw; ++w) r += sred[w];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_mask_frame(MaskFrameArgs p)
+{
+    __shared__ double sred[4];
+    __shared__ double sg[2];
+    __shared__ int sdec;
+    const int tid = threadIdx.x, K = p.K, Kh = K - 1;    // Kh = N/2 complex bins = "first N doubles"
+    const double dK = (double)K, dKh = (double)Kh;
+    if (p.method == 5) return;                            // NOTHING :130-134
+    for (int b = 0; b < 45; ++b) {
+        const double *H = p.H + (long long)b * K;
+        double s_mix = 0, s_ll = 0, s_rr = 0, s_lr = 0, s_ll_h = 0, s_rr_h = 0;
+        for (int k = tid; k < K; k += 256) {
+            const double h = H[k];
+            const double lr = p.L[2 * k] * h, li = p.L[2 * k + 1] * h, rr = p.R[2 * k] * h, ri = p.R[2 * k + 1] * h;
+            const double ll = lr * lr + li * li, rrr = rr * rr + ri * ri;
+            s_ll += ll; s_rr += rrr; s_lr += lr * rr + li * ri;
+            if (k < Kh) {
+                const double mr = lr / 2 + rr / 2, mi = li / 2 + ri / 2;
+                s_mix += mr * mr + mi * mi; s_ll_h += ll; s_rr_h += rrr;
+            }
+        }
+        s_mix = block_sum_d(s_mix, sred); s_ll = block_sum_d(s_ll, sred); s_rr = block_sum_d(s_rr, sred);
+        s_lr = block_sum_d(s_lr, sred); s_ll_h = block_sum_d(s_ll_h, sred); s_rr_h = block_sum_d(s_rr_h, sred);
+        if (tid == 0) {
+            const double P = sqrt(s_mix / dKh);
+            double Q = p.Q[b] * p.lambda + p.one_minus_lambda * P;
+            p.Q[b] = Q;
+            bool temp = P < p.reject * Q, spat = false;
+            if (p.alg == 0 || p.alg == 1) {
+                const double num = s_lr / dK;
+                double nc;
+                if (num == 0) nc = 0;
+                else { const double den = sqrt((s_ll / dK) * (s_rr / dK)); nc = den == 0 ? 1 : num / den; }
+                spat = nc < p.thr[b];
+                if (p.alg == 1) temp = false;
+            }
+            const int dec = spat ? 2 : (temp ? 1 : 0);
+            double gL = 1, gR = 1;
+            if (dec != 0) {
+                if (p.method == 3) gL = gR = 1.0 / 1000;
+                else if (p.method == 0) gL = gR = 1.0 / (double)(dec == 2 ? 10.f : 3.f);
+                else if (p.method == 1) {
+                    double fl = (s_ll / dK) * p.rho, fr = (s_rr / dK) * p.rho;
+                    if (Q < 1e-10) { fl = p.rho; fr = p.rho; } else { fl /= Q; fr /= Q; }
+                    gL = sqrt(fl); gR = sqrt(fr);
+                } else if (p.method == 4 && p.first_call >= 2) {
+                    const double pl = sqrt(s_ll_h / dKh), pr = sqrt(s_rr_h / dKh);
+                    gL = pl > 0 ? p.noise[b] / pl : 1; gR = pr > 0 ? p.noise[b] / pr : 1;
+                }
+            }
+            sg[0] = gL; sg[1] = gR; sdec = dec;
+            if (p.decisions) p.decisions[b] = dec;
+        }
+        __syncthreads();
+        const double gL = sg[0], gR = sg[1];
+        for (int k = tid; k < K; k += 256) {
+            const double h = H[k];
+            const double ml = k < Kh ? gL : 1.0, mr = k < Kh ? gR : 1.0;
+            p.outL[2 * k] += p.L[2 * k] * h * ml; p.outL[2 * k + 1] += p.L[2 * k + 1] * h * ml;
+            p.outR[2 * k] += p.R[2 * k] * h * mr; p.outR[2 * k + 1] += p.R[2 * k + 1] * h * mr;
+        }
+        __syncthreads();
+    }
+    if (tid < 45 && p.first_call == 0) p.noise[tid] = p.Q[tid];      // :193-197
+}
+
+}  // namespace mca

@@ -415,4 +415,96 @@ __global__ __launch_bounds__(512, CPW == 1 ? 4 : 2) void k_beamform_ola(Beamform
 template __global__ void k_beamform_ola<1>(BeamformArgs);
 template __global__ void k_beamform_ola<2>(BeamformArgs);
 
+// --------------------------------------------------------------------------------------
+// k_gcc2_scan -- FreqGCCBinauralLocalisation, deterministic part (BinauralLocalisation.cpp:438-523)
+// --------------------------------------------------------------------------------------
+// grid (chunks, arrays), thread d = steering delay.  Phase 1: corr_t = (1-mu) R_t + mu corr_{t-1}
+// (:445-448; mu = 0 on the stream's very first frame, 0.8f afterwards, :323,:523) with the same
+// 128-frame warm-up as k_scan_pick; the smoothed correlation of the last GCC2_DOAWARM warm-up
+// frames and of the chunk is kept in LDS.  Phase 2: one wave per frame: first-max argmax (:502),
+// min and sum (setProbability :584-588).  Phase 3: one thread runs the scalar DOA recursion
+// DOA = m DOA + (1-m) angle (:504, m = 0.6f; 0.6^64 = 6e-15 so 64 warm-up frames suffice) and the
+// interpolated probability of the PREVIOUS DOA (:454, :590-630) in frame order.
+__global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int D = p.D, Dl = p.Dp + 8;
+    float *sC = reinterpret_cast<float *>(smem_raw);                    // [GCC2_DOAWARM + chunk][Dl]
+    const int nslot = GCC2_DOAWARM + p.chunk;
+    int *sIdx = reinterpret_cast<int *>(sC + nslot * Dl);               // [nslot]
+    float *sMin = reinterpret_cast<float *>(sIdx + nslot);              // [nslot]
+    float *sSum = sMin + nslot;                                         // [nslot]
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
+    const int a = blockIdx.y;
+    const int t_start = blockIdx.x * p.chunk, t_end = min(t_start + p.chunk, p.n_frames);
+    const int keep_start = max(0, t_start - GCC2_DOAWARM);             // first frame whose corr is kept
+    const int warm_start = max(0, keep_start - SCAN_WARM);
+    const float *C = p.C + (long long)a * p.n_frames * p.Dp;
+    if (d < D) {
+        float c = warm_start == 0 ? p.corr_in[(long long)a * D + d] : 0.f;
+        for (int t = warm_start; t < t_end; ++t) {
+            const bool first = (p.frames_done + t) == 0;                // _corrMemoryFactor = 0 on the first frame
+            const float r = C[(long long)t * p.Dp + d];
+            c = first ? r : (p.one_minus_mu * r + p.mu * c);            // :445-447
+            if (t >= keep_start) sC[(t - keep_start) * Dl + d] = c;
+            if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + t) * D + d] = c;
+        }
+        if (t_end == p.n_frames) p.corr_out[(long long)a * D + d] = c;  // _prevCorrelationsReal :448
+    }
+    __syncthreads();
+    for (int tl = wave; tl < t_end - keep_start; tl += nwaves) {
+        const float *cr = sC + tl * Dl;
+        float bv = -INFINITY, mn = INFINITY, sm = 0.f; int bi = 0x7fffffff;
+        for (int dd = lane; dd < D; dd += 64) {
+            const float v = cr[dd];
+            if (v > bv) { bv = v; bi = dd; }
+            mn = fminf(mn, v); sm += v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off); const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            mn = fminf(mn, __shfl_xor(mn, off));
+            sm += __shfl_xor(sm, off);
+        }
+        if (lane == 0) { sIdx[tl] = bi; sMin[tl] = mn; sSum[tl] = sm; }
+    }
+    __syncthreads();
+    if (d == 0) {
+        float doa = keep_start == 0 ? p.doa_in[a] : 0.f;
+        const float halfpi = 1.57079632679489661923f;
+        for (int t = keep_start; t < t_end; ++t) {
+            const int tl = t - keep_start;
+            const float *cr = sC + tl * Dl;
+            if (t >= t_start) {
+                // setProbability(_currentDOA, _prob, 1) with the DOA of the previous frame (:454)
+                const float mn = sMin[tl];
+                const float sum = sSum[tl] - mn * (float)D;              // :588
+                float ang = fminf(fmaxf(doa, -halfpi), halfpi);          // angle2DOAidx :110-115
+                int idx = (int)((ang + halfpi) / p.step);
+                idx = min(max(idx, 0), D - 1);
+                const float angle = p.grid[idx];
+                float pr;
+                if (0 < idx && idx < D - 1) {
+                    float pc, nc, pd, nd;
+                    if (angle > doa) { pc = cr[idx - 1]; pd = p.grid[idx - 1]; nc = cr[idx]; nd = angle; }
+                    else { pc = cr[idx]; pd = angle; nc = cr[idx + 1]; nd = p.grid[idx + 1]; }
+                    pr = (nc - pc) / (nd - pd) * (doa - pd) + pc;
+                } else pr = cr[idx];
+                float pb = sum > 0.f ? (pr - mn) / sum : 0.f;
+                pb = pb < 0.01f ? 0.f : pb;
+                if (p.prob) p.prob[(long long)a * p.n_frames + t] = pb;
+            }
+            const bool first = (p.frames_done + t) == 0;
+            const float angle = p.grid[sIdx[tl]];                        // doaIdx2angle(idx) :503
+            doa = first ? angle : (p.doa_mem * doa + p.one_minus_doa_mem * angle);   // :504
+            if (t >= t_start) {
+                p.argmax[(long long)a * p.n_frames + t] = sIdx[tl];
+                if (p.doa_rad) p.doa_rad[(long long)a * p.n_frames + t] = doa;
+            }
+        }
+        if (t_end == p.n_frames) p.doa_out[a] = doa;
+    }
+}
+
 }  // namespace mca

@@ -7,7 +7,10 @@
 
 namespace mca {
 
+constexpr int MK_NB = 4;           // frames per batch of k_mask_stream (8 waves = 4 frames x 2 channels)
+constexpr int MK_WARM = 8;         // frames of Q warm-up for mask chunks that do not start a stream (0.04^8 = 6.6e-12)
 constexpr int BF_NB = 4;           // frames per inverse-FFT batch of k_beamform_ola
+constexpr int GCC2_DOAWARM = 64;   // frames of DOA-recursion warm-up in k_gcc2_scan (0.6^64 = 6e-15)
 constexpr int SCAN_WARM = 128;    // frames of IIR warm-up per scan chunk (0.8^128 = 4e-13)
 
 struct StftPhatArgs {
@@ -69,6 +72,51 @@ struct BeamformArgs {
     float *out;              // [arrays][S][n_frames*hop]
     const float *tail_in;    // [arrays][S][hop] overlap-add carry at entry
     float *tail_out;         // at exit
+};
+
+struct Gcc2ScanArgs {
+    const float *C;          // [arrays][n_frames][Dp] un-smoothed GCC-PHAT R_t[d]
+    int n_frames, Dp, D, chunk;
+    long long frames_done;   // frames this context has processed before this call (0 = stream start)
+    float mu, one_minus_mu;  // _maxCorrMemoryFactor 0.8f and 1 - 0.8f (float arithmetic)
+    float doa_mem, one_minus_doa_mem;   // _maxDoaMemoryFactor 0.6f
+    float step;              // _doaStep
+    const float *corr_in; float *corr_out;      // [arrays][D] _prevCorrelationsReal
+    const float *doa_in; float *doa_out;        // [arrays] _currentDOA
+    const float *grid;       // [D]
+    int *argmax; float *doa_rad; float *prob; float *corr;
+};
+
+struct MaskParams {
+    float thr[45];
+    int lo[45], hi[45];       // support of band b (bins with H_b > 0), lo > hi for an empty band
+    int kb[513];              // first band covering bin k (the second one is kb+1), -1 if none
+    float kw0[513], kw1[513]; // H_kb[k], H_{kb+1}[k]
+    float lambda, one_minus_lambda, reject, rho;
+    int method, alg;
+};
+
+struct MaskArgs {
+    const float *pcm;
+    long long stream_stride, ch_stride;
+    int n_frames, ft;
+    long long frames_done;
+    const float *window;
+    const MaskParams *mp;
+    const float *Q_in; float *Q_out; float *noise;      // [streams][45]
+    const float *tail_in; float *tail_out;              // [streams][2][512]
+    float *out; int *decisions;
+};
+
+struct MaskFrameArgs {
+    const double *L, *R;      // [K] complex (CCS)
+    double *outL, *outR;      // [K] complex, zeroed by the caller
+    const double *H;          // [45][K] filter magnitudes
+    const double *thr;        // [45]
+    double *Q, *noise;        // [45] state
+    int K, method, alg, first_call;
+    double lambda, one_minus_lambda, reject, rho;
+    int *decisions;
 };
 
 }  // namespace mca

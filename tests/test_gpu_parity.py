@@ -260,3 +260,131 @@ def test_full_size_properties(prec):
     # (5) checksum: the energy recursion is linear -- sum_d E_t = 0.8 sum_d E_{t-1} + 0.2 sum_d C_t is implied by
     #     the map; check prob (= normalised energy at the peak) stays inside its analytic bounds
     assert float(pr.max()) <= (28 * 513 + 15 * 28) / (30 * 28) + 1e-3 and float(pr.min()) >= 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-microphone GCC-PHAT path (FreqGCCBinauralLocalisation) and binaural masking
+# ---------------------------------------------------------------------------------------------
+def test_freqgcc_matches_golden_and_oracle(golden_dir):
+    g = _golden(golden_dir, "freqgcc_16k_d61")
+    fs, N = int(g["fs"]), int(g["N"])
+    loc = api.FreqGCCBinauralLocalisation(fs, g["xs"], False, float(g["step_deg"]))
+    assert loc.ctx.D == 61
+    r = loc.process(g["pcm"], want_corr=True)
+    assert np.array_equal(r["argmax"][0], g["argmax"])
+    assert np.abs(r["corr"][0] - g["corr"]).max() <= 2e-5 * np.abs(g["corr"]).max()
+    # longer stream vs the oracle, crossing the 32-frame chunks of the scan kernel
+    F = 150
+    pcm = synth.noise_source_stream(synth.BINAURAL, np.deg2rad(-42.0), fs, (F + 1) * N // 2, 8)
+    loc = api.FreqGCCBinauralLocalisation(fs, synth.BINAURAL, False, 3.0)
+    r = loc.process(pcm, want_corr=True)
+    og = po.FreqGCC(fs, synth.BINAURAL, N + 2, False, 3.0)
+    X = po.stft_frames(pcm.astype(np.float64), N)
+    prev_doa = 0.0
+    nbad = 0
+    for t in range(F):
+        voiced, corr, idx, doa, power = og.process(X[t, 0], X[t, 1])
+        assert voiced
+        if idx != r["argmax"][0, t]:
+            assert abs(corr[idx] - corr[r["argmax"][0, t]]) < 1e-5 * np.abs(corr).max()   # numerical tie
+            nbad += 1
+        assert np.abs(r["corr"][0, t] - corr).max() <= 2e-5 * np.abs(corr).max()
+        assert abs(r["doa"][0, t] - doa) <= 2e-5 + 0.06 * nbad
+        pr = og.set_probability(np.array([prev_doa]))[0]           # setProbability of the previous DOA (:454)
+        assert abs(r["prob"][0, t] - pr) <= 2e-4
+        prev_doa = doa
+    assert nbad <= 1
+    # state carries over calls
+    loc2 = api.FreqGCCBinauralLocalisation(fs, synth.BINAURAL, False, 3.0)
+    h = 70
+    ra = loc2.process(pcm[:, :(h + 1) * 512], want_corr=True)
+    rb = loc2.process(pcm[:, h * 512:], want_corr=True)
+    assert np.array_equal(np.concatenate([ra["argmax"], rb["argmax"]], axis=1), r["argmax"])
+    np.testing.assert_allclose(np.concatenate([ra["doa"], rb["doa"]], axis=1), r["doa"], atol=1e-5)
+
+
+def _mask_margins(m, X, t_count):
+    """oracle decisions plus a flag per (frame, band): decision sits within 1e-4 (relative) of a threshold"""
+    decs, near = [], []
+    for t in range(t_count):
+        Q_before = m.short_time_power
+        _, _, dec = m.process(X[t, 0], X[t, 1])
+        decs.append(dec)
+    return np.array(decs)
+
+
+@pytest.mark.parametrize("name", ["mask_relative_both", "mask_full_both", "mask_factor_temporal", "mask_noisy_spatial"])
+def test_masking_stream_matches_golden(golden_dir, name):
+    g = _golden(golden_dir, name)
+    fs, N = int(g["fs"]), int(g["N"])
+    m = api.FastBinauralMasking(fs, float(g["d"]), float(g["flo"]), float(g["fhi"]), int(g["method"]), int(g["alg"]))
+    thr, cen = m.thresholds()
+    np.testing.assert_allclose(thr, g["thresholds"], atol=1e-14)
+    np.testing.assert_allclose(cen, g["center"], atol=1e-15)
+    out, dec = m.process(np.stack([g["left"], g["right"]]))
+    ndiff = int((dec[0] != g["decisions"]).sum())
+    assert ndiff == 0, "decisions differ in %d (frame, band) cells" % ndiff
+    assert np.abs(out[0] - g["out"]).max() <= 2e-5 * np.abs(g["out"]).max() + 1e-7
+
+
+def test_masking_hook_double_matches_oracle(golden_dir):
+    g = _golden(golden_dir, "mask_relative_both")
+    fs, N = int(g["fs"]), int(g["N"])
+    X = po.stft_frames(np.stack([g["left"], g["right"]]).astype(np.float64), N)
+    for method, alg in ((api.RELATIVE, api.BOTH), (api.NOISY, api.SPATIAL), (api.FACTOR, api.TEMPORAL), (api.FULL, api.BOTH)):
+        m = api.FastBinauralMasking(fs, float(g["d"]), float(g["flo"]), float(g["fhi"]), method, alg)
+        o = po.Masking(fs, N, float(g["d"]), float(g["flo"]), float(g["fhi"]), method, alg)
+        for t in range(X.shape[0]):
+            l, r, dec = m.process_parametrisation(X[t, 0], X[t, 1])
+            ol, orr, odec = o.process(X[t, 0], X[t, 1])
+            assert np.array_equal(dec, odec), (method, alg, t)
+            np.testing.assert_allclose(l, ol, rtol=0, atol=1e-10 * np.abs(ol).max())
+            np.testing.assert_allclose(r, orr, rtol=0, atol=1e-10 * np.abs(orr).max())
+        m.close()
+
+
+def test_masking_long_stream_chunks_and_reference_windows():
+    """The reference's own masking tests (test/test_mcarray.cpp:892-1065) through the HIP path, long enough to
+    cross the 64-frame chunks of the kernel: band-power windows 70+-10 dB, 2+-0.5 dB -> 5+-1 dB."""
+    from scipy import signal
+    fs, N = 16000, 1024
+    magn = 5000
+    delay = int(0.1 * fs)
+    tonestep = int(0.1 * fs)
+    n = 50 * 1024
+    tone = np.zeros(n)
+    i, sfreq, interest_start = 0, np.float32(0.01), 0
+    while i < n - tonestep and sfreq < 0.5:
+        if np.float32(0.2) - np.float32(0.005) < sfreq < np.float32(0.2) + np.float32(0.005):
+            interest_start = i
+        tone[i:i + tonestep] = synth.tone16(tonestep, magn, float(sfreq))
+        i += tonestep
+        sfreq = np.float32(sfreq + np.float32(0.01))
+    sig = np.zeros(n)
+    tb = tone.copy()
+    for k in range(6):
+        tb = np.trunc(tb / 2)
+        sig[delay * k:] += tb[:n - delay * k]
+    F = n // 512 - 1
+    pcm = np.stack([sig, sig])[:, :(F + 1) * 512].astype(np.float32)
+    m = api.FastBinauralMasking(fs, 0.086, 500, 5000, api.FULL, api.BOTH)
+    out, dec = m.process(pcm)
+    o = po.Masking(fs, N, 0.086, 500, 5000, po.FULL, po.BOTH)
+    ol, orr = o.stream(pcm[0].astype(np.float64), pcm[1].astype(np.float64))
+    # same decisions as the oracle except threshold ties (identical channels make ncorr == 1 exactly: no spatial ties)
+    X = po.stft_frames(pcm.astype(np.float64), N)
+    o2 = po.Masking(fs, N, 0.086, 500, 5000, po.FULL, po.BOTH)
+    odec = np.array([o2.process(X[t, 0], X[t, 1])[2] for t in range(F)])
+    assert (dec[0] != odec).mean() < 2e-3
+    agree = (dec[0] == odec).all(axis=1)
+    # frames whose decisions all agree must match the oracle's audio (two frames overlap per output hop)
+    ok = agree[1:] & agree[:-1]
+    hop = 512
+    err = np.abs(out[0, 0] - ol).reshape(F, hop).max(axis=1)[1:]
+    assert err[ok].max() <= 2e-5 * np.abs(ol).max() + 1e-3
+    sigf = signal.firwin(257, [0.19, 0.21], pass_zero=False, fs=1.0)
+    intf = signal.firwin(257, [0.15, 0.20], pass_zero=False, fs=1.0)
+    sl = slice(interest_start, interest_start + tonestep)
+    diff = lambda x: po.log_power(signal.lfilter(sigf, 1.0, x)[sl]) - po.log_power(signal.lfilter(intf, 1.0, x)[sl])
+    assert abs(diff(sig[:F * hop]) - 2) < 0.5
+    assert abs(diff(out[0, 0].astype(np.float64)) - 5) < 1.0
