@@ -124,13 +124,13 @@ struct RangeCallback : public LocalisationCallback {
 };
 
 // deterministic broadband far-field source: many random-phase sinusoids, analytic fractional delays
-static void make_source(const std::vector<double> &xs, double theta, int fs, int n, unsigned seed, std::vector<std::vector<double> > &ch)
+static void make_source(const std::vector<double> &xs, double theta, int fs, int n, unsigned seed, std::vector<std::vector<double> > &ch, double fspan = 15000.0)
 {
     const int NC = 400;
     std::vector<double> f(NC), ph(NC);
     unsigned s = seed;
     for (int i = 0; i < NC; ++i) {
-        s = s * 1664525u + 1013904223u; f[i] = 150.0 + (s >> 8) * (1.0 / 16777216.0) * 15000.0;
+        s = s * 1664525u + 1013904223u; f[i] = 150.0 + (s >> 8) * (1.0 / 16777216.0) * fspan;
         s = s * 1664525u + 1013904223u; ph[i] = (s >> 8) * (1.0 / 16777216.0) * 2 * M_PI;
     }
     ch.assign(xs.size(), std::vector<double>(n));
@@ -221,6 +221,49 @@ static void testHookMatchesStream()
     std::printf("hook vs stream DOA[last] %.3f / %.3f deg\n", ca.doa.back(), cb.doa.back());
 }
 
+static void testBinauralModules()
+{
+    // FreqGCCBinauralLocalisation: 2 mics 0.086 m, 16 kHz, 3 degree grid (BinauralLocalisation.cpp:328), broadband source
+    const int fs = 16000;
+    const std::vector<double> xs = {0.0, 0.086};
+    ArrayDescription mics = ArrayDescription::make_linear_array_description(xs);
+    for (int doa = -60; doa <= 60; doa += 30) {
+        FreqGCCBinauralLocalisation loc(fs, mics, false);
+        RangeCallback cb(doa - 4, doa + 4);
+        loc.setCallback(&cb);
+        std::vector<std::vector<double> > ch;
+        const int n = 20 * loc.getFrameSize();
+        make_source(xs, doa * M_PI / 180, fs, n, 300u + doa, ch, 7000.0);
+        for (auto &c : ch) for (auto &v : c) v *= 0.3;
+        std::vector<double *> in = {ch[0].data(), ch[1].data()};
+        const int frames = loc.process(in, n);
+        EXPECT(frames == 19 && cb.calls == 19);
+        EXPECT(cb.bad <= 3);   // the DOA smoothing (0.6) needs a few frames to settle from 0
+        std::printf("FreqGCC DOA %d: %d callbacks, %d out of range\n", doa, cb.calls, cb.bad);
+    }
+    // FastBinauralMasking: NOTHING leaves the frames untouched (FastBinauralMasking.cpp:130-134) -> STFT/ISTFT identity;
+    // FULL on two uncorrelated channels attenuates (spatial mask, -60 dB per masked band)
+    std::vector<std::vector<double> > ch;
+    const int n = 24 * 512;
+    make_source(xs, 0.0, fs, n, 9u, ch, 7000.0);
+    std::vector<std::vector<double> > other;
+    make_source(xs, 0.0, fs, n, 10u, other, 7000.0);
+    for (int pass = 0; pass < 2; ++pass) {
+        FastBinauralMasking m(fs, 0.086, 500, 5000, pass == 0 ? BinauralMasking::NOTHING : BinauralMasking::FULL, BinauralMasking::BOTH);
+        EXPECT(m.getWindowSize() == 1024 && m.getNumberOfChannels() == 2);
+        std::vector<double *> in = {ch[0].data(), pass == 0 ? ch[1].data() : other[1].data()};
+        std::vector<std::vector<double> > ob(2, std::vector<double>(n));
+        std::vector<double *> out = {ob[0].data(), ob[1].data()};
+        const int produced = m.process(in, n, out, n);
+        EXPECT(produced == n - 512);
+        double eo = 0, ei = 0, ed = 0;
+        for (int i = 512; i < produced; ++i) { eo += ob[0][i] * ob[0][i]; ei += ch[0][i] * ch[0][i]; ed += (ob[0][i] - ch[0][i]) * (ob[0][i] - ch[0][i]); }
+        if (pass == 0) EXPECT(ed < 1e-10 * ei);
+        else EXPECT(eo < 0.05 * ei);
+        std::printf("masking pass %d: out/in %.2f dB\n", pass, 10 * std::log10(eo / ei + 1e-300));
+    }
+}
+
 int main(int argc, char **argv)
 {
     const bool cpu_only = argc > 1 && std::string(argv[1]) == "--cpu";
@@ -230,6 +273,7 @@ int main(int argc, char **argv)
             testBeamformingSeparation();
             testBeamformingSoundLocalisation();
             testHookMatchesStream();
+            testBinauralModules();
         } catch (const MCArrayException &e) {
             std::printf("FAIL: MCArrayException: %s\n", e.what());
             ++g_fail;
