@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,7 +28,7 @@ struct mca_hip_ctx {
     mca_hip_config cfg{};
     std::vector<double> xyz;
     int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, Kp = 0, S = 1, prec = 0;
-    bool ula = false, stream_ok = false;
+    bool ula = false, stream_ok = false, force_v1 = false;
     float step = 0.f;
     std::vector<float> delays, grid;
     std::vector<int2> pairs;
@@ -46,6 +47,8 @@ struct mca_hip_ctx {
     // workspace
     void *d_A = nullptr; size_t a_bytes = 0;
     float *d_C = nullptr; size_t c_bytes = 0;
+    bool c_split = false;          // the last contraction left two partial maps (split-K) in d_C
+    long long c_plane = 0;
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
     double *d_fr = nullptr; size_t fr_elems = 0;
@@ -167,7 +170,8 @@ void time_end(mca_hip_ctx *c, hipStream_t st)
 
 int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
 {
-    size_t need_a = (size_t)rows_chunk * c->a_row_elems * c->a_elem;
+    // rows rounded up to the 256-row tile of the split-K MFMA kernel, which loads whole tiles unclamped
+    size_t need_a = (size_t)((rows_chunk + 255) / 256 * 256) * c->a_row_elems * c->a_elem;
     if (need_a > c->a_bytes) {
         if (c->d_A) (void)hipFree(c->d_A);
         c->d_A = nullptr; c->a_bytes = 0;
@@ -175,7 +179,7 @@ int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
         HIP_TRY(c, hipMemset(c->d_A, 0, need_a));       // the Kp padding columns stay zero forever
         c->a_bytes = need_a;
     }
-    size_t need_c = (size_t)rows_total * c->Dp * sizeof(float);
+    size_t need_c = (size_t)rows_total * c->Dp * sizeof(float) * 2;   // room for the two partial maps of the split-K kernel
     if (need_c > c->c_bytes) {
         if (c->d_C) (void)hipFree(c->d_C);
         c->d_C = nullptr; c->c_bytes = 0;
@@ -280,6 +284,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     c->P = c->M * (c->M - 1) / 2;
     c->Dp = round_up(c->D, 192);
     c->stream_ok = (c->N == FFT_N);
+    c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switch for measurements
 
     // generateLookupTable (SteeringBeamforming.cpp:58-94): pairs i<j lexicographic, float delays
     c->delays.resize((size_t)c->P * c->D);
@@ -416,11 +421,27 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         ga.A = c->d_A; ga.B = c->d_B; ga.C = c->d_C;
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
         ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
-        dim3 g2((ga.rows + 127) / 128, c->Dp / 192);
+        ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
+        const bool v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && ga.rows >= 1024 && !c->force_v1;
+        c->c_split = v2; c->c_plane = ga.c_plane_elems;
         time_begin(c, MCA_HIP_K_SRP_GEMM, st);
-        if (c->prec == MCA_HIP_SRP_FP32) hipLaunchKernelGGL(k_srp_gemm_f32, g2, dim3(256), 0, st, ga);
-        else if (c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL(k_srp_gemm_f16<true>, g2, dim3(256), 0, st, ga);
-        else hipLaunchKernelGGL(k_srp_gemm_f16<false>, g2, dim3(256), 0, st, ga);
+        if (v2) {
+            const int np = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
+            const size_t smem = (size_t)3 * np * (256 + 384) * 32;
+            dim3 gv((ga.rows + 255) / 256, 2);
+            if (c->prec == MCA_HIP_SRP_FP16X3) {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_srp_gemm_f16_v2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                hipLaunchKernelGGL(k_srp_gemm_f16_v2<true>, gv, dim3(512), smem, st, ga);
+            } else {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_srp_gemm_f16_v2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                hipLaunchKernelGGL(k_srp_gemm_f16_v2<false>, gv, dim3(512), smem, st, ga);
+            }
+        } else {
+            dim3 g2((ga.rows + 127) / 128, c->Dp / 192);
+            if (c->prec == MCA_HIP_SRP_FP32) hipLaunchKernelGGL(k_srp_gemm_f32, g2, dim3(256), 0, st, ga);
+            else if (c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL(k_srp_gemm_f16<true>, g2, dim3(256), 0, st, ga);
+            else hipLaunchKernelGGL(k_srp_gemm_f16<false>, g2, dim3(256), 0, st, ga);
+        }
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
     }
@@ -439,13 +460,16 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
 
     ScanPickArgs pa{};
-    pa.C = c->d_C; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S; pa.chunk = c->Dp > 384 ? 16 : 32;
+    pa.C = c->d_C; pa.C2 = c->c_split ? c->d_C + c->c_plane : nullptr; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S; pa.chunk = 128;
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
     pa.state_in = c->d_E[c->e_cur]; pa.state_out = c->d_E[c->e_cur ^ 1];
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
     dim3 g3((n_frames + pa.chunk - 1) / pa.chunk, n_arrays);
     time_begin(c, MCA_HIP_K_SCAN_PICK, st);
-    hipLaunchKernelGGL(k_scan_pick, g3, dim3(round_up(c->D, 64)), (size_t)pa.chunk * (c->Dp + 8) * sizeof(float), st, pa);
+    const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
+    if (smem3 > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
+    hipLaunchKernelGGL(k_scan_pick, g3, dim3(round_up(c->D, 64)), smem3, st, pa);
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
     c->e_cur ^= 1;
@@ -470,15 +494,17 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     if (smem > 160 * 1024) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "n_mics/n_sources combination exceeds the 160 KiB LDS of a CU");
     dim3 g((n_frames + ba.ft - 1) / ba.ft, n_arrays);
     time_begin(c, MCA_HIP_K_BEAMFORM, st);
-    if (c->M <= 8) {
-        if (smem > 64 * 1024)
-            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_ola<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k_beamform_ola<1>, g, dim3(512), smem, st, ba);
-    } else {
-        if (smem > 64 * 1024)
-            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_ola<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k_beamform_ola<2>, g, dim3(512), smem, st, ba);
-    }
+    static const bool occ4 = std::getenv("MCA_HIP_BF_OCC2") == nullptr;     // A/B switch for measurements
+#define BF_LAUNCH(K)                                                                                                     \
+    do {                                                                                                                 \
+        if (smem > 64 * 1024)                                                                                            \
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(K, g, dim3(512), smem, st, ba);                                                               \
+    } while (0)
+    if (c->M <= 8 && occ4) BF_LAUNCH((k_beamform_ola<1, 4>));
+    else if (c->M <= 8) BF_LAUNCH((k_beamform_ola<1, 2>));
+    else BF_LAUNCH((k_beamform_ola<2, 2>));
+#undef BF_LAUNCH
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
     c->tail_cur ^= 1;
@@ -542,7 +568,7 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
     Gcc2ScanArgs ga{};
-    ga.C = c->d_C; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D; ga.chunk = 32;
+    ga.C = c->d_C; ga.C2 = c->c_split ? c->d_C + c->c_plane : nullptr; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D; ga.chunk = 32;
     ga.frames_done = c->gcc2_frames_done;
     ga.mu = 0.8f; ga.one_minus_mu = 1 - 0.8f;                      // _maxCorrMemoryFactor (BinauralLocalisation.h:198)
     ga.doa_mem = 0.6f; ga.one_minus_doa_mem = 1 - 0.6f;            // _maxDoaMemoryFactor (:199)

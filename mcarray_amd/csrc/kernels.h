@@ -6,10 +6,11 @@ namespace mca {
 
 template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat(StftPhatArgs p);
 __global__ void k_scan_pick(ScanPickArgs p);
-template <int CPW> __global__ void k_beamform_ola(BeamformArgs p);
+template <int CPW, int OCC> __global__ void k_beamform_ola(BeamformArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);
 template <bool SPLIT> __global__ void k_srp_gemm_f16(GemmArgs p);
+template <bool SPLIT> __global__ void k_srp_gemm_f16_v2(GemmArgs p);
 
 template <typename T> struct C2;
 template <typename T>

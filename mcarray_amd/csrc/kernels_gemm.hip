@@ -199,4 +199,146 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
 template __global__ void k_srp_gemm_f16<false>(GemmArgs);
 template __global__ void k_srp_gemm_f16<true>(GemmArgs);
 
+// ---------------------------------------------------------------------------------------
+// v2 of the fp16 contraction for Dp == 384 (the 361-angle grid): the v1 tile streams 35 B of
+// operands per CU-cycle from L2 for its MFMAs, which is what bounds it.  v2 holds a 256 x 384
+// output tile per workgroup (8 waves as 4 x 2, wave tile 64 x 192 = 2 x 6 MFMA tiles, 192
+// accumulator registers) -> 17 B/cycle, splits K over blockIdx.y (two partial maps, summed by the
+// scan kernel) so that 32 768 rows still give one workgroup per CU, and moves operands with
+// direct global->LDS loads (no staging registers, no ds_write) through a 3-stage ring of BK = 16
+// slices with ONE barrier per slice.  LDS rows are 32 B (two 16-B chunks); the physical chunk is
+// the logical one XOR ((row >> 3) & 1) -- applied on the per-lane SOURCE address of the LDS-DMA
+// and on the ds_read_b128 address -- which makes every 16-lane read group hit 16 distinct 4-bank
+// slots.
+// ---------------------------------------------------------------------------------------
+constexpr int V2_BM = 256, V2_BN = 384, V2_BK = 16, V2_ROWB = 32;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <bool SPLIT>
+__global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
+{
+    constexpr int NP = SPLIT ? 2 : 1;
+    constexpr int A_BYTES = V2_BM * V2_ROWB, B_BYTES = V2_BN * V2_ROWB;      // per plane
+    constexpr int STAGE = NP * (A_BYTES + B_BYTES);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0 = blockIdx.x * V2_BM;
+    const unsigned char *A = reinterpret_cast<const unsigned char *>(p.A);
+    const unsigned char *B = reinterpret_cast<const unsigned char *>(p.B);
+
+    // K slices of this workgroup
+    const int nslices = p.Kp / V2_BK;
+    const int per = (nslices + gridDim.y - 1) / gridDim.y;
+    const int s_beg = blockIdx.y * per, s_end = min(s_beg + per, nslices);
+    const int ns = s_end - s_beg;
+
+    // Operand movement: waves 0..3 are the LOADERS.  Each LDS-DMA instruction moves 32 rows x 32 B;
+    // loader w owns row blocks w, w+4, ... of every region (2 per A plane, 3 per B plane).  The other
+    // four waves go straight to their MFMAs, so on every SIMD (waves w and w+4 share one) the loader's
+    // DMA issue overlaps its partner's matrix work instead of both stalling in lock-step.
+    // The A workspace is allocated in multiples of 256 rows, so no row clamp is needed.
+    const bool loader = wave < 4;
+    const int lr = (wave & 3) * 32 + (lane >> 1);
+    const int lc = (lane & 1) ^ ((lane >> 4) & 1);             // logical chunk stored at this lane's physical position
+    const unsigned char *a_lane = A + ((long long)(row0 + lr) * p.a_row_elems + lc * 8) * 2;
+    const unsigned char *b_lane = B + ((long long)lr * p.Kp + lc * 8) * 2;
+    const long long a_blk = (long long)128 * p.a_row_elems * 2, a_pl = (long long)p.Kp * 2;
+    const long long b_blk = (long long)128 * p.Kp * 2, b_pl = (long long)p.Dp * p.Kp * 2;
+    const int dst_lane_blk = (wave & 3) * 1024;
+
+    f32x16 acc[2][6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int s, int buf) {
+        const long long koff = (long long)(s_beg + s) * V2_BK * 2;
+        unsigned char *sb = smem_g + buf * STAGE + dst_lane_blk;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + i * a_blk + koff),
+                                                 (lds_void_t *)(sb + pl * A_BYTES + i * 4096), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + i * b_blk + koff),
+                                                 (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + i * 4096), 16, 0, 0);
+        }
+    };
+
+    // fragment byte offsets inside a plane (slice-independent)
+    int a_off[2], b_off[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + (lane & 31);
+        a_off[i] = r * V2_ROWB + (((lane >> 5) ^ ((r >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int r = wn * 192 + j * 32 + (lane & 31);
+        b_off[j] = r * V2_ROWB + (((lane >> 5) ^ ((r >> 3) & 1)) << 4);
+    }
+
+    if (loader) {
+        if (ns > 0) issue(0, 0);
+        if (ns > 1) issue(1, 1);
+    }
+    for (int s = 0; s < ns; ++s) {
+        // slice s has landed once at most the loads of slice s+1 (5 * NP per loader wave) are outstanding
+        if (s + 1 < ns) {
+            if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (loader && s + 2 < ns) issue(s + 2, (s + 2) % 3);  // that buffer was last read in slice s-1
+        const unsigned char *st = smem_g + (s % 3) * STAGE;
+        f16x8 af[NP][2];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[pl][i] = *reinterpret_cast<const f16x8 *>(st + pl * A_BYTES + a_off[i]);
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            f16x8 bf[NP][3];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) bf[pl][jj] = *reinterpret_cast<const f16x8 *>(st + NP * A_BYTES + pl * B_BYTES + b_off[jh * 3 + jj]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    const int j = jh * 3 + jj;
+                    if constexpr (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][jj], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][jj], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][jj], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    float *Cp = p.C + (long long)blockIdx.y * p.c_plane_elems;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int frow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (frow < p.rows) {
+                const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
+                float *crow = Cp + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + wn * 192 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) crow[j * 32] = acc[i][j][r];
+            }
+        }
+}
+
+template __global__ void k_srp_gemm_f16_v2<false>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<true>(GemmArgs);
+
 }  // namespace mca

@@ -164,10 +164,11 @@ INST_STFT(16, true, _Float16)
 // --------------------------------------------------------------------------------------
 // k_scan_pick
 // --------------------------------------------------------------------------------------
-// grid (chunks, arrays).  Phase 1: thread d owns steering angle d, carries E[d] in a register
-// through the frames of its chunk and leaves the normalised energies of the chunk in LDS.  A chunk
+// grid (chunks, arrays).  The chunk is walked in sub-batches of SCAN_SUB frames.  Phase 1: thread d
+// owns steering angle d, carries E[d] in a register and leaves the normalised energies of the
+// sub-batch in LDS.  A chunk
 // that does not start at frame 0 warms the recursion up over the preceding SCAN_WARM frames from
-// zero (0.8^128 = 4e-13, below fp32 rounding of E), so chunks are independent.  Phase 2: one WAVE
+// zero (0.8^96 = 5e-10, below fp32 rounding of E), so chunks are independent.  Phase 2: one WAVE
 // per frame does selectDOA with no block barrier: lane l evaluates sd[d] for d = l + 64 i straight
 // from five neighbouring energies (sign of the first derivative, median-3, second derivative x
 // energy) and the argmax is a wave shuffle reduction with first-index tie-break.
@@ -180,7 +181,7 @@ __device__ __forceinline__ float median3f(float a, float b, float c)
 __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *sEn = reinterpret_cast<float *>(smem_raw);                   // [chunk][Dl]
+    float *sEn = reinterpret_cast<float *>(smem_raw);                   // [SCAN_SUB][Dl]
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
     const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
     const int t_start = blockIdx.x * p.chunk;
@@ -189,82 +190,91 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
+    const float *C2 = p.C2 ? p.C2 + (long long)a * p.n_frames * p.Dp : nullptr;
     const float mn = -15.f * (float)p.P;
+    auto ldc = [&](int t) { const long long o = (long long)t * p.Dp + d; return C2 ? C[o] + C2[o] : C[o]; };
+    float E = 0.f;
     if (act) {
-        float E = warm_start == 0 ? p.state_in[(long long)a * D + d] : 0.f;
+        E = warm_start == 0 ? p.state_in[(long long)a * D + d] : 0.f;
         int t = warm_start;
         for (; t + 8 <= t_start; t += 8) {              // 8 independent loads in flight per thread
             float c8[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) c8[i] = C[(long long)(t + i) * p.Dp + d];
+            for (int i = 0; i < 8; ++i) c8[i] = ldc(t + i);
 #pragma unroll
             for (int i = 0; i < 8; ++i) E = mu * E + omu * c8[i];
         }
-        for (; t < t_start; ++t) E = mu * E + omu * C[(long long)t * p.Dp + d];
-        for (; t + 8 <= t_end; t += 8) {
-            float c8[8];
+        for (; t < t_start; ++t) E = mu * E + omu * ldc(t);
+    }
+    for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
+        const int te = min(ts + SCAN_SUB, t_end);
+        if (act) {
+            int t = ts;
+            for (; t + 8 <= te; t += 8) {
+                float c8[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) c8[i] = C[(long long)(t + i) * p.Dp + d];
+                for (int i = 0; i < 8; ++i) c8[i] = ldc(t + i);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    E = mu * E + omu * c8[i];                                   // :134-140
+                    if (p.energy) p.energy[((long long)a * p.n_frames + t + i) * D + d] = E;
+                    sEn[(t + i - ts) * Dl + d] = (E - mn) / (-2.f * mn);        // :155-156
+                }
+            }
+            for (; t < te; ++t) {
+                E = mu * E + omu * ldc(t);
+                if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
+                sEn[(t - ts) * Dl + d] = (E - mn) / (-2.f * mn);
+            }
+        }
+        __syncthreads();
+        for (int tl = wave; tl < te - ts; tl += nwaves) {
+            const float *En = sEn + tl * Dl;
+            float sdv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                E = mu * E + omu * c8[i];                                   // :134-140
-                if (p.energy) p.energy[((long long)a * p.n_frames + t + i) * D + d] = E;
-                sEn[(t + i - t_start) * Dl + d] = (E - mn) / (-2.f * mn);   // :155-156
+                const int dd = lane + 64 * i;
+                float sd = -INFINITY;
+                if (dd < D - 2) {
+                    // fd(j) = 1 if En[j+1] - En[j] < 0 else 0, j in [0, D-2]; edges replicate (median_filter)
+                    const int j0 = max(dd - 1, 0), j3 = min(dd + 2, D - 2);
+                    const float e0 = En[j0], e1 = En[j0 + 1];
+                    const float ed = En[dd], ed1 = En[dd + 1], ed2 = En[dd + 2];
+                    const float e3 = En[j3], e4 = En[j3 + 1];
+                    const float fm1 = (e1 - e0) < 0.f ? 1.f : 0.f;        // fd(d-1) (or fd(0) at the edge)
+                    const float f0 = (ed1 - ed) < 0.f ? 1.f : 0.f;        // fd(d)
+                    const float f1 = (ed2 - ed1) < 0.f ? 1.f : 0.f;       // fd(d+1)
+                    const float f2 = (e4 - e3) < 0.f ? 1.f : 0.f;         // fd(d+2) (or fd(D-2) at the edge)
+                    const float m0 = median3f(fm1, f0, f1);               // filtered fd(d)     :164
+                    const float m1 = median3f(f0, f1, f2);                // filtered fd(d+1)
+                    sd = (m1 - m0) * ed1;                                  // :170-173
+                }
+                sdv[i] = sd;
+            }
+            for (int s = 0; s < p.S; ++s) {                                // :185-194
+                float bv = sdv[0]; int bi = lane;
+#pragma unroll
+                for (int i = 1; i < 8; ++i)
+                    if (sdv[i] > bv) { bv = sdv[i]; bi = lane + 64 * i; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (bi == lane + 64 * i) sdv[i] = 0.f;                 // _secondDerivative[maxIdx] = 0
+                if (lane == 0) {
+                    const long long o = ((long long)a * p.n_frames + ts + tl) * p.S + s;
+                    p.doa_bin[o] = bi + 1;
+                    if (p.doa_rad) p.doa_rad[o] = p.grid[bi + 1];          // doaIdx2angle(maxIdx+1)
+                    if (p.prob) p.prob[o] = bv;
+                }
             }
         }
-        for (; t < t_end; ++t) {
-            E = mu * E + omu * C[(long long)t * p.Dp + d];
-            if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
-            sEn[(t - t_start) * Dl + d] = (E - mn) / (-2.f * mn);
-        }
-        if (t_end == p.n_frames) p.state_out[(long long)a * D + d] = E;     // _prevEnergyInDOA (:143)
+        __syncthreads();
     }
-    __syncthreads();
-
-    for (int tl = wave; tl < t_end - t_start; tl += nwaves) {
-        const float *En = sEn + tl * Dl;
-        float sdv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int dd = lane + 64 * i;
-            float sd = -INFINITY;
-            if (dd < D - 2) {
-                // fd(j) = 1 if En[j+1] - En[j] < 0 else 0, j in [0, D-2]; edges replicate (median_filter)
-                const int j0 = max(dd - 1, 0), j3 = min(dd + 2, D - 2);
-                const float e0 = En[j0], e1 = En[j0 + 1];
-                const float ed = En[dd], ed1 = En[dd + 1], ed2 = En[dd + 2];
-                const float e3 = En[j3], e4 = En[j3 + 1];
-                const float fm1 = (e1 - e0) < 0.f ? 1.f : 0.f;        // fd(d-1) (or fd(0) at the edge)
-                const float f0 = (ed1 - ed) < 0.f ? 1.f : 0.f;        // fd(d)
-                const float f1 = (ed2 - ed1) < 0.f ? 1.f : 0.f;       // fd(d+1)
-                const float f2 = (e4 - e3) < 0.f ? 1.f : 0.f;         // fd(d+2) (or fd(D-2) at the edge)
-                const float m0 = median3f(fm1, f0, f1);               // filtered fd(d)     :164
-                const float m1 = median3f(f0, f1, f2);                // filtered fd(d+1)
-                sd = (m1 - m0) * ed1;                                  // :170-173
-            }
-            sdv[i] = sd;
-        }
-        for (int s = 0; s < p.S; ++s) {                                // :185-194
-            float bv = sdv[0]; int bi = lane;
-#pragma unroll
-            for (int i = 1; i < 8; ++i)
-                if (sdv[i] > bv) { bv = sdv[i]; bi = lane + 64 * i; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (bi == lane + 64 * i) sdv[i] = 0.f;                 // _secondDerivative[maxIdx] = 0
-            if (lane == 0) {
-                const long long o = ((long long)a * p.n_frames + t_start + tl) * p.S + s;
-                p.doa_bin[o] = bi + 1;
-                if (p.doa_rad) p.doa_rad[o] = p.grid[bi + 1];          // doaIdx2angle(maxIdx+1)
-                if (p.prob) p.prob[o] = bv;
-            }
-        }
-    }
+    if (act && t_end == p.n_frames) p.state_out[(long long)a * D + d] = E;     // _prevEnergyInDOA (:143)
 }
 
 // --------------------------------------------------------------------------------------
@@ -278,8 +288,8 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 // the Nyquist bins of the batch are finished in one pass (lane = slot); then wave w inverse
 // transforms the beamformed spectrum of batch slot w; then the 512 threads emit hop samples per
 // frame with the carry in a register.  LDS per workgroup ~69 KB (M = 8, S = 1): two per CU.
-template <int CPW>
-__global__ __launch_bounds__(512, CPW == 1 ? 4 : 2) void k_beamform_ola(BeamformArgs p)
+template <int CPW, int OCC>
+__global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int M = p.M, S = p.S, a = blockIdx.y;
@@ -332,14 +342,20 @@ __global__ __launch_bounds__(512, CPW == 1 ? 4 : 2) void k_beamform_ola(Beamform
         const int nb = min(BF_NB, t1 - tb);
         for (int j = 0; j < nb; ++j) {
             const int t = tb + j;
-            for (int e = tid; e < S * M * 49; e += 512) {
-                const int s = e / (M * 49), rem = e - s * (M * 49), c = rem / 49, q = rem - c * 49;
-                const int kk = q < 32 ? q : (q - 32) * 32;
-                double turns = (double)kk * (unit * p.mic_x[c] * cdoa[(t - tfirst) * S + s]);
-                turns -= rint(turns);
-                float sn, cs;
-                sincospif(2.0f * (float)turns, &sn, &cs);
-                steer[e] = make_float2(cs, sn);
+            // the table only changes when a source moved to another steering angle: sources are slow
+            // compared with the 10.7 ms hop, so most frames reuse the previous frame's phasors
+            bool same = t > tfirst;
+            for (int s = 0; s < S && same; ++s) same = cdoa[(t - tfirst) * S + s] == cdoa[(t - tfirst - 1) * S + s];
+            if (!same) {
+                for (int e = tid; e < S * M * 49; e += 512) {
+                    const int s = e / (M * 49), rem = e - s * (M * 49), c = rem / 49, q = rem - c * 49;
+                    const int kk = q < 32 ? q : (q - 32) * 32;
+                    double turns = (double)kk * (unit * p.mic_x[c] * cdoa[(t - tfirst) * S + s]);
+                    turns -= rint(turns);
+                    float sn, cs;
+                    sincospif(2.0f * (float)turns, &sn, &cs);
+                    steer[e] = make_float2(cs, sn);
+                }
             }
             // analysis of frame t
 #pragma unroll
@@ -412,8 +428,9 @@ __global__ __launch_bounds__(512, CPW == 1 ? 4 : 2) void k_beamform_ola(Beamform
     }
 }
 
-template __global__ void k_beamform_ola<1>(BeamformArgs);
-template __global__ void k_beamform_ola<2>(BeamformArgs);
+template __global__ void k_beamform_ola<1, 2>(BeamformArgs);
+template __global__ void k_beamform_ola<1, 4>(BeamformArgs);
+template __global__ void k_beamform_ola<2, 2>(BeamformArgs);
 
 // --------------------------------------------------------------------------------------
 // k_gcc2_scan -- FreqGCCBinauralLocalisation, deterministic part (BinauralLocalisation.cpp:438-523)
@@ -444,7 +461,8 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
         float c = warm_start == 0 ? p.corr_in[(long long)a * D + d] : 0.f;
         for (int t = warm_start; t < t_end; ++t) {
             const bool first = (p.frames_done + t) == 0;                // _corrMemoryFactor = 0 on the first frame
-            const float r = C[(long long)t * p.Dp + d];
+            const long long o = (long long)t * p.Dp + d;
+            const float r = p.C2 ? C[o] + (p.C2 + (long long)a * p.n_frames * p.Dp)[o] : C[o];
             c = first ? r : (p.one_minus_mu * r + p.mu * c);            // :445-447
             if (t >= keep_start) sC[(t - keep_start) * Dl + d] = c;
             if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + t) * D + d] = c;

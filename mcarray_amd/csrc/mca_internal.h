@@ -11,7 +11,8 @@ constexpr int MK_NB = 4;           // frames per batch of k_mask_stream (8 waves
 constexpr int MK_WARM = 8;         // frames of Q warm-up for mask chunks that do not start a stream (0.04^8 = 6.6e-12)
 constexpr int BF_NB = 4;           // frames per inverse-FFT batch of k_beamform_ola
 constexpr int GCC2_DOAWARM = 64;   // frames of DOA-recursion warm-up in k_gcc2_scan (0.6^64 = 6e-15)
-constexpr int SCAN_WARM = 128;    // frames of IIR warm-up per scan chunk (0.8^128 = 4e-13)
+constexpr int SCAN_WARM = 96;     // frames of IIR warm-up per scan chunk (0.8^96 = 5e-10 << fp32 epsilon)
+constexpr int SCAN_SUB = 32;      // frames per LDS sub-batch of k_scan_pick
 
 struct StftPhatArgs {
     const float *pcm;
@@ -50,10 +51,12 @@ struct GemmArgs {
     int rows;                // arrays * chunk_frames
     int chunk_frames, total_frames, frame0;
     int Kp, Dp, a_row_elems;
+    long long c_plane_elems;  // elements between the partial maps of a split-K launch
 };
 
 struct ScanPickArgs {
     const float *C;          // [arrays][n_frames][Dp]
+    const float *C2;         // second partial map of a split-K contraction (NULL if none)
     int n_frames, Dp, D, P, S, chunk;
     float mu, one_minus_mu;
     const float *state_in;   // [arrays][D]  E_prev at entry
@@ -76,6 +79,7 @@ struct BeamformArgs {
 
 struct Gcc2ScanArgs {
     const float *C;          // [arrays][n_frames][Dp] un-smoothed GCC-PHAT R_t[d]
+    const float *C2;         // second partial map of a split-K contraction (NULL if none)
     int n_frames, Dp, D, chunk;
     long long frames_done;   // frames this context has processed before this call (0 = stream start)
     float mu, one_minus_mu;  // _maxCorrMemoryFactor 0.8f and 1 - 0.8f (float arithmetic)

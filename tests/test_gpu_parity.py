@@ -78,6 +78,21 @@ def test_stream_vs_oracle_random_ula8_d361(prec):
     ctx.close()
 
 
+@pytest.mark.parametrize("prec", [api.SRP_FP16X3, api.SRP_FP16])
+def test_split_k_contraction_vs_oracle(prec):
+    # >= 1024 rows with 361 angles selects the 256 x 384 split-K MFMA kernel (two partial maps summed by the scan)
+    fs, N, F, A = 48000, 1024, 136, 8
+    xs = synth.ULA8
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-75.0 + 20.0 * a), fs, (F + 1) * N // 2, 500 + a) for a in range(A)])
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=prec, max_arrays=A)
+    r = ctx.process_frames_host(pcm, want_energy=True)
+    for a in (0, 5, 7):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, 0.5, want_map=True, want_audio=False)
+        _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=2)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= TOL_E[prec] * np.abs(o["energy"]).max()
+    ctx.close()
+
+
 def test_nonuniform_array_no_merging():
     # Reem-C has 6 distinct pair distances: G == P, the un-merged kernel variant
     fs, N, F = 48000, 1024, 20
@@ -207,7 +222,7 @@ def test_invalid_arguments_are_rejected():
         ctx.process_frames_host(np.zeros((2, 8, 2048), dtype=np.float32))   # more arrays than max_arrays
 
 
-@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3])
+@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16])
 def test_full_size_properties(prec):
     """BASELINE config 3 size (8 arrays x 4096 frames, 361 angles) through size-independent properties."""
     torch = pytest.importorskip("torch")

@@ -9,8 +9,8 @@ import sys
 def main(src, dst):
     f = sorted(glob.glob(src + "/**/*kernel_stats.csv", recursive=True))[0]
     rows = list(csv.DictReader(open(f)))
-    mine = [r for r in rows if "mca::" in r["Name"]]
-    other = [r for r in rows if "mca::" not in r["Name"]]
+    mine = [r for r in rows if "mca" in r["Name"]]
+    other = [r for r in rows if "mca" not in r["Name"]]
     with open(dst, "w", newline="") as out:
         w = csv.writer(out)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
