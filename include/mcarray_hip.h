@@ -66,7 +66,9 @@ typedef struct {
     const double *mic_xyz;     /* [M][3] metres, ArrayDescription coordinates (ArrayDescription.h:31-92) */
     double doa_step_deg;       /* SteeringBeamforming.cpp:39 hard-codes 5.0; BASELINE uses 0.5 */
     int n_sources;             /* numOfSources, 1..4 */
-    int use_power_floor;       /* usePowerFloor (frame API only; the stream API runs ungated like mcabeamf.cpp:194) */
+    int use_power_floor;       /* usePowerFloor (reference default true, SourceSeparationAndLocalisation.h:47): the stream API
+                                  then runs the power gate of BeamformingSeparationAndLocalisation.cpp:55-87 on the GPU;
+                                  the frame API exposes mca_hip_fft_log_power for the caller's gate */
     int srp_precision;         /* mca_hip_srp_precision */
     int max_arrays;            /* number of independent arrays whose state the context holds (>= 1) */
 } mca_hip_config;
@@ -123,6 +125,12 @@ int mca_hip_process_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long
                                long long mic_stride, int n_arrays, int n_frames,
                                int *doa_bin_dev, float *doa_rad_dev, float *prob_dev,
                                float *energy_dev, float *out_pcm_dev, void *stream);
+
+/* After a stream call on a context with use_power_floor = 1: copies, for the frames of that call,
+ * voiced[A][F] (1 where processFrameLocalisation passed the gate and the callback fires,
+ * BeamformingSeparationAndLocalisation.cpp:87-94) and power[A][F] (the value handed to setDOA).  Either may be NULL.
+ * Gated-out frames repeat the previous _currentDOA/_prob in the DOA outputs (initially 0 rad / -1, bin -1). */
+int mca_hip_copy_gate(mca_hip_ctx *ctx, unsigned char *voiced, float *power);
 
 /* Host-buffer variant of mca_hip_process_frames_dev (copies in, runs, copies out, synchronises);
  * pcm is [A][M][(F+1)*hop] contiguous; outputs as above, any of doa_rad/prob/energy/out_pcm may be NULL. */

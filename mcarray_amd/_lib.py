@@ -69,6 +69,7 @@ SYMBOLS = [
     ("mca_hip_process_frames_dev", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
       C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mca_hip_copy_gate", C.c_int, [C.c_void_p, C.c_void_p, c_fp]),
     ("mca_hip_process_frames_host", C.c_int,
      [C.c_void_p, c_fp, C.c_int, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp]),
     ("mca_hip_steering_process_frame", C.c_int,

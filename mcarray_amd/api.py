@@ -37,6 +37,7 @@ class Context:
         self.hop = fft_size // 2
         self.S = n_sources
         self.fs = sample_rate
+        self.use_power_floor = bool(use_power_floor)
         cfg = _lib.Config()
         cfg.struct_size = C.sizeof(_lib.Config)
         cfg.device = device
@@ -110,7 +111,14 @@ class Context:
             self.h, pcm.ctypes.data_as(fp), A, F, bins.ctypes.data_as(_lib.c_ip), doa.ctypes.data_as(fp),
             prob.ctypes.data_as(fp), energy.ctypes.data_as(fp) if want_energy else None,
             out.ctypes.data_as(fp) if want_audio else None))
-        return dict(bin=bins, doa=doa, prob=prob, energy=energy, out=out)
+        res = dict(bin=bins, doa=doa, prob=prob, energy=energy, out=out)
+        if self.use_power_floor:
+            voiced = np.empty((A, F), dtype=np.uint8)
+            power = np.empty((A, F), dtype=np.float32)
+            self._check(self._lib.mca_hip_copy_gate(self.h, voiced.ctypes.data_as(C.c_void_p), power.ctypes.data_as(fp)))
+            res["voiced"] = voiced
+            res["power"] = power
+        return res
 
     # ---- stream API, device tensors (torch used for memory only) ----
     def process_frames_dev(self, pcm, n_frames, doa_bin, doa_rad, prob, energy=None, out_pcm=None, stream=None,
@@ -231,9 +239,7 @@ class SourceSeparationAndLocalisation:
 
     def __init__(self, sample_rate, mic_positions, n_sources=1, use_power_floor=False, doa_step_deg=5.0, fft_size=1024,
                  srp_precision=SRP_FP32, device=0):
-        if use_power_floor:
-            raise MCArrayHipError("the stream API runs ungated (usePowerFloor=false, as mcabeamf.cpp:194)")
-        self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, n_sources, False, srp_precision, 1, device)
+        self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, n_sources, use_power_floor, srp_precision, 1, device)
         self.callback = None
 
     def set_callback(self, cb):
@@ -244,7 +250,9 @@ class SourceSeparationAndLocalisation:
         if self.callback is not None:
             deg = r["doa"][0].astype(np.float64) * (180.0 / np.pi)   # toDegrees (microhponeArrayHelpers.cpp:91-98)
             for t in range(deg.shape[0]):
-                self.callback(deg[t], r["prob"][0, t], None, self.ctx.S)
+                if "voiced" in r and not r["voiced"][0, t]:
+                    continue                                   # gated out: the reference does not call setDOA (:87-94)
+                self.callback(deg[t], r["prob"][0, t], r["power"][0, t] if "power" in r else None, self.ctx.S)
         return r["out"][0], r
 
 

@@ -41,6 +41,12 @@ struct mca_hip_ctx {
     float *d_E[2] = {nullptr, nullptr};
     float *d_tail[2] = {nullptr, nullptr};
     int e_cur = 0, tail_cur = 0;
+    // exact chunked scan + power gate
+    float *d_part = nullptr, *d_estart = nullptr; int *d_nv = nullptr; size_t scan_ws_chunks = 0;
+    float *d_power = nullptr; unsigned char *d_voiced = nullptr; float *d_power_out = nullptr; size_t gate_frames = 0;
+    double *d_gate_state = nullptr;
+    int *d_last_bin = nullptr; float *d_last_rad = nullptr, *d_last_prob = nullptr;
+    int last_arrays = 0, last_frames = 0;
     float *d_doa[2] = {nullptr, nullptr};   // 2-mic path: smoothed _currentDOA per array
     int doa_cur = 0;
     long long gcc2_frames_done = 0;
@@ -103,6 +109,8 @@ void free_ctx(mca_hip_ctx *c)
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_window); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]);
+    F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
+    F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -110,6 +118,19 @@ void free_ctx(mca_hip_ctx *c)
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// _currentDOA = 0, _prob = -1 (BeamformingSeparationAndLocalisation.cpp:51-52); no frame has fired yet -> bin -1
+int init_last_state(mca_hip_ctx *c, hipStream_t st)
+{
+    const size_t n = (size_t)c->cfg.max_arrays * MCA_MAX_SOURCES;
+    std::vector<int> b(n, -1); std::vector<float> pr(n, -1.f);
+    HIP_TRY(c, hipMemcpyAsync(c->d_last_bin, b.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->d_last_rad, 0, n * 4, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_last_prob, pr.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipMemsetAsync(c->d_gate_state, 0, (size_t)c->cfg.max_arrays * 4 * 8, st));
+    return MCA_HIP_OK;
+}
 
 // steering table B of the SRP contraction = precomputeTauMatrix (SteeringBeamforming.cpp:87-88)
 // for the first pair of every delay group, laid out for the MFMA kernels.
@@ -185,6 +206,33 @@ int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
         c->d_C = nullptr; c->c_bytes = 0;
         HIP_TRY(c, hipMalloc((void **)&c->d_C, need_c));
         c->c_bytes = need_c;
+    }
+    return MCA_HIP_OK;
+}
+
+int ensure_scan_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chunks)
+{
+    const size_t need = (size_t)n_arrays * n_chunks;
+    if (need > c->scan_ws_chunks) {
+        if (c->d_part) (void)hipFree(c->d_part);
+        if (c->d_estart) (void)hipFree(c->d_estart);
+        if (c->d_nv) (void)hipFree(c->d_nv);
+        c->d_part = c->d_estart = nullptr; c->d_nv = nullptr; c->scan_ws_chunks = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_part, need * c->D * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->d_estart, need * c->D * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->d_nv, need * 4));
+        c->scan_ws_chunks = need;
+    }
+    const size_t nf = (size_t)n_arrays * n_frames;
+    if (c->cfg.use_power_floor && nf > c->gate_frames) {
+        if (c->d_power) (void)hipFree(c->d_power);
+        if (c->d_voiced) (void)hipFree(c->d_voiced);
+        if (c->d_power_out) (void)hipFree(c->d_power_out);
+        c->d_power = c->d_power_out = nullptr; c->d_voiced = nullptr; c->gate_frames = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_power, nf * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->d_power_out, nf * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->d_voiced, nf));
+        c->gate_frames = nf;
     }
     return MCA_HIP_OK;
 }
@@ -338,12 +386,15 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = up((void **)&c->d_pairs, c->pairs.data(), c->pairs.size() * sizeof(int2))) ||
         (rc = zalloc((void **)&c->d_E[0], na * c->D * 4)) || (rc = zalloc((void **)&c->d_E[1], na * c->D * 4)) ||
         (rc = zalloc((void **)&c->d_tail[0], na * c->S * FFT_H * 4)) || (rc = zalloc((void **)&c->d_tail[1], na * c->S * FFT_H * 4)) ||
+        (rc = zalloc((void **)&c->d_gate_state, na * 4 * 8)) || (rc = zalloc((void **)&c->d_last_bin, na * MCA_MAX_SOURCES * 4)) ||
+        (rc = zalloc((void **)&c->d_last_rad, na * MCA_MAX_SOURCES * 4)) || (rc = zalloc((void **)&c->d_last_prob, na * MCA_MAX_SOURCES * 4)) ||
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
     }
     if (c->stream_ok && (rc = build_steering_table(c))) { g_create_error = c->err; free_ctx(c); return rc; }
+    if ((rc = init_last_state(c, nullptr))) { g_create_error = c->err; free_ctx(c); return rc; }
     *out = c;
     return MCA_HIP_OK;
 }
@@ -386,7 +437,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
         HIP_TRY(c, hipMemsetAsync(c->d_doa[i], 0, na * 4, st));
     }
     c->gcc2_frames_done = 0;
-    return MCA_HIP_OK;
+    return init_last_state(c, st);
 }
 
 int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
@@ -394,7 +445,9 @@ int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
     if (!c || n_arrays < 1 || n_frames < 1) return MCA_HIP_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     long long fc = chunk_frames_for(c, n_arrays, n_frames);
-    return ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames);
+    int rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames);
+    if (rc) return rc;
+    return ensure_scan_workspace(c, n_arrays, n_frames, (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK);
 }
 
 // STFT + PHAT + steering contraction for every frame: fills c->d_C [arrays][n_frames][Dp]
@@ -404,14 +457,16 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
     int rc;
     const long long fc = chunk_frames_for(c, n_arrays, n_frames);
     if ((rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames))) return rc;
+    if ((rc = ensure_scan_workspace(c, n_arrays, n_frames, (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK))) return rc;
     for (int f0 = 0; f0 < n_frames; f0 += (int)fc) {
         const int nf = (int)std::min<long long>(fc, n_frames - f0);
         StftPhatArgs sa{};
         sa.pcm = pcm; sa.array_stride = array_stride; sa.mic_stride = mic_stride;
         sa.M = c->M; sa.n_frames = nf; sa.frame0 = f0; sa.fpb = 8;
+        sa.power = c->cfg.use_power_floor ? c->d_power : nullptr; sa.total_frames = n_frames;
         sa.window = c->d_window; sa.A = c->d_A; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
         dim3 g1((nf + sa.fpb - 1) / sa.fpb, n_arrays);
-        const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2);
+        const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft<float>(c, sa, g1, smem1, st) : launch_stft<_Float16>(c, sa, g1, smem1, st);
         time_end(c, st);
@@ -459,19 +514,41 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
 
+    const bool gate = c->cfg.use_power_floor != 0;
+    time_begin(c, MCA_HIP_K_SCAN_PICK, st);
+    if (gate) {
+        GateArgs gg{};
+        gg.power_lin = c->d_power; gg.n_frames = n_frames; gg.fft_n = FFT_N;
+        gg.needed_samples = (int)(3.0 * c->cfg.sample_rate);              // _durationToEstimatePowerFloor (SoundLocalisationImpl.h:77)
+        gg.margin_db = 3.f;                                                // _noiseMarginDB (BeamformingSeparationAndLocalistaion.h:52)
+        gg.state = c->d_gate_state; gg.voiced = c->d_voiced; gg.power_out = c->d_power_out;
+        hipLaunchKernelGGL(k_gate, dim3(n_arrays), dim3(256), 0, st, gg);
+    }
     ScanPickArgs pa{};
-    pa.C = c->d_C; pa.C2 = c->c_split ? c->d_C + c->c_plane : nullptr; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S; pa.chunk = 128;
+    pa.C = c->d_C; pa.C2 = c->c_split ? c->d_C + c->c_plane : nullptr; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
+    pa.chunk = SCAN_CHUNK; pa.n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
     pa.state_in = c->d_E[c->e_cur]; pa.state_out = c->d_E[c->e_cur ^ 1];
+    pa.part = c->d_part; pa.nvoiced = c->d_nv; pa.e_start = c->d_estart; pa.voiced = gate ? c->d_voiced : nullptr;
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
-    dim3 g3((n_frames + pa.chunk - 1) / pa.chunk, n_arrays);
-    time_begin(c, MCA_HIP_K_SCAN_PICK, st);
+    const int nthr = round_up(c->D, 64);
+    dim3 g3(pa.n_chunks, n_arrays);
+    hipLaunchKernelGGL(k_scan_partial, g3, dim3(nthr), 0, st, pa);
+    hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays), dim3(nthr), 0, st, pa);
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
     if (smem3 > 64 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
-    hipLaunchKernelGGL(k_scan_pick, g3, dim3(round_up(c->D, 64)), smem3, st, pa);
+    hipLaunchKernelGGL(k_scan_pick, g3, dim3(nthr), smem3, st, pa);
+    if (gate) {
+        DoaFillArgs fa{};
+        fa.voiced = c->d_voiced; fa.n_frames = n_frames; fa.S = c->S;
+        fa.doa_bin = doa_bin; fa.doa_rad = doa_rad; fa.prob = prob;
+        fa.last_bin = c->d_last_bin; fa.last_rad = c->d_last_rad; fa.last_prob = c->d_last_prob;
+        hipLaunchKernelGGL(k_doa_fill, dim3(n_arrays), dim3(1024), 0, st, fa);
+    }
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
+    c->last_arrays = n_arrays; c->last_frames = n_frames;
     c->e_cur ^= 1;
     return MCA_HIP_OK;
 }
@@ -617,6 +694,19 @@ int mca_hip_gcc2_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int
     if (corr) TRY2(hipMemcpy(corr, d_corr, n_f * c->D * 4, hipMemcpyDeviceToHost));
 #undef TRY2
     cleanup();
+    return MCA_HIP_OK;
+}
+
+int mca_hip_copy_gate(mca_hip_ctx *c, unsigned char *voiced, float *power)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!c->cfg.use_power_floor) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "the context was created with use_power_floor = 0");
+    if (c->last_frames == 0) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "no stream call has run yet");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    const size_t n = (size_t)c->last_arrays * c->last_frames;
+    if (voiced) HIP_TRY(c, hipMemcpy(voiced, c->d_voiced, n, hipMemcpyDeviceToHost));
+    if (power) HIP_TRY(c, hipMemcpy(power, c->d_power_out, n * 4, hipMemcpyDeviceToHost));
     return MCA_HIP_OK;
 }
 

@@ -5,7 +5,11 @@
 namespace mca {
 
 template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat(StftPhatArgs p);
+__global__ void k_scan_partial(ScanPickArgs p);
+__global__ void k_scan_carry(ScanPickArgs p);
 __global__ void k_scan_pick(ScanPickArgs p);
+__global__ void k_gate(GateArgs p);
+__global__ void k_doa_fill(DoaFillArgs p);
 template <int CPW, int OCC> __global__ void k_beamform_ola(BeamformArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);

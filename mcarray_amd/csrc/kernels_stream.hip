@@ -84,12 +84,14 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
     const int M = MT > 0 ? MT : p.M;
     float2 *tab = smem + M * FFT_SCRATCH;                                 // [TW_WORDS] twiddles + window
     float2 *nyq = tab + TW_WORDS;                                         // [fpb][M] whitened Nyquist bins
+    float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);             // [fpb] sum_c sum_k w_k |X_c[k]|^2 (power gate)
     const int a = blockIdx.y;
     const int f_begin = blockIdx.x * p.fpb;
     const int f_end = min(f_begin + p.fpb, p.n_frames);
     constexpr int CPW = (MT > 0 && MT <= 8) ? 1 : 2;   // channels per FFT wave
 
     fft_table_init(tab, p.window, tid, 512);
+    if (tid < p.fpb) spow[tid] = 0.f;
     __syncthreads();
     FftTw tw{tab};
 
@@ -134,6 +136,16 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
 
         OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f) * (long long)p.a_row_elems;
         if (tid < M) nyq[(f - f_begin) * M + tid] = whiten(smem[tid * FFT_SCRATCH + FFT_H]);
+        if (p.power) {
+            // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) { const float2 z = smem[m * FFT_SCRATCH + tid]; acc += z.x * z.x + z.y * z.y; }
+            acc *= tid == 0 ? 1.f : 2.f;
+            if (tid < M) { const float2 z = smem[tid * FFT_SCRATCH + FFT_H]; acc += z.x * z.x + z.y * z.y; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+            if (lane == 0) atomicAdd(&spow[f - f_begin], acc);
+        }
         {
             const int k = tid;   // bins 0..511
             if constexpr (MT == 0)   // runtime M: whiten the thread's own column in place, pairs re-read it from LDS
@@ -142,6 +154,8 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
         }
         __syncthreads();
     }
+    if (p.power && tid < f_end - f_begin)
+        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = spow[tid] / ((float)FFT_N * (float)FFT_N) / (float)M;
     // Nyquist bins of the block's frames: lane = frame
     if (tid < f_end - f_begin) {
         OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
@@ -162,20 +176,118 @@ INST_STFT(8, false, _Float16) INST_STFT(8, true, _Float16)
 INST_STFT(16, true, _Float16)
 
 // --------------------------------------------------------------------------------------
-// k_scan_pick
+// k_gate -- the power gate of BeamformingSeparationAndLocalisation::processFrameLocalisation
+// (BeamformingSeparationAndLocalisation.cpp:55-87) for every frame of the batch
 // --------------------------------------------------------------------------------------
-// grid (chunks, arrays).  The chunk is walked in sub-batches of SCAN_SUB frames.  Phase 1: thread d
-// owns steering angle d, carries E[d] in a register and leaves the normalised energies of the
-// sub-batch in LDS.  A chunk
-// that does not start at frame 0 warms the recursion up over the preceding SCAN_WARM frames from
-// zero (0.8^96 = 5e-10, below fp32 rounding of E), so chunks are independent.  Phase 2: one WAVE
-// per frame does selectDOA with no block barrier: lane l evaluates sd[d] for d = l + 64 i straight
-// from five neighbouring energies (sign of the first derivative, median-3, second derivative x
-// energy) and the argmax is a wave shuffle reduction with first-index tie-break.
+// grid (arrays).  The floor estimation accumulates FFTPower * N over the first 3 s of a stream
+// (:57-66, sequential by nature, at most ~141 frames: thread 0); every later frame is independent:
+// voiced = 10 log10(FFTPower) > floor (:83,:87).  During the estimation setPowerFloor returns the
+// running _powerFloor itself, so `power > _powerFloor` is false and those frames never fire.
+__global__ __launch_bounds__(256) void k_gate(GateArgs p)
+{
+    __shared__ int s_first_free;     // first frame after the estimation phase
+    __shared__ double s_floor;
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const float *pl = p.power_lin + (long long)a * p.n_frames;
+    double *st = p.state + (long long)a * 4;
+    if (tid == 0) {
+        double acc = st[0], consumed = st[1], floor_db = st[2];
+        bool est = st[3] != 0.0;
+        int t = 0;
+        for (; t < p.n_frames && !est; ++t) {
+            acc += (double)pl[t] * (double)p.fft_n;                      // _powerFloor += FFTPower * (fftCCSLength - 2) :58-59
+            consumed += (double)p.fft_n;                                 // :60
+            double shown = acc;
+            if (consumed >= (double)p.needed_samples) {                  // :62-67
+                est = true;
+                floor_db = 10.0 * log10(acc / consumed) + (double)p.margin_db;
+                acc = floor_db;                                          // _powerFloor now holds the floor in dB
+                shown = floor_db;
+            }
+            p.voiced[(long long)a * p.n_frames + t] = 0;                 // power == _powerFloor, never greater :87
+            if (p.power_out) p.power_out[(long long)a * p.n_frames + t] = (float)shown;
+        }
+        st[0] = acc; st[1] = consumed; st[2] = floor_db; st[3] = est ? 1.0 : 0.0;
+        s_first_free = t; s_floor = floor_db;
+    }
+    __syncthreads();
+    const double floor_db = s_floor;
+    for (int t = s_first_free + tid; t < p.n_frames; t += 256) {
+        const float pw = 10.f * log10f(pl[t]);                           // FFTLogPower :83
+        p.voiced[(long long)a * p.n_frames + t] = (double)pw > floor_db ? 1 : 0;
+        if (p.power_out) p.power_out[(long long)a * p.n_frames + t] = pw;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// k_scan_partial / k_scan_carry / k_scan_pick -- computeEnergyInDOA + selectDOA over all frames
+// --------------------------------------------------------------------------------------
+// E_t = 0.8f E_{t-1} + (1 - 0.8f) C_t on frames that pass the gate, unchanged otherwise
+// (SteeringBeamforming.cpp:132-144 is only reached for voiced frames, BeamformingSeparation...cpp:87-89).
+// The recursion over frames is evaluated as an exact chunked scan: (1) k_scan_partial runs it from
+// zero inside every chunk (result b, count n of voiced frames), (2) k_scan_carry composes the
+// chunks in order, E_start[c+1] = 0.8f^n E_start[c] + b, (3) k_scan_pick re-runs every chunk from its
+// true start value and peak-picks.  All chunks of (1) and (3) run in parallel.
 __device__ __forceinline__ float median3f(float a, float b, float c)
 {
     float lo = fminf(a, b), hi = fmaxf(a, b);
     return fmaxf(lo, fminf(hi, c));
+}
+
+__global__ __launch_bounds__(512) void k_scan_partial(ScanPickArgs p)
+{
+    const int d = threadIdx.x, a = blockIdx.y, c = blockIdx.x;
+    const int t_start = c * p.chunk, t_end = min(t_start + p.chunk, p.n_frames);
+    const float *C = p.C + (long long)a * p.n_frames * p.Dp;
+    const float *C2 = p.C2 ? p.C2 + (long long)a * p.n_frames * p.Dp : nullptr;
+    const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
+    float b = 0.f;
+    int nv = 0;
+    if (d < p.D) {
+        for (int t0 = t_start; t0 < t_end; t0 += 8) {
+            float c8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = min(t0 + i, t_end - 1);
+                const long long o = (long long)t * p.Dp + d;
+                c8[i] = C2 ? C[o] + C2[o] : C[o];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (t0 + i < t_end && (!vc || vc[t0 + i])) { b = p.mu * b + p.one_minus_mu * c8[i]; ++nv; }
+        }
+        p.part[((long long)a * p.n_chunks + c) * p.D + d] = b;
+    }
+    if (d == 0) p.nvoiced[(long long)a * p.n_chunks + c] = nv;
+}
+
+__global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
+{
+    __shared__ float spow[SCAN_CHUNK + 1];                          // 0.8f^n
+    const int d = threadIdx.x, a = blockIdx.x;
+    for (int n = d; n <= SCAN_CHUNK; n += blockDim.x) {
+        float g = 1.f;
+        for (int i = 0; i < n; ++i) g *= p.mu;
+        spow[n] = g;
+    }
+    __syncthreads();
+    if (d >= p.D) return;
+    float E = p.state_in[(long long)a * p.D + d];
+    const int *nvp = p.nvoiced + (long long)a * p.n_chunks;
+    const float *pp = p.part + (long long)a * p.n_chunks * p.D + d;
+    float *ep = p.e_start + (long long)a * p.n_chunks * p.D + d;
+    for (int c0 = 0; c0 < p.n_chunks; c0 += 8) {                     // 8 independent loads in flight, then the serial composition
+        int nv8[8]; float b8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = min(c0 + i, p.n_chunks - 1);
+            nv8[i] = nvp[c]; b8[i] = pp[(long long)c * p.D];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (c0 + i < p.n_chunks) { ep[(long long)(c0 + i) * p.D] = E; E = spow[nv8[i]] * E + b8[i]; }
+    }
+    p.state_out[(long long)a * p.D + d] = E;                         // _prevEnergyInDOA (:143)
 }
 
 __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
@@ -186,49 +298,41 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
     const int t_start = blockIdx.x * p.chunk;
     const int t_end = min(t_start + p.chunk, p.n_frames);
-    const int warm_start = max(0, t_start - SCAN_WARM);
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     const float *C2 = p.C2 ? p.C2 + (long long)a * p.n_frames * p.Dp : nullptr;
+    const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
     const float mn = -15.f * (float)p.P;
-    auto ldc = [&](int t) { const long long o = (long long)t * p.Dp + d; return C2 ? C[o] + C2[o] : C[o]; };
-    float E = 0.f;
-    if (act) {
-        E = warm_start == 0 ? p.state_in[(long long)a * D + d] : 0.f;
-        int t = warm_start;
-        for (; t + 8 <= t_start; t += 8) {              // 8 independent loads in flight per thread
-            float c8[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) c8[i] = ldc(t + i);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) E = mu * E + omu * c8[i];
-        }
-        for (; t < t_start; ++t) E = mu * E + omu * ldc(t);
-    }
+    float E = act ? p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d] : 0.f;
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
         if (act) {
-            int t = ts;
-            for (; t + 8 <= te; t += 8) {
+            for (int t0 = ts; t0 < te; t0 += 8) {
                 float c8[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) c8[i] = ldc(t + i);
+                for (int i = 0; i < 8; ++i) {
+                    const int t = min(t0 + i, te - 1);
+                    const long long o = (long long)t * p.Dp + d;
+                    c8[i] = C2 ? C[o] + C2[o] : C[o];
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    E = mu * E + omu * c8[i];                                   // :134-140
-                    if (p.energy) p.energy[((long long)a * p.n_frames + t + i) * D + d] = E;
-                    sEn[(t + i - ts) * Dl + d] = (E - mn) / (-2.f * mn);        // :155-156
+                    const int t = t0 + i;
+                    if (t < te) {
+                        if (!vc || vc[t]) E = mu * E + omu * c8[i];                 // :134-140
+                        if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
+                        sEn[(t - ts) * Dl + d] = (E - mn) / (-2.f * mn);            // :155-156
+                    }
                 }
-            }
-            for (; t < te; ++t) {
-                E = mu * E + omu * ldc(t);
-                if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
-                sEn[(t - ts) * Dl + d] = (E - mn) / (-2.f * mn);
             }
         }
         __syncthreads();
         for (int tl = wave; tl < te - ts; tl += nwaves) {
+            if (vc && !vc[ts + tl]) {                                   // gated out: selectDOA is not reached (:87)
+                if (lane < p.S) p.doa_bin[((long long)a * p.n_frames + ts + tl) * p.S + lane] = -1;
+                continue;
+            }
             const float *En = sEn + tl * Dl;
             float sdv[8];
 #pragma unroll
@@ -274,7 +378,58 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         }
         __syncthreads();
     }
-    if (act && t_end == p.n_frames) p.state_out[(long long)a * D + d] = E;     // _prevEnergyInDOA (:143)
+}
+
+// --------------------------------------------------------------------------------------
+// k_doa_fill -- gated-out frames keep the module's previous _currentDOA / _prob
+// (BeamformingSeparationAndLocalisation.cpp:87: processFrame is simply not called)
+// --------------------------------------------------------------------------------------
+// grid (arrays), 1024 threads.  last[t] = index of the last voiced frame <= t (inclusive prefix max
+// over the frames, Hillis-Steele in LDS over per-thread segments); unvoiced frames copy from it, or
+// from the state carried over from the previous call when no frame has fired yet in this one.
+__global__ __launch_bounds__(1024) void k_doa_fill(DoaFillArgs p)
+{
+    __shared__ int sLast[1024];
+    const int a = blockIdx.x, tid = threadIdx.x, F = p.n_frames, S = p.S;
+    const unsigned char *vc = p.voiced + (long long)a * F;
+    const int per = (F + 1023) / 1024;
+    const int t0 = tid * per, t1 = min(t0 + per, F);
+    int last = -1;
+    for (int t = t0; t < t1; ++t) if (vc[t]) last = t;
+    sLast[tid] = last;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int other = tid >= off ? sLast[tid - off] : -1;
+        __syncthreads();
+        sLast[tid] = max(sLast[tid], other);
+        __syncthreads();
+    }
+    int run = tid > 0 ? sLast[tid - 1] : -1;            // last voiced frame before this thread's segment
+    const long long base = (long long)a * F * S;
+    for (int t = t0; t < t1; ++t) {
+        if (vc[t]) { run = t; continue; }
+        for (int s = 0; s < S; ++s) {
+            const long long o = base + (long long)t * S + s;
+            if (run >= 0) {
+                p.doa_bin[o] = p.doa_bin[base + (long long)run * S + s];
+                if (p.doa_rad) p.doa_rad[o] = p.doa_rad[base + (long long)run * S + s];
+                if (p.prob) p.prob[o] = p.prob[base + (long long)run * S + s];
+            } else {
+                p.doa_bin[o] = p.last_bin[a * S + s];
+                if (p.doa_rad) p.doa_rad[o] = p.last_rad[a * S + s];
+                if (p.prob) p.prob[o] = p.last_prob[a * S + s];
+            }
+        }
+    }
+    __syncthreads();
+    // state for the next call = values of the last frame (written by the thread that owns it, after its own fill)
+    if (F - 1 >= t0 && F - 1 < t1)
+        for (int s = 0; s < S; ++s) {
+            const long long o = base + (long long)(F - 1) * S + s;
+            p.last_bin[a * S + s] = p.doa_bin[o];
+            if (p.doa_rad) p.last_rad[a * S + s] = p.doa_rad[o];
+            if (p.prob) p.last_prob[a * S + s] = p.prob[o];
+        }
 }
 
 // --------------------------------------------------------------------------------------

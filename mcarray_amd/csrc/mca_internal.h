@@ -12,6 +12,7 @@ constexpr int MK_WARM = 8;         // frames of Q warm-up for mask chunks that d
 constexpr int BF_NB = 4;           // frames per inverse-FFT batch of k_beamform_ola
 constexpr int GCC2_DOAWARM = 64;   // frames of DOA-recursion warm-up in k_gcc2_scan (0.6^64 = 6e-15)
 constexpr int SCAN_WARM = 96;     // frames of IIR warm-up per scan chunk (0.8^96 = 5e-10 << fp32 epsilon)
+constexpr int SCAN_CHUNK = 128;   // frames per chunk of the exact chunked scan
 constexpr int SCAN_SUB = 32;      // frames per LDS sub-batch of k_scan_pick
 
 struct StftPhatArgs {
@@ -23,6 +24,8 @@ struct StftPhatArgs {
     int Kp;                  // padded contraction depth (elements per plane)
     int a_row_elems;         // elements per A row = Kp * planes
     int a_planes;            // 1 (fp32 / fp16) or 2 (fp16 hi plane + lo plane)
+    float *power;            // [arrays][total_frames] linear FFTPower per frame, or NULL (ungated)
+    int total_frames;
 };
 
 __device__ __forceinline__ void store_a(float *row, const StftPhatArgs &, int cidx, float2 v)
@@ -57,12 +60,33 @@ struct GemmArgs {
 struct ScanPickArgs {
     const float *C;          // [arrays][n_frames][Dp]
     const float *C2;         // second partial map of a split-K contraction (NULL if none)
-    int n_frames, Dp, D, P, S, chunk;
+    int n_frames, Dp, D, P, S, chunk, n_chunks;
     float mu, one_minus_mu;
     const float *state_in;   // [arrays][D]  E_prev at entry
     float *state_out;        // [arrays][D]  E_prev at exit
+    float *part;             // [arrays][n_chunks][D]  chunk-local recursion result (E from 0)
+    int *nvoiced;            // [arrays][n_chunks]     voiced frames per chunk
+    float *e_start;          // [arrays][n_chunks][D]  E at the start of every chunk
+    const unsigned char *voiced;   // [arrays][n_frames] 1 = frame passed the power gate; NULL = ungated (all frames)
     const float *grid;       // [D] doaIdx2angle
     int *doa_bin; float *doa_rad; float *prob; float *energy;
+};
+
+struct GateArgs {
+    const float *power_lin;  // [arrays][n_frames] FFTPower of every frame
+    int n_frames, fft_n, needed_samples;
+    float margin_db;
+    // persistent gate state per array: {accumulated power (double), samples consumed (double), floor dB (double), estimated (double 0/1)}
+    double *state;           // [arrays][4]
+    unsigned char *voiced;   // [arrays][n_frames]
+    float *power_out;        // [arrays][n_frames] value handed to setDOA / compared with the floor (may be NULL)
+};
+
+struct DoaFillArgs {
+    const unsigned char *voiced;   // [arrays][n_frames]
+    int n_frames, S;
+    int *doa_bin; float *doa_rad; float *prob;      // [arrays][n_frames][S], filled forward over gated-out frames
+    int *last_bin; float *last_rad; float *last_prob;   // [arrays][S] _currentDOA / _prob carried between calls
 };
 
 struct BeamformArgs {

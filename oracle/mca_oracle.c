@@ -548,6 +548,48 @@ void mca_or_ssl_stream(int fs, int N, const double *xyz, int M, int S, double st
     mca_or_bsl_destroy(b);
 }
 
+void mca_or_ssl_stream_gated(int fs, int N, const double *xyz, int M, int S, double step_deg, int use_floor,
+                             const double *pcm, long stride, int F, int *doa_bin, double *doa_rad, double *prob,
+                             double *out_pcm, double *energy_map, int *fired, double *power)
+{
+    const int hop = N / 2, ccs = N + 2;
+    mca_or_bsl *b = mca_or_bsl_create(fs, ccs, xyz, M, S, use_floor, step_deg);
+    const int D = b->st->D;
+    double *win = (double *)malloc(sizeof(double) * (size_t)N);
+    mca_or_hann_periodic(win, N);
+    double **fr = (double **)malloc(sizeof(double *) * (size_t)M);
+    for (int c = 0; c < M; ++c) fr[c] = (double *)malloc(sizeof(double) * (size_t)ccs);
+    int nout = M < S ? M : S;
+    double *tail = (double *)calloc((size_t)nout * hop, sizeof(double));
+    double *y = (double *)malloc(sizeof(double) * (size_t)N);
+    for (int s = 0; s < S; ++s) b->curBin[s] = -1;
+    for (int t = 0; t < F; ++t) {
+        for (int c = 0; c < M; ++c) mca_or_stft_frame(pcm + (size_t)c * stride + (size_t)t * hop, win, N, fr[c]);
+        double pw = 0;
+        int f = mca_or_bsl_localise(b, (const double *const *)fr, NULL, NULL, &pw);      /* :74-101 */
+        if (fired) fired[t] = f;
+        if (power) power[t] = pw;
+        if (energy_map) memcpy(energy_map + (size_t)t * D, b->st->Eprev, sizeof(double) * (size_t)D);
+        for (int s = 0; s < S; ++s) {
+            if (doa_bin) doa_bin[(size_t)t * S + s] = b->curBin[s];
+            if (doa_rad) doa_rad[(size_t)t * S + s] = b->curDOA[s];
+            if (prob) prob[(size_t)t * S + s] = b->prob[s];
+        }
+        if (out_pcm) {
+            mca_or_bsl_separate(b, fr);                                                  /* :103-119 */
+            for (int s = 0; s < nout; ++s) {
+                mca_or_irfft_ccs(fr[s], N, y);
+                double *o = out_pcm + (size_t)s * F * hop + (size_t)t * hop;
+                double *tl = tail + (size_t)s * hop;
+                for (int n = 0; n < hop; ++n) { o[n] = tl[n] + y[n]; tl[n] = y[n + hop]; }
+            }
+        }
+    }
+    for (int c = 0; c < M; ++c) free(fr[c]);
+    free(fr); free(win); free(tail); free(y);
+    mca_or_bsl_destroy(b);
+}
+
 /* ======================================================================= */
 /* FreqGCCBinauralLocalisation (deterministic part) -- SURVEY A.7           */
 /* ======================================================================= */

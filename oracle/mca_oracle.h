@@ -117,6 +117,16 @@ void mca_or_ssl_stream(int fs, int N, const double *xyz, int M, int n_sources,
                        int *doa_bin, double *doa_rad, double *prob, double *out_pcm,
                        double *energy_map);
 
+/* Same with the power gate of BeamformingSeparationAndLocalisation::processFrameLocalisation
+ * (BeamformingSeparationAndLocalisation.cpp:74-101) switched by use_power_floor (the reference's default is
+ * true, SourceSeparationAndLocalisation.h:47).  fired[F] = 1 where the callback would fire (:87-94);
+ * power[F] = the value handed to setDOA / compared with the floor; doa_* hold _currentDOA after each frame
+ * (unchanged on gated-out frames: initial 0 rad / prob -1, :51-52; doa_bin = -1 until a first frame fires). */
+void mca_or_ssl_stream_gated(int fs, int N, const double *xyz, int M, int n_sources, double doa_step_deg,
+                             int use_power_floor, const double *pcm, long stride, int F,
+                             int *doa_bin, double *doa_rad, double *prob, double *out_pcm,
+                             double *energy_map, int *fired, double *power);
+
 /* ---- FreqGCCBinauralLocalisation: src/mcarray/BinauralLocalisation.cpp:320-631
  * deterministic part only: smoothed corr, argmax, setProbability */
 typedef struct mca_or_freqgcc mca_or_freqgcc;

@@ -85,6 +85,8 @@ def lib():
         L.mca_or_bsl_separate.argtypes = [C.c_void_p, C.POINTER(c_dp)]
         L.mca_or_ssl_stream.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, c_dp, C.c_long,
                                         C.c_int, c_ip, c_dp, c_dp, c_dp, c_dp]
+        L.mca_or_ssl_stream_gated.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, C.c_long,
+                                              C.c_int, c_ip, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp]
         L.mca_or_freqgcc_create.restype = C.c_void_p
         L.mca_or_freqgcc_create.argtypes = [C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_double]
         L.mca_or_freqgcc_destroy.argtypes = [C.c_void_p]
@@ -302,6 +304,27 @@ def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0, want_map=False, want_
     lib().mca_or_ssl_stream(fs, N, _dp(a), M, S, step_deg, _dp(pcm), L, F, _ip(bins), _dp(doa), _dp(prob),
                             _dp(out) if want_audio else None, _dp(emap) if want_map else None)
     return dict(bin=bins, doa=doa, prob=prob, out=out, energy=emap)
+
+
+def ssl_stream_gated(fs, N, xyz, pcm, n_sources=1, step_deg=5.0, use_power_floor=True, want_audio=True):
+    """SourceSeparationAndLocalisation stream with the power gate (usePowerFloor, the reference's default)."""
+    a = _xyz(xyz)
+    pcm = np.ascontiguousarray(pcm, dtype=np.float64)
+    M, L = pcm.shape
+    hop = N // 2
+    F = L // hop - 1
+    D = num_steps(step_deg)
+    S = n_sources
+    bins = np.empty((F, S), dtype=np.int32)
+    doa = np.empty((F, S))
+    prob = np.empty((F, S))
+    out = np.zeros((min(M, S), F * hop)) if want_audio else None
+    emap = np.empty((F, D))
+    fired = np.empty(F, dtype=np.int32)
+    power = np.empty(F)
+    lib().mca_or_ssl_stream_gated(fs, N, _dp(a), M, S, step_deg, int(use_power_floor), _dp(pcm), L, F, _ip(bins), _dp(doa),
+                                  _dp(prob), _dp(out) if want_audio else None, _dp(emap), _ip(fired), _dp(power))
+    return dict(bin=bins, doa=doa, prob=prob, out=out, energy=emap, fired=fired, power=power)
 
 
 class FreqGCC:

@@ -403,3 +403,63 @@ def test_masking_long_stream_chunks_and_reference_windows():
     diff = lambda x: po.log_power(signal.lfilter(sigf, 1.0, x)[sl]) - po.log_power(signal.lfilter(intf, 1.0, x)[sl])
     assert abs(diff(sig[:F * hop]) - 2) < 0.5
     assert abs(diff(out[0, 0].astype(np.float64)) - 5) < 1.0
+
+
+# ---------------------------------------------------------------------------------------------
+# power gate (usePowerFloor = true, the reference's default) in the batched stream path
+# ---------------------------------------------------------------------------------------------
+def _gated_signal(xs, fs, F, seed):
+    rng = np.random.default_rng(seed)
+    L = (F + 1) * 512
+    pcm = rng.standard_normal((len(xs), L)) * 0.001                 # sensor-noise floor for the first 3 s and the gaps
+    src = synth.noise_source_stream(xs, np.deg2rad(30.0), fs, L, seed + 1).astype(np.float64)
+    env = np.zeros(L)
+    for a, b in ((150, 165), (172, 180), (190, F - 1)):
+        env[a * 512:b * 512] = 1.0
+    return (pcm + src * env).astype(np.float32)
+
+
+@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3])
+def test_power_gate_stream_matches_oracle(prec):
+    fs, N, F = 48000, 1024, 230
+    xs = synth.REEM_C
+    pcm = _gated_signal(xs, fs, F, 3)
+    o = po.ssl_stream_gated(fs, N, xs, pcm.astype(np.float64), 1, 5.0, True)
+    assert 0 < o["fired"].sum() < F and o["fired"][:141].sum() == 0          # 3 s of floor estimation never fire
+    ctx = api.Context(fs, xs, N, 5.0, 1, use_power_floor=True, srp_precision=prec)
+    r = ctx.process_frames_host(pcm[None], want_energy=True)
+    assert np.array_equal(r["voiced"][0], o["fired"])
+    np.testing.assert_allclose(r["power"][0][141:], o["power"][141:], rtol=0, atol=2e-3)        # dB
+    np.testing.assert_allclose(r["power"][0][:140], o["power"][:140], rtol=2e-5)                # running sum (linear)
+    assert np.array_equal(r["bin"][0], o["bin"])
+    np.testing.assert_allclose(r["doa"][0], o["doa"].astype(np.float32), rtol=0, atol=0)
+    np.testing.assert_allclose(r["prob"][0], o["prob"], rtol=0, atol=2e-5)
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+    assert np.abs(r["out"][0] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    # chunked streaming: the floor estimation, E_prev, the last DOA and the OLA tail all carry across calls
+    two = api.Context(fs, xs, N, 5.0, 1, use_power_floor=True, srp_precision=prec)
+    cut = 100
+    ra = two.process_frames_host(pcm[None, :, :(cut + 1) * 512], want_energy=True)
+    rb = two.process_frames_host(pcm[None, :, cut * 512:], want_energy=True)
+    for k in ("voiced", "bin", "doa"):
+        assert np.array_equal(np.concatenate([ra[k], rb[k]], axis=1), r[k]), k
+    np.testing.assert_allclose(np.concatenate([ra["out"], rb["out"]], axis=2), r["out"], rtol=0, atol=1e-6)
+    # a third call that starts inside a silent gap keeps reporting the previous DOA
+    rc = two.process_frames_host((pcm[None, :, :6 * 512] * 0).astype(np.float32))
+    assert np.all(rc["voiced"] == 0) and np.all(rc["bin"] == r["bin"][0, -1]) and np.all(rc["doa"] == r["doa"][0, -1])
+    two.reset()
+    rd = two.process_frames_host(pcm[None])
+    assert np.array_equal(rd["bin"], r["bin"])
+
+
+def test_exact_chunked_scan_long_stream():
+    # 700 frames cross several 128-frame scan chunks: the chunk composition E_start[c+1] = 0.8^n E_start[c] + b
+    # must reproduce the frame-by-frame recursion of the oracle
+    fs, N, F = 48000, 1024, 700
+    xs = synth.REEM_C
+    pcm = synth.noise_source_stream(xs, np.deg2rad(-20.0), fs, (F + 1) * 512, 77)
+    ctx = api.Context(fs, xs, N, 5.0, 2)
+    r = ctx.process_frames_host(pcm[None], want_energy=True, want_audio=False)
+    o = po.ssl_stream(fs, N, xs, pcm.astype(np.float64), 2, 5.0, want_map=True, want_audio=False)
+    _assert_bins(r["bin"][0], o["bin"], o["energy"], 6, max_ties=3)
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
