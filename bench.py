@@ -153,10 +153,18 @@ def main():
         roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None}
     else:
-        per_frame = {"k_stft_phat": M * HOP * 4, "k_beamform_ola": M * HOP * 4 + HOP * 4, "k_scan_pick": D * 4 + 8}[dom]
+        per_frame = {"k_stft_phat": M * HOP * 4, "k_beamform_ola": M * HOP * 4 + HOP * 4, "k_scan_pick": D * 4 + 8}.get(dom, D * 4 + 8)
         ach = per_frame * frames_per_launch / (kt[dom]["avg_ms"] * 1e-3) / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": None}
+
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh), if present
+    tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.precision)
+    if os.path.exists(tj) and A == 8 and F == 4096:
+        kk = json.load(open(tj))["kernels"].get(dom)
+        if kk:   # gfx950 correction: FETCH_SIZE reports half of a wide coalesced read stream
+            roof["traffic"] = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0
+            roof["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)"
 
     if rank == 0:
         cpu = None

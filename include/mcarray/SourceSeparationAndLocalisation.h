@@ -30,8 +30,8 @@ public:
     {
         const int N = 1 << _order;
         _impl.reset(new BeamformingSeparationAndLocalisation(sampleRate, N + 2, microphonePositions, numOfSources, usePowerFloor, doaStepDeg));
-        if (N == 1024 && !usePowerFloor)
-            _stream.reset(new detail::HipContext(sampleRate, microphonePositions, N, doaStepDeg, _numOfSources, false, srpPrecision));
+        if (N == 1024)
+            _stream.reset(new detail::HipContext(sampleRate, microphonePositions, N, doaStepDeg, _numOfSources, usePowerFloor, srpPrecision));
         _pending.assign(static_cast<size_t>(_nchannels), std::vector<float>());
         for (int c = 0; c < _nchannels; ++c) _wienerCoefs.push_back(SignalPtr(new BaseType[N + 2]));
     }
@@ -70,7 +70,7 @@ public:
     template <typename Tin, typename Tout>
     int process(const std::vector<Tin *> &in, int nSamples, const std::vector<Tout *> &out, int outSize)
     {
-        if (!_stream) throw MCArrayException("process() needs the 1024-point stream path and usePowerFloor=false; use the frame hook otherwise");
+        if (!_stream) throw MCArrayException("process() needs the 1024-point stream path; use the frame hook for other frame sizes");
         const int N = getWindowSize(), hop = N / 2;
         for (int c = 0; c < _nchannels; ++c) {
             std::vector<float> &buf = _pending[static_cast<size_t>(c)];
@@ -89,14 +89,18 @@ public:
         std::vector<int> bins(FS);
         std::vector<float> doa(FS), prob(FS), audio(FS * static_cast<size_t>(hop));
         _stream->check(mca_hip_process_frames_host(_stream->get(), pcm.data(), 1, F, bins.data(), doa.data(), prob.data(), nullptr, audio.data()));
+        std::vector<unsigned char> voiced(static_cast<size_t>(F), 1);
+        std::vector<float> power(static_cast<size_t>(F), 0.f);
+        if (_usePowerFloor) _stream->check(mca_hip_copy_gate(_stream->get(), voiced.data(), power.data()));
         if (_callback) {
             for (int t = 0; t < F; ++t) {
+                if (!voiced[static_cast<size_t>(t)]) continue;     // gated out: no setDOA (BeamformingSeparationAndLocalisation.cpp:87-94)
                 SignalPtr d(new BaseType[_numOfSources]), p(new BaseType[_numOfSources]);
                 for (int s = 0; s < _numOfSources; ++s) {
                     d[s] = (180 / M_PI) * static_cast<double>(doa[static_cast<size_t>(t * _numOfSources + s)]);   // toDegrees
                     p[s] = static_cast<double>(prob[static_cast<size_t>(t * _numOfSources + s)]);
                 }
-                _callback->setDOA(d, p, 0.0, _numOfSources);
+                _callback->setDOA(d, p, static_cast<double>(power[static_cast<size_t>(t)]), _numOfSources);
             }
         }
         for (size_t c = 0; c < out.size(); ++c)

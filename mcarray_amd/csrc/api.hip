@@ -484,13 +484,14 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             const int np = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
             const size_t smem = (size_t)3 * np * (256 + 384) * 32;
             dim3 gv((ga.rows + 255) / 256, 2);
-            if (c->prec == MCA_HIP_SRP_FP16X3) {
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_srp_gemm_f16_v2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                hipLaunchKernelGGL(k_srp_gemm_f16_v2<true>, gv, dim3(512), smem, st, ga);
-            } else {
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_srp_gemm_f16_v2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                hipLaunchKernelGGL(k_srp_gemm_f16_v2<false>, gv, dim3(512), smem, st, ga);
-            }
+#define V2_LAUNCH(K)                                                                                                      \
+            do {                                                                                                          \
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+                hipLaunchKernelGGL(K, gv, dim3(512), smem, st, ga);                                                       \
+            } while (0)
+            if (c->prec == MCA_HIP_SRP_FP16X3) V2_LAUNCH((k_srp_gemm_f16_v2<true, 8, 3>));
+            else V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3>));
+#undef V2_LAUNCH
         } else {
             dim3 g2((ga.rows + 127) / 128, c->Dp / 192);
             if (c->prec == MCA_HIP_SRP_FP32) hipLaunchKernelGGL(k_srp_gemm_f32, g2, dim3(256), 0, st, ga);

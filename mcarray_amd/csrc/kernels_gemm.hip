@@ -200,8 +200,12 @@ template __global__ void k_srp_gemm_f16<false>(GemmArgs);
 template __global__ void k_srp_gemm_f16<true>(GemmArgs);
 
 // ---------------------------------------------------------------------------------------
-// v2 of the fp16 contraction for Dp == 384 (the 361-angle grid): the v1 tile streams 35 B of
-// operands per CU-cycle from L2 for its MFMAs, which is what bounds it.  v2 holds a 256 x 384
+// v2 of the fp16 contraction for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction
+// is bound by how fast a CU can ingest operands from L2 (~10-13 B/clk/CU, ~18 GB/s/CU observed for any
+// ring depth, loader count or priority), not by the MFMA pipe: time = operand bytes per CU / ingest rate.
+// So the design goal is the fewest operand bytes per CU, i.e. the largest output tile the register
+// file can hold.  v1 (128 x 192 tiles, two workgroups per CU) moves 35 B per CU-cycle of MFMA work;
+// v2 holds a 256 x 384
 // output tile per workgroup (8 waves as 4 x 2, wave tile 64 x 192 = 2 x 6 MFMA tiles, 192
 // accumulator registers) -> 17 B/cycle, splits K over blockIdx.y (two partial maps, summed by the
 // scan kernel) so that 32 768 rows still give one workgroup per CU, and moves operands with
@@ -215,7 +219,7 @@ constexpr int V2_BM = 256, V2_BN = 384, V2_BK = 16, V2_ROWB = 32;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <bool SPLIT>
+template <bool SPLIT, int NLOAD, int NSTAGE>
 __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
 {
     constexpr int NP = SPLIT ? 2 : 1;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     // four waves go straight to their MFMAs, so on every SIMD (waves w and w+4 share one) the loader's
     // DMA issue overlaps its partner's matrix work instead of both stalling in lock-step.
     // The A workspace is allocated in multiples of 256 rows, so no row clamp is needed.
-    const bool loader = wave < 4;
+    const bool loader = wave < NLOAD;
     const int lr = (wave & 3) * 32 + (lane >> 1);
     const int lc = (lane & 1) ^ ((lane >> 4) & 1);             // logical chunk stored at this lane's physical position
     const unsigned char *a_lane = A + ((long long)(row0 + lr) * p.a_row_elems + lc * 8) * 2;
@@ -256,19 +260,32 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // NLOAD == 4: loader w moves A blocks {w, w+4} and B blocks {w, w+4, w+8} of every plane (5 * NP instructions);
+    // NLOAD == 8: every wave moves A block w and B block w of every plane, waves 0..3 also B block w+8.
     auto issue = [&](int s, int buf) {
         const long long koff = (long long)(s_beg + s) * V2_BK * 2;
         unsigned char *sb = smem_g + buf * STAGE + dst_lane_blk;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
+            if constexpr (NLOAD == 4) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + i * a_blk + koff),
-                                                 (lds_void_t *)(sb + pl * A_BYTES + i * 4096), 16, 0, 0);
+                for (int i = 0; i < 2; ++i)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + i * a_blk + koff),
+                                                     (lds_void_t *)(sb + pl * A_BYTES + i * 4096), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + i * b_blk + koff),
-                                                 (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + i * 4096), 16, 0, 0);
+                for (int i = 0; i < 3; ++i)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + i * b_blk + koff),
+                                                     (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + i * 4096), 16, 0, 0);
+            } else {
+                const int hi = wave >> 2;                       // 0: blocks w, 1: blocks w (= (w&3)+4)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + hi * a_blk + koff),
+                                                 (lds_void_t *)(sb + pl * A_BYTES + hi * 4096), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + hi * b_blk + koff),
+                                                 (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + hi * 4096), 16, 0, 0);
+                if (wave < 4)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + 2 * b_blk + koff),
+                                                     (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + 2 * 4096), 16, 0, 0);
+            }
         }
     };
 
@@ -286,18 +303,25 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     }
 
     if (loader) {
-        if (ns > 0) issue(0, 0);
-        if (ns > 1) issue(1, 1);
+#pragma unroll
+        for (int q = 0; q < NSTAGE - 1; ++q)
+            if (q < ns) issue(q, q);
     }
     for (int s = 0; s < ns; ++s) {
-        // slice s has landed once at most the loads of slice s+1 (5 * NP per loader wave) are outstanding
-        if (s + 1 < ns) {
-            if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // slice s has landed once at most the loads of the NSTAGE-2 younger slices in flight are outstanding
+        // (per wave and slice: NLOAD == 4: 5 * NP; NLOAD == 8: at least 2 * NP -- waiting for the smaller count is safe)
+        {
+            constexpr int PERW = (NLOAD == 4 ? 5 : 2) * NP;
+            const int younger = min(NSTAGE - 2, ns - 1 - s);
+            if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERW) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERW) : "memory");
+            else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PERW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PERW) : "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (loader && s + 2 < ns) issue(s + 2, (s + 2) % 3);  // that buffer was last read in slice s-1
-        const unsigned char *st = smem_g + (s % 3) * STAGE;
+        if (loader && s + NSTAGE - 1 < ns) issue(s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);   // that buffer was last read in slice s-1
+        const unsigned char *st = smem_g + (s % NSTAGE) * STAGE;
         f16x8 af[NP][2];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
         }
 }
 
-template __global__ void k_srp_gemm_f16_v2<false>(GemmArgs);
-template __global__ void k_srp_gemm_f16_v2<true>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<true, 8, 3>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<false, 8, 3>(GemmArgs);
 
 }  // namespace mca
