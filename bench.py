@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arrays", type=int, default=8, help="independent 8-mic arrays per GPU")
     ap.add_argument("--frames", type=int, default=4096, help="STFT frames per array per step")
-    ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "fp32"))
+    ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "fp16x3"))
     ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of array 0 timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
