@@ -29,6 +29,7 @@ struct mca_hip_ctx {
     std::vector<double> xyz;
     int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, Kp = 0, S = 1, prec = 0;
     bool ula = false, stream_ok = false, force_v1 = false;
+    int v2_min_rows = 32768;
     float step = 0.f;
     std::vector<float> delays, grid;
     std::vector<int2> pairs;
@@ -332,7 +333,8 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     c->P = c->M * (c->M - 1) / 2;
     c->Dp = round_up(c->D, 192);
     c->stream_ok = (c->N == FFT_N);
-    c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switch for measurements
+    c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switches for measurements
+    if (std::getenv("MCA_HIP_V2_MIN_ROWS")) c->v2_min_rows = std::atoi(std::getenv("MCA_HIP_V2_MIN_ROWS"));
 
     // generateLookupTable (SteeringBeamforming.cpp:58-94): pairs i<j lexicographic, float delays
     c->delays.resize((size_t)c->P * c->D);
@@ -477,13 +479,15 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
         ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
         ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
-        const bool v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && ga.rows >= 1024 && !c->force_v1;
-        c->c_split = v2; c->c_plane = ga.c_plane_elems;
+        // 256 x 384 tiles need >= ~256 workgroups to fill the chip: split K in two below 65 536 rows
+        const bool v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && ga.rows >= c->v2_min_rows && !c->force_v1;
+        const int ksplit = ga.rows >= 65536 ? 1 : 2;
+        c->c_split = v2 && ksplit == 2; c->c_plane = ga.c_plane_elems;
         time_begin(c, MCA_HIP_K_SRP_GEMM, st);
         if (v2) {
             const int np = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
             const size_t smem = (size_t)3 * np * (256 + 384) * 32;
-            dim3 gv((ga.rows + 255) / 256, 2);
+            dim3 gv((ga.rows + 255) / 256, ksplit);
 #define V2_LAUNCH(K)                                                                                                      \
             do {                                                                                                          \
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
