@@ -148,7 +148,7 @@ int build_steering_table(mca_hip_ctx *c)
             for (int k = 0; k < K; ++k)
                 for (int d = 0; d < D; ++d) {
                     double ph = 2.0 * M_PI * (double)k * (double)c->delays[(size_t)first_pair[g] * D + d] / N;
-                    size_t r = ((size_t)g * K + k) * 2;
+                    size_t r = ((size_t)g * KG + k) * 2;
                     B[r * Dp + d] = (float)std::cos(ph);
                     B[(r + 1) * Dp + d] = (float)(-std::sin(ph));
                 }
@@ -163,7 +163,7 @@ int build_steering_table(mca_hip_ctx *c)
                     double ph = 2.0 * M_PI * (double)k * (double)c->delays[(size_t)first_pair[g] * D + d] / N;
                     float v[2] = {(float)std::cos(ph), (float)(-std::sin(ph))};
                     for (int q = 0; q < 2; ++q) {
-                        size_t kk = ((size_t)g * K + k) * 2 + q;
+                        size_t kk = ((size_t)g * KG + k) * 2 + q;
                         _Float16 hi = (_Float16)v[q];
                         B[(size_t)d * Kp + kk] = hi;
                         if (planes == 2) B[((size_t)Dp + d) * Kp + kk] = (_Float16)(v[q] - (float)hi);
@@ -362,7 +362,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
                 if (std::memcmp(&fdist[p], &fdist[j - i - 1], sizeof(float)) != 0) { c->ula = false; break; }
     }
     c->G = c->ula ? c->M - 1 : c->P;
-    c->Kp = round_up(c->G * c->K * 2, 32);
+    c->Kp = round_up(c->G * KG * 2, 32);
     c->a_planes = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
     c->a_elem = c->prec == MCA_HIP_SRP_FP32 ? 4 : 2;
     c->a_row_elems = c->Kp * c->a_planes;

@@ -203,7 +203,11 @@ template __global__ void k_srp_gemm_f16<true>(GemmArgs);
 // v2 of the fp16 contraction for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction
 // is bound by how fast a CU can ingest operands from L2 (~10-13 B/clk/CU, ~18 GB/s/CU observed for any
 // ring depth, loader count or priority), not by the MFMA pipe: time = operand bytes per CU / ingest rate.
-// So the design goal is the fewest operand bytes per CU, i.e. the largest output tile the register
+// (A variant that computes the steering operand into LDS with sincospif + rotations instead of loading
+// it -- 2.5x fewer bytes per slice -- passed every parity test and ran at the SAME speed, so it is not the
+// byte count either: with 192 accumulator registers per lane there is no room to software-pipeline the
+// LDS fragment reads across the per-slice barrier, and that serialisation is what remains.)
+// The design goal is the fewest operand bytes per CU, i.e. the largest output tile the register
 // file can hold.  v1 (128 x 192 tiles, two workgroups per CU) moves 35 B per CU-cycle of MFMA work;
 // v2 holds a 256 x 384
 // output tile per workgroup (8 waves as 4 x 2, wave tile 64 x 192 = 2 x 6 MFMA tiles, 192

@@ -7,7 +7,7 @@
 //
 // Data layout in HBM: PCM fp32 channel-major [array][mic][sample] (coalesced float2 loads along
 // time); A operand [frame][Kp] with Kp = roundup(G*1026, 32), flat index (g*513 + k)*2 + {re,im};
-// correlation map C [array][frame][Dp] fp32.
+// correlation map C [array][frame][Dp] fp32.  (Kp = roundup(G*KG*2, 32) with KG = 520 slots per group.)
 #include "fft512.h"
 #include "mca_internal.h"
 
@@ -52,25 +52,25 @@ __device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, 
 #pragma unroll
                 for (int j = i + 1; j < MT; ++j) acc[j - i - 1] = cadd(acc[j - i - 1], cmulc(r[i], r[j]));
 #pragma unroll
-            for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * FFT_K + k, acc[g]);
+            for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * KG + k, acc[g]);
         } else {
             int pi = 0;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = i + 1; j < MT; ++j) { store_a(arow, p, pi * FFT_K + k, cmulc(r[i], r[j])); ++pi; }
+                for (int j = i + 1; j < MT; ++j) { store_a(arow, p, pi * KG + k, cmulc(r[i], r[j])); ++pi; }
         }
     } else {
         if (ULA) {
             for (int g = 0; g < M - 1; ++g) {
                 float2 acc = make_float2(0.f, 0.f);
                 for (int i = 0; i + g + 1 < M; ++i) acc = cadd(acc, cmulc(x[i * xstride], x[(i + g + 1) * xstride]));
-                store_a(arow, p, g * FFT_K + k, acc);
+                store_a(arow, p, g * KG + k, acc);
             }
         } else {
             int pi = 0;
             for (int i = 0; i < M; ++i)
-                for (int j = i + 1; j < M; ++j) { store_a(arow, p, pi * FFT_K + k, cmulc(x[i * xstride], x[j * xstride])); ++pi; }
+                for (int j = i + 1; j < M; ++j) { store_a(arow, p, pi * KG + k, cmulc(x[i * xstride], x[j * xstride])); ++pi; }
         }
     }
 }
