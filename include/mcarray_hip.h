@@ -46,7 +46,7 @@ typedef enum {
 typedef enum {
     MCA_HIP_SRP_FP32 = 0,    /* v_mfma_f32_32x32x2_f32, exact fp32 (parity anchor) */
     MCA_HIP_SRP_FP16X3 = 1,  /* fp16 hi/lo split operands, 3 MFMAs per k-step, ~fp32 accuracy */
-    MCA_HIP_SRP_FP16 = 2     /* single fp16 MFMA per k-step (fast; energy map rel. error ~3e-5) */
+    MCA_HIP_SRP_FP16 = 2     /* single fp16 MFMA per k-step (fast; energy map error ~1.5e-5 of the peak) */
 } mca_hip_srp_precision;
 
 typedef struct mca_hip_ctx mca_hip_ctx;

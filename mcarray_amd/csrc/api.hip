@@ -238,12 +238,17 @@ int ensure_scan_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chun
     return MCA_HIP_OK;
 }
 
-constexpr long long WS_MAX_BYTES = 4LL << 30;   // A-operand workspace budget per chunk
+long long ws_max_bytes()
+{
+    // A-operand workspace budget per chunk of frames; MCA_HIP_WS_MAX_MB lets the tests force the chunked path
+    static const long long v = std::getenv("MCA_HIP_WS_MAX_MB") ? (long long)std::atoll(std::getenv("MCA_HIP_WS_MAX_MB")) << 20 : 4LL << 30;
+    return v;
+}
 
 long long chunk_frames_for(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     long long row_bytes = (long long)c->a_row_elems * c->a_elem;
-    long long rows_cap = WS_MAX_BYTES / row_bytes;
+    long long rows_cap = ws_max_bytes() / row_bytes;
     long long fc = rows_cap / n_arrays;
     if (fc >= n_frames) return n_frames;
     fc = fc / 8 * 8;

@@ -4,7 +4,7 @@ the CPU oracle and the committed golden vectors.  Run on the MI355X box with `-m
 Tolerances (fp32 GPU vs fp64 oracle), written where they are used:
   * DOA bin: bit-exact, except frames the oracle itself flags as numerical ties (two candidate
     peaks whose normalised energies differ by < 1e-6) where +-1 bin is accepted and counted.
-  * energy map E_t[d]: |gpu - oracle| <= TOL_E * max|E| with TOL_E = 2e-5 (fp32), 2e-5 (fp16x3), 2e-3 (fp16)
+  * energy map E_t[d]: |gpu - oracle| <= TOL_E * max|E| with TOL_E = 2e-5 (fp32), 2e-5 (fp16x3), 2e-4 (fp16)
   * beamformed audio: |gpu - oracle| <= 2e-5 * max|out| + 1e-7
 """
 import numpy as np
@@ -15,7 +15,7 @@ from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
 
-TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-3}
+TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4}
 PRECS = [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16]
 
 
@@ -463,3 +463,30 @@ def test_exact_chunked_scan_long_stream():
     o = po.ssl_stream(fs, N, xs, pcm.astype(np.float64), 2, 5.0, want_map=True, want_audio=False)
     _assert_bins(r["bin"][0], o["bin"], o["energy"], 6, max_ties=3)
     assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+
+
+def test_workspace_chunking_gives_identical_results():
+    """The A-operand workspace is bounded (4 GiB by default): long batches are processed in chunks of frames.
+    Forcing a tiny budget must not change a single output bit (run in a subprocess: the budget is read once)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, sys, hashlib
+        from mcarray_amd import api, synth
+        fs, N, F, A = 48000, 1024, 300, 3
+        pcm = np.stack([synth.noise_source_stream(synth.ULA8, np.deg2rad(-50 + 45 * a), fs, (F + 1) * 512, 900 + a) for a in range(A)])
+        ctx = api.Context(fs, synth.ULA8, N, 0.5, 1, srp_precision=api.SRP_FP16X3, max_arrays=A)
+        r = ctx.process_frames_host(pcm, want_energy=True)
+        h = hashlib.sha256()
+        for k in ("bin", "doa", "prob", "energy", "out"):
+            h.update(np.ascontiguousarray(r[k]).tobytes())
+        print(h.hexdigest())
+    ''')
+    import os
+    env = dict(os.environ)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    a = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    env["MCA_HIP_WS_MAX_MB"] = "8"          # 8 MiB / 57.6 KB per row -> ~145 rows -> 48-frame chunks for 3 arrays
+    b = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert a.stdout.strip().splitlines()[-1] == b.stdout.strip().splitlines()[-1]
