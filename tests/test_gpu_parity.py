@@ -490,3 +490,26 @@ def test_workspace_chunking_gives_identical_results():
     b = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
     assert a.stdout.strip().splitlines()[-1] == b.stdout.strip().splitlines()[-1]
+
+
+def test_mcbeam_cli_wav_roundtrip(tmp_path):
+    """tools/mcbeam.py (the counterpart of src/programs/mcabeamf.cpp): 4-channel 16-bit WAV in, mono WAV + DOA text out."""
+    import subprocess, sys, wave, os
+    fs, F = 48000, 40
+    xs = synth.REEM_C
+    x = synth.noise_source_stream(xs, np.deg2rad(25.0), fs, (F + 1) * 512, 12)
+    pcm16 = np.clip(np.round(x * 32768), -32768, 32767).astype("<i2")
+    wav_in, wav_out, doa_txt = str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), str(tmp_path / "doa.txt")
+    with wave.open(wav_in, "wb") as w:
+        w.setnchannels(4); w.setsampwidth(2); w.setframerate(fs); w.writeframes(pcm16.T.tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mcbeam.py"), "-i", wav_in, "-o", wav_out, "-d", doa_txt,
+                        "--mics", "0,0.07,0.175,0.21"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    doa = np.loadtxt(doa_txt)
+    assert doa.shape == (F, 2) and np.all(np.abs(doa[5:, 0] - 25.0) <= 5.0)
+    with wave.open(wav_out, "rb") as w:
+        assert w.getnchannels() == 1 and w.getframerate() == fs and w.getnframes() == F * 512
+        y = np.frombuffer(w.readframes(F * 512), dtype="<i2").astype(np.float64) / 32768
+    o = po.ssl_stream(fs, 1024, xs, pcm16.astype(np.float64) / 32768, 1, 5.0)
+    assert np.abs(y - o["out"][0]).max() <= 1.5 / 32768 + 2e-5
