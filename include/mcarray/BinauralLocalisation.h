@@ -22,7 +22,6 @@ public:
     {
         if (microphonePositions.size() != 2) throw MCArrayException("FreqGCCBinauralLocalisation needs an ArrayDescription with 2 microphones");
         if (usePowerFloor) throw MCArrayException("the stream path runs ungated: construct with usePowerFloor=false");
-        if ((1 << _order) != 1024) throw MCArrayException("the stream path needs a 1024-point frame (e.g. 16 kHz at 0.075 s)");
         _ctx.reset(new detail::HipContext(sampleRate, microphonePositions, 1 << _order, doaStepDeg, 1, false));
         _currentDOA.reset(new BaseType[1]);
         _prob.reset(new BaseType[1]);

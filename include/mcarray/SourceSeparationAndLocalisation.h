@@ -8,7 +8,8 @@
 //   * process(in, nSamples, out, outSize) -- a stand-in for the dsp::ShortTimeProcess::process overloads the
 //     reference's callers use (mcabeamf.cpp:112, test_mcarray.cpp:869): buffers chunked PCM, runs every complete
 //     frame of the chunk through the batched stream API in ONE device call (STFT, GCC-PHAT, SRP, pick,
-//     delay-and-sum, ISTFT, overlap-add all on the GPU), fires the callback once per frame.  [BUILD-DEFINES]
+//     delay-and-sum, ISTFT, overlap-add all on the GPU; any frame length 2^order the sample rate gives), fires
+//     the callback once per frame.  [BUILD-DEFINES]
 //     framing: N = 2^order, hop N/2, periodic Hann, plain overlap-add.
 #ifndef MCA_HIP_SOURCESEPARATIONANDLOCALISATION_H
 #define MCA_HIP_SOURCESEPARATIONANDLOCALISATION_H
@@ -30,8 +31,7 @@ public:
     {
         const int N = 1 << _order;
         _impl.reset(new BeamformingSeparationAndLocalisation(sampleRate, N + 2, microphonePositions, numOfSources, usePowerFloor, doaStepDeg));
-        if (N == 1024)
-            _stream.reset(new detail::HipContext(sampleRate, microphonePositions, N, doaStepDeg, _numOfSources, usePowerFloor, srpPrecision));
+        _stream.reset(new detail::HipContext(sampleRate, microphonePositions, N, doaStepDeg, _numOfSources, usePowerFloor, srpPrecision));
         _pending.assign(static_cast<size_t>(_nchannels), std::vector<float>());
         for (int c = 0; c < _nchannels; ++c) _wienerCoefs.push_back(SignalPtr(new BaseType[N + 2]));
     }
@@ -70,7 +70,6 @@ public:
     template <typename Tin, typename Tout>
     int process(const std::vector<Tin *> &in, int nSamples, const std::vector<Tout *> &out, int outSize)
     {
-        if (!_stream) throw MCArrayException("process() needs the 1024-point stream path; use the frame hook for other frame sizes");
         const int N = getWindowSize(), hop = N / 2;
         for (int c = 0; c < _nchannels; ++c) {
             std::vector<float> &buf = _pending[static_cast<size_t>(c)];

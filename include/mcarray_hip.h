@@ -60,8 +60,10 @@ typedef struct {
     int device;                /* HIP device ordinal */
     int sample_rate;           /* Hz */
     int fft_size;              /* N; the reference derives it with calculateOrderFromSampleRate
-                                  (SourceSeparationAndLocalisation.cpp:52); the stream API supports N = 1024,
-                                  the frame API any even N with N/2+1 <= 4097 */
+                                  (SourceSeparationAndLocalisation.cpp:52).  Stream API: N = 1024 runs the tuned
+                                  kernels, any other power of two 64..8192 the any-length kernels as long as
+                                  (n_mics + n_sources) spectra of N/2+1 bins fit the 160 KiB LDS; the frame API
+                                  takes any even N with N/2+1 <= 4097 */
     int n_mics;                /* M, 2..16 */
     const double *mic_xyz;     /* [M][3] metres, ArrayDescription coordinates (ArrayDescription.h:31-92) */
     double doa_step_deg;       /* SteeringBeamforming.cpp:39 hard-codes 5.0; BASELINE uses 0.5 */

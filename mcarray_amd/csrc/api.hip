@@ -27,14 +27,16 @@ struct TimedEvent { int id; hipEvent_t a, b; };
 struct mca_hip_ctx {
     mca_hip_config cfg{};
     std::vector<double> xyz;
-    int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, Kp = 0, S = 1, prec = 0;
-    bool ula = false, stream_ok = false, force_v1 = false;
+    int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, H = 0, logH = 0, Kp = 0, S = 1, prec = 0;
+    bool ula = false, stream_ok = false, generic = false, force_v1 = false;
+    std::string stream_why;       // why the stream API is unavailable for this configuration
     int v2_min_rows = 32768;
     float step = 0.f;
     std::vector<float> delays, grid;
     std::vector<int2> pairs;
     // device tables
     float *d_window = nullptr, *d_grid = nullptr, *d_delays = nullptr;
+    float2 *d_tw = nullptr;       // [N/2] exp(-j 2 pi i / N), any-N kernels
     double *d_micx = nullptr;
     int2 *d_pairs = nullptr;
     void *d_B = nullptr;
@@ -108,7 +110,7 @@ void free_ctx(mca_hip_ctx *c)
 {
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->d_window); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B);
+    F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]);
     F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
@@ -148,7 +150,7 @@ int build_steering_table(mca_hip_ctx *c)
             for (int k = 0; k < K; ++k)
                 for (int d = 0; d < D; ++d) {
                     double ph = 2.0 * M_PI * (double)k * (double)c->delays[(size_t)first_pair[g] * D + d] / N;
-                    size_t r = ((size_t)g * KG + k) * 2;
+                    size_t r = ((size_t)g * K + k) * 2;
                     B[r * Dp + d] = (float)std::cos(ph);
                     B[(r + 1) * Dp + d] = (float)(-std::sin(ph));
                 }
@@ -163,7 +165,7 @@ int build_steering_table(mca_hip_ctx *c)
                     double ph = 2.0 * M_PI * (double)k * (double)c->delays[(size_t)first_pair[g] * D + d] / N;
                     float v[2] = {(float)std::cos(ph), (float)(-std::sin(ph))};
                     for (int q = 0; q < 2; ++q) {
-                        size_t kk = ((size_t)g * KG + k) * 2 + q;
+                        size_t kk = ((size_t)g * K + k) * 2 + q;
                         _Float16 hi = (_Float16)v[q];
                         B[(size_t)d * Kp + kk] = hi;
                         if (planes == 2) B[((size_t)Dp + d) * Kp + kk] = (_Float16)(v[q] - (float)hi);
@@ -283,11 +285,11 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
 int check_stream_args(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride, int n_arrays, int n_frames)
 {
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
-    if (!c->stream_ok) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "the stream API needs fft_size == 1024 (the frame API takes any size)");
+    if (!c->stream_ok) return fail(c, MCA_HIP_ERR_UNSUPPORTED, c->stream_why);
     if (!pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev is NULL");
     if (n_arrays < 1 || n_arrays > c->cfg.max_arrays) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays outside [1, max_arrays]");
     if (n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_frames < 1");
-    const long long need = (long long)(n_frames + 1) * FFT_H;
+    const long long need = (long long)(n_frames + 1) * c->H;
     if (mic_stride < need) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "mic_stride shorter than (n_frames+1)*hop samples");
     if (n_arrays > 1 && array_stride < (long long)(c->M - 1) * mic_stride + need) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "array_stride too short");
     if ((mic_stride & 1) || (array_stride & 1) || (reinterpret_cast<uintptr_t>(pcm) & 7))
@@ -337,7 +339,18 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     if (c->D < 3 || c->D > 512) { free_ctx(c); return fail(nullptr, MCA_HIP_ERR_UNSUPPORTED, "number of steering angles must be in [3,512]"); }
     c->P = c->M * (c->M - 1) / 2;
     c->Dp = round_up(c->D, 192);
-    c->stream_ok = (c->N == FFT_N);
+    c->H = c->N / 2;
+    // stream API: the tuned 1024-sample kernels, or the any-power-of-two kernels (kernels_generic.hip)
+    // whose channel spectra of one frame must fit the 160 KiB LDS of a CU
+    c->generic = c->N != FFT_N || std::getenv("MCA_HIP_FORCE_GENERIC") != nullptr;
+    c->stream_ok = true;
+    if (c->generic) {
+        while ((1 << c->logH) < c->H) ++c->logH;
+        if ((1 << c->logH) != c->H || c->N < 64) { c->stream_ok = false; c->stream_why = "the stream API needs a power-of-two fft_size >= 64 (the frame API takes any even size)"; }
+        else if ((size_t)(c->M + c->S) * (c->H + 1) * 8 + (size_t)c->S * c->H * 4 + 17 * c->S * 8 + 16 > 160 * 1024) {
+            c->stream_ok = false; c->stream_why = "fft_size x n_mics exceeds the 160 KiB LDS of a CU in the stream API (use the frame API)";
+        }
+    }
     c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switches for measurements
     if (std::getenv("MCA_HIP_V2_MIN_ROWS")) c->v2_min_rows = std::atoi(std::getenv("MCA_HIP_V2_MIN_ROWS"));
 
@@ -367,7 +380,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
                 if (std::memcmp(&fdist[p], &fdist[j - i - 1], sizeof(float)) != 0) { c->ula = false; break; }
     }
     c->G = c->ula ? c->M - 1 : c->P;
-    c->Kp = round_up(c->G * KG * 2, 32);
+    c->Kp = round_up(c->G * c->K * 2, 32);     // K == KG == 513 on the tuned path
     c->a_planes = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
     c->a_elem = c->prec == MCA_HIP_SRP_FP32 ? 4 : 2;
     c->a_row_elems = c->Kp * c->a_planes;
@@ -385,14 +398,16 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     };
     std::vector<double> micx(c->M);
     for (int m = 0; m < c->M; ++m) micx[m] = c->xyz[3 * m];
-    std::vector<float> win(FFT_N);
-    for (int n = 0; n < FFT_N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / FFT_N));   // periodic Hann
+    std::vector<float> win(c->N);
+    for (int n = 0; n < c->N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / c->N));   // periodic Hann
+    std::vector<float2> twv(c->N / 2);
+    for (int i = 0; i < c->N / 2; ++i) twv[i] = make_float2((float)std::cos(2.0 * M_PI * i / c->N), (float)(-std::sin(2.0 * M_PI * i / c->N)));
     const size_t na = (size_t)cfg->max_arrays;
-    if ((rc = up((void **)&c->d_window, win.data(), win.size() * 4)) || (rc = up((void **)&c->d_grid, c->grid.data(), c->grid.size() * 4)) ||
+    if ((rc = up((void **)&c->d_window, win.data(), win.size() * 4)) || (rc = up((void **)&c->d_tw, twv.data(), twv.size() * 8)) || (rc = up((void **)&c->d_grid, c->grid.data(), c->grid.size() * 4)) ||
         (rc = up((void **)&c->d_delays, c->delays.data(), c->delays.size() * 4)) || (rc = up((void **)&c->d_micx, micx.data(), micx.size() * 8)) ||
         (rc = up((void **)&c->d_pairs, c->pairs.data(), c->pairs.size() * sizeof(int2))) ||
         (rc = zalloc((void **)&c->d_E[0], na * c->D * 4)) || (rc = zalloc((void **)&c->d_E[1], na * c->D * 4)) ||
-        (rc = zalloc((void **)&c->d_tail[0], na * c->S * FFT_H * 4)) || (rc = zalloc((void **)&c->d_tail[1], na * c->S * FFT_H * 4)) ||
+        (rc = zalloc((void **)&c->d_tail[0], na * c->S * c->H * 4)) || (rc = zalloc((void **)&c->d_tail[1], na * c->S * c->H * 4)) ||
         (rc = zalloc((void **)&c->d_gate_state, na * 4 * 8)) || (rc = zalloc((void **)&c->d_last_bin, na * MCA_MAX_SOURCES * 4)) ||
         (rc = zalloc((void **)&c->d_last_rad, na * MCA_MAX_SOURCES * 4)) || (rc = zalloc((void **)&c->d_last_prob, na * MCA_MAX_SOURCES * 4)) ||
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
@@ -439,7 +454,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     const size_t na = (size_t)c->cfg.max_arrays;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(c, hipMemsetAsync(c->d_E[i], 0, na * c->D * 4, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_tail[i], 0, na * c->S * FFT_H * 4, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_tail[i], 0, na * c->S * c->H * 4, st));
         HIP_TRY(c, hipMemsetAsync(c->d_E64[i], 0, (size_t)c->D * 8, st));
         HIP_TRY(c, hipMemsetAsync(c->d_doa[i], 0, na * 4, st));
     }
@@ -472,10 +487,25 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         sa.M = c->M; sa.n_frames = nf; sa.frame0 = f0; sa.fpb = 8;
         sa.power = c->cfg.use_power_floor ? c->d_power : nullptr; sa.total_frames = n_frames;
         sa.window = c->d_window; sa.A = c->d_A; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
-        dim3 g1((nf + sa.fpb - 1) / sa.fpb, n_arrays);
-        const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
+        sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
-        rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft<float>(c, sa, g1, smem1, st) : launch_stft<_Float16>(c, sa, g1, smem1, st);
+        if (c->generic) {
+            const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2) + 16;
+#define GEN_LAUNCH(K)                                                                                                     \
+            do {                                                                                                          \
+                if (smem1 > 64 * 1024)                                                                                    \
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1)); \
+                hipLaunchKernelGGL(K, dim3(nf, n_arrays), dim3(256), smem1, st, sa);                                      \
+            } while (0)
+            if (c->prec == MCA_HIP_SRP_FP32) GEN_LAUNCH(k_stft_phat_gen<float>);
+            else GEN_LAUNCH(k_stft_phat_gen<_Float16>);
+#undef GEN_LAUNCH
+            rc = MCA_HIP_OK;
+        } else {
+            dim3 g1((nf + sa.fpb - 1) / sa.fpb, n_arrays);
+            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
+            rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft<float>(c, sa, g1, smem1, st) : launch_stft<_Float16>(c, sa, g1, smem1, st);
+        }
         time_end(c, st);
         if (rc) return rc;
 
@@ -528,7 +558,7 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     time_begin(c, MCA_HIP_K_SCAN_PICK, st);
     if (gate) {
         GateArgs gg{};
-        gg.power_lin = c->d_power; gg.n_frames = n_frames; gg.fft_n = FFT_N;
+        gg.power_lin = c->d_power; gg.n_frames = n_frames; gg.fft_n = c->N;
         gg.needed_samples = (int)(3.0 * c->cfg.sample_rate);              // _durationToEstimatePowerFloor (SoundLocalisationImpl.h:77)
         gg.margin_db = 3.f;                                                // _noiseMarginDB (BeamformingSeparationAndLocalistaion.h:52)
         gg.state = c->d_gate_state; gg.voiced = c->d_voiced; gg.power_out = c->d_power_out;
@@ -575,6 +605,18 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     ba.M = c->M; ba.Mpad = c->M; ba.S = c->S; ba.n_frames = n_frames; ba.ft = 16; ba.fs = c->cfg.sample_rate;
     ba.window = c->d_window; ba.mic_x = c->d_micx; ba.doa_rad = doa_rad; ba.out = out_pcm;
     ba.tail_in = c->d_tail[c->tail_cur]; ba.tail_out = c->d_tail[c->tail_cur ^ 1];
+    ba.N = c->N; ba.logH = c->logH; ba.tw = c->d_tw;
+    if (c->generic) {
+        const size_t smem = (size_t)(c->M + c->S) * (c->H + 1) * sizeof(float2) + (size_t)c->S * c->H * sizeof(float) + (size_t)(ba.ft + 1) * c->S * sizeof(double);
+        if (smem > 64 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_beamform_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        time_begin(c, MCA_HIP_K_BEAMFORM, st);
+        hipLaunchKernelGGL(k_beamform_gen, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(256), smem, st, ba);
+        time_end(c, st);
+        HIP_TRY(c, hipGetLastError());
+        c->tail_cur ^= 1;
+        return MCA_HIP_OK;
+    }
     const size_t smem = ((size_t)ba.M + BF_NB * c->S) * FFT_SCRATCH * sizeof(float2) + (size_t)c->S * c->M * 49 * sizeof(float2) +
                         TW_WORDS * sizeof(float2) + (size_t)BF_NB * c->M * (1 + c->S) * sizeof(float2) +
                         (size_t)(ba.ft + 1) * c->S * sizeof(double);
@@ -615,7 +657,7 @@ int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, 
     if (!c || !pcm || !doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const long long ms = (long long)(n_frames + 1) * FFT_H, as = ms * c->M;
+    const long long ms = (long long)(n_frames + 1) * c->H, as = ms * c->M;
     const size_t n_pcm = (size_t)as * n_arrays, n_fs = (size_t)n_arrays * n_frames * c->S;
     float *d_pcm = nullptr, *d_rad = nullptr, *d_prob = nullptr, *d_en = nullptr, *d_out = nullptr;
     int *d_bin = nullptr;
@@ -627,7 +669,7 @@ int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, 
     TRY2(hipMalloc((void **)&d_rad, n_fs * 4));
     TRY2(hipMalloc((void **)&d_prob, n_fs * 4));
     if (energy) TRY2(hipMalloc((void **)&d_en, (size_t)n_arrays * n_frames * c->D * 4));
-    if (out_pcm) TRY2(hipMalloc((void **)&d_out, (size_t)n_arrays * c->S * n_frames * FFT_H * 4));
+    if (out_pcm) TRY2(hipMalloc((void **)&d_out, (size_t)n_arrays * c->S * n_frames * c->H * 4));
     TRY2(hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
     rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
     if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
@@ -637,7 +679,7 @@ int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, 
     if (doa_rad) TRY2(hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
     if (prob) TRY2(hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
     if (energy) TRY2(hipMemcpy(energy, d_en, (size_t)n_arrays * n_frames * c->D * 4, hipMemcpyDeviceToHost));
-    if (out_pcm) TRY2(hipMemcpy(out_pcm, d_out, (size_t)n_arrays * c->S * n_frames * FFT_H * 4, hipMemcpyDeviceToHost));
+    if (out_pcm) TRY2(hipMemcpy(out_pcm, d_out, (size_t)n_arrays * c->S * n_frames * c->H * 4, hipMemcpyDeviceToHost));
 #undef TRY2
     cleanup();
     return MCA_HIP_OK;
@@ -683,7 +725,7 @@ int mca_hip_gcc2_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int
     if (!c || !pcm || !argmax) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const long long ms = (long long)(n_frames + 1) * FFT_H, as = ms * c->M;
+    const long long ms = (long long)(n_frames + 1) * c->H, as = ms * c->M;
     const size_t n_pcm = (size_t)as * n_arrays, n_f = (size_t)n_arrays * n_frames;
     float *d_pcm = nullptr, *d_rad = nullptr, *d_prob = nullptr, *d_corr = nullptr;
     int *d_idx = nullptr;

@@ -11,6 +11,8 @@ __global__ void k_scan_pick(ScanPickArgs p);
 __global__ void k_gate(GateArgs p);
 __global__ void k_doa_fill(DoaFillArgs p);
 template <int CPW, int OCC> __global__ void k_beamform_ola(BeamformArgs p);
+template <typename OutT> __global__ void k_stft_phat_gen(StftPhatArgs p);
+__global__ void k_beamform_gen(BeamformArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);
 template <bool SPLIT> __global__ void k_srp_gemm_f16(GemmArgs p);

@@ -1,0 +1,244 @@
+// kernels_generic.hip -- any-power-of-two frame length for the stream API (gfx950).
+//
+// The tuned kernels of kernels_stream.hip are built around the 1024-sample frame the reference's
+// 44.1/48 kHz configuration uses (calculateOrderFromSampleRate).  Other sample rates give
+// N = 256 ... 4096 (8 kHz -> 256, 16 kHz -> 512, 96 kHz -> 2048).  These two kernels cover them with
+// the same data layout and the same arithmetic conventions: one workgroup per frame (analysis) or
+// per run of frames (synthesis), all channels transformed together by a block-cooperative radix-2
+// FFT in LDS with a twiddle table in global memory (L2 resident).  They feed the same SRP
+// contraction, scan and gate kernels; only the transform is slower (one barrier per radix-2 stage).
+//
+//   k_stft_phat_gen   PCM -> windowed N-pt real FFT per channel -> PHAT -> pair / delay-group sums -> A
+//   k_beamform_gen    PCM -> FFT -> delay-and-sum (Beamformer.cpp:51-71) -> inverse FFT -> overlap-add
+#include "fft512.h"
+#include "mca_internal.h"
+
+namespace mca {
+
+namespace {
+
+__device__ __forceinline__ float2 whiten_g(float2 z)
+{
+    const float pw = z.x * z.x + z.y * z.y;
+    const float s = pw > 1e-30f ? rsqrtf(pw) : 0.f;
+    return make_float2(z.x * s, z.y * s);
+}
+
+// nch interleaved H-point complex transforms in LDS, channel c at z + c * zs.
+// DIT: input in bit-reversed order, output natural.  Ends with a barrier.
+__device__ __forceinline__ void block_fft_dit(float2 *z, int zs, int nch, int logH, const float2 *tw, int N, int tid, int nthr)
+{
+    const int halfH = 1 << (logH - 1);
+    for (int s = 0; s < logH; ++s) {
+        const int half = 1 << s;
+        for (int e = tid; e < nch * halfH; e += nthr) {
+            const int ch = e >> (logH - 1), j = e & (halfH - 1);
+            const int pos = j & (half - 1);
+            const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
+            const float2 w = tw[pos * (N >> (s + 1))];               // exp(-j 2 pi pos / (2 half))
+            float2 *zz = z + ch * zs;
+            const float2 a = zz[i0], b = cmul(zz[i1], w);
+            zz[i0] = cadd(a, b); zz[i1] = csub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+// inverse, DIF: natural input, bit-reversed output, unnormalised.  Ends with a barrier.
+__device__ __forceinline__ void block_ifft_dif(float2 *z, int zs, int nch, int logH, const float2 *tw, int N, int tid, int nthr)
+{
+    const int halfH = 1 << (logH - 1);
+    for (int s = logH - 1; s >= 0; --s) {
+        const int half = 1 << s;
+        for (int e = tid; e < nch * halfH; e += nthr) {
+            const int ch = e >> (logH - 1), j = e & (halfH - 1);
+            const int pos = j & (half - 1);
+            const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
+            const float2 w = cconj(tw[pos * (N >> (s + 1))]);
+            float2 *zz = z + ch * zs;
+            const float2 a = zz[i0], b = zz[i1];
+            zz[i0] = cadd(a, b); zz[i1] = cmul(csub(a, b), w);
+        }
+        __syncthreads();
+    }
+}
+
+// windowed frame t of nch channels -> packed z[n] = x[2n] + j x[2n+1] at bit-reversed n
+__device__ __forceinline__ void load_frames(float2 *z, int zs, int nch, int logH, const float *base, long long mic_stride,
+                                            long long t, const float *window, int tid, int nthr)
+{
+    const int H = 1 << logH;
+    for (int e = tid; e < nch * H; e += nthr) {
+        const int ch = e >> logH, n = e & (H - 1);
+        const float2 x = reinterpret_cast<const float2 *>(base + (long long)ch * mic_stride + t * H)[n];
+        const float2 w = reinterpret_cast<const float2 *>(window)[n];
+        z[ch * zs + (int)(__brev((unsigned)n) >> (32 - logH))] = make_float2(x.x * w.x, x.y * w.y);
+    }
+    __syncthreads();
+}
+
+// Z (H-point transform of the packed sequence) -> one-sided spectrum X[0..H], in place.  Ends with a barrier.
+__device__ __forceinline__ void split_forward(float2 *z, int zs, int nch, int logH, const float2 *tw, int tid, int nthr)
+{
+    const int H = 1 << logH, per = H / 2 + 1;
+    for (int e = tid; e < nch * per; e += nthr) {
+        const int ch = e / per, k = e - ch * per;
+        float2 *zz = z + ch * zs;
+        if (k == 0) {
+            const float2 z0 = zz[0];
+            zz[0] = make_float2(z0.x + z0.y, 0.f);
+            zz[H] = make_float2(z0.x - z0.y, 0.f);
+        } else {
+            const float2 zk = zz[k], zp = zz[H - k];
+            const float2 ev = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));     // (Zk + conj Zp) / 2
+            const float2 od = make_float2(0.5f * (zk.y + zp.y), -0.5f * (zk.x - zp.x));    // (Zk - conj Zp) / 2j
+            const float2 wo = cmul(od, tw[k]);                                              // W_N^k O[k]
+            zz[k] = cadd(ev, wo);
+            zz[H - k] = cconj(csub(ev, wo));
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------
+// k_stft_phat_gen: grid (frames of the chunk, arrays), 256 threads, LDS = M * (H + 1) float2 (+ 4 floats)
+// --------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_stft_phat_gen(StftPhatArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = p.M, logH = p.logH, H = 1 << logH, zs = H + 1;
+    float2 *xs = reinterpret_cast<float2 *>(smem_raw);                  // [M][H + 1]
+    float *spow = reinterpret_cast<float *>(xs + M * zs);               // [1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int a = blockIdx.y, f = blockIdx.x;
+    const float *base = p.pcm + (long long)a * p.array_stride;
+    if (tid == 0) spow[0] = 0.f;
+
+    load_frames(xs, zs, M, logH, base, p.mic_stride, (long long)p.frame0 + f, p.window, tid, 256);
+    block_fft_dit(xs, zs, M, logH, p.tw, p.N, tid, 256);
+    split_forward(xs, zs, M, logH, p.tw, tid, 256);
+
+    if (p.power) {
+        // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
+        float acc = 0.f;
+        for (int k = tid; k <= H; k += 256) {
+            float s = 0.f;
+            for (int m = 0; m < M; ++m) { const float2 z = xs[m * zs + k]; s += z.x * z.x + z.y * z.y; }
+            acc += (k == 0 || k == H) ? s : 2.f * s;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) atomicAdd(spow, acc);
+    }
+    // PHAT whitening in place (each thread its own bins), then the pair products of those bins
+    OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f) * (long long)p.a_row_elems;
+    const int kg = p.kg;
+    for (int k = tid; k <= H; k += 256) {
+        for (int m = 0; m < M; ++m) xs[m * zs + k] = whiten_g(xs[m * zs + k]);
+        if (p.ula) {
+            for (int g = 0; g < M - 1; ++g) {
+                float2 acc = make_float2(0.f, 0.f);
+                for (int i = 0; i + g + 1 < M; ++i) acc = cadd(acc, cmulc(xs[i * zs + k], xs[(i + g + 1) * zs + k]));
+                store_a(arow, p, g * kg + k, acc);
+            }
+        } else {
+            int pi = 0;
+            for (int i = 0; i < M; ++i)
+                for (int j = i + 1; j < M; ++j) { store_a(arow, p, pi * kg + k, cmulc(xs[i * zs + k], xs[j * zs + k])); ++pi; }
+        }
+    }
+    if (p.power) {
+        __syncthreads();
+        if (tid == 0) p.power[(long long)a * p.total_frames + p.frame0 + f] = spow[0] / ((float)p.N * (float)p.N) / (float)M;
+    }
+}
+
+template __global__ void k_stft_phat_gen<float>(StftPhatArgs);
+template __global__ void k_stft_phat_gen<_Float16>(StftPhatArgs);
+
+// --------------------------------------------------------------------------------------
+// k_beamform_gen: grid (runs of ft frames, arrays), 256 threads,
+// LDS = (M + S) * (H + 1) float2 + S * H floats (overlap-add carry) + (ft + 1) * S doubles
+// --------------------------------------------------------------------------------------
+// A run starts one frame early (tfirst = t0 - 1) to rebuild the overlap-add carry the previous run
+// leaves; the very first run of a call takes it from tail_in and the last one leaves it in tail_out.
+__global__ __launch_bounds__(256) void k_beamform_gen(BeamformArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = p.M, S = p.S, a = blockIdx.y, logH = p.logH, H = 1 << logH, zs = H + 1;
+    float2 *xs = reinterpret_cast<float2 *>(smem_raw);                 // [M][H + 1]
+    float2 *ys = xs + M * zs;                                           // [S][H + 1]
+    float *carry = reinterpret_cast<float *>(ys + S * zs);             // [S][H]
+    double *cdoa = reinterpret_cast<double *>(carry + S * H + ((S * H) & 1));   // [ft + 1][S]
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * p.ft;
+    const int t1 = min(t0 + p.ft, p.n_frames);
+    const int tfirst = t0 > 0 ? t0 - 1 : 0;
+
+    for (int e = tid; e < (t1 - tfirst) * S; e += 256) {
+        const double doa = (double)p.doa_rad[((long long)a * p.n_frames + tfirst) * S + e];
+        cdoa[e] = cos(doa + 1.57079632679489661923);                    // cos(DOA + M_PI/2), Beamformer.cpp:59
+    }
+    for (int e = tid; e < S * H; e += 256) carry[e] = t0 == 0 ? p.tail_in[(long long)a * S * H + e] : 0.f;
+    __syncthreads();
+
+    const float *base = p.pcm + (long long)a * p.array_stride;
+    const double unit = (double)p.fs / (double)p.N / 346.1;            // Beamformer.cpp:59 without 2 pi
+    const float inv = 1.0f / (float)M;
+    const float sc = 1.0f / (float)H;
+
+    for (int t = tfirst; t < t1; ++t) {
+        load_frames(xs, zs, M, logH, base, p.mic_stride, (long long)t, p.window, tid, 256);
+        block_fft_dit(xs, zs, M, logH, p.tw, p.N, tid, 256);
+        split_forward(xs, zs, M, logH, p.tw, tid, 256);
+        // delay-and-sum: Y[k] = (1/M) sum_c X_c[k] exp(j 2 pi k unit x_c cos(DOA + pi/2))
+        for (int e = tid; e < S * (H + 1); e += 256) {
+            const int s = e / (H + 1), k = e - s * (H + 1);
+            const double cd = cdoa[(t - tfirst) * S + s];
+            float2 acc = make_float2(0.f, 0.f);
+            for (int c = 0; c < M; ++c) {
+                double turns = (double)k * (unit * p.mic_x[c] * cd);
+                turns -= rint(turns);
+                float sn, cs;
+                sincospif(2.0f * (float)turns, &sn, &cs);
+                acc = cadd(acc, cmul(xs[c * zs + k], make_float2(cs, sn)));
+            }
+            ys[s * zs + k] = make_float2(acc.x * inv, acc.y * inv);     // divC :70
+        }
+        __syncthreads();
+        // one-sided spectrum -> packed Z (imaginary parts of DC and Nyquist ignored, like a CCS inverse)
+        for (int e = tid; e < S * (H / 2 + 1); e += 256) {
+            const int s = e / (H / 2 + 1), k = e - s * (H / 2 + 1);
+            float2 *yy = ys + s * zs;
+            float2 xk = yy[k], xp = yy[H - k];
+            if (k == 0) { xk.y = 0.f; xp.y = 0.f; }
+            const float2 ev = make_float2(0.5f * (xk.x + xp.x), 0.5f * (xk.y - xp.y));
+            const float2 df = make_float2(0.5f * (xk.x - xp.x), 0.5f * (xk.y + xp.y));
+            const float2 od = cmulc(df, p.tw[k]);                        // conj(W_N^k) (X[k] - conj X[H-k]) / 2
+            yy[k] = make_float2(ev.x - od.y, ev.y + od.x);               // E + j O
+            if (k != 0 && k != H - k) yy[H - k] = make_float2(ev.x + od.y, -ev.y + od.x);   // conj(E) + j conj(O)
+        }
+        __syncthreads();
+        block_ifft_dif(ys, zs, S, logH, p.tw, p.N, tid, 256);
+        // overlap-add: y[2n], y[2n+1] = Re, Im of z[n] / H, z[n] stored at bitrev(n)
+        for (int e = tid; e < S * (H / 2); e += 256) {
+            const int s = e / (H / 2), n = e - s * (H / 2);              // sample pair (2n, 2n+1) of the hop
+            const float2 lo = ys[s * zs + (int)(__brev((unsigned)n) >> (32 - logH))];
+            const float2 hi = ys[s * zs + (int)(__brev((unsigned)(n + H / 2)) >> (32 - logH))];
+            float *cr = carry + s * H + 2 * n;
+            if (t >= t0) {
+                float *o = p.out + ((long long)a * S + s) * (long long)p.n_frames * H + (long long)t * H + 2 * n;
+                o[0] = cr[0] + lo.x * sc; o[1] = cr[1] + lo.y * sc;
+            }
+            cr[0] = hi.x * sc; cr[1] = hi.y * sc;
+        }
+        __syncthreads();
+    }
+    if (t1 == p.n_frames)
+        for (int e = tid; e < S * H; e += 256) p.tail_out[(long long)a * S * H + e] = carry[e];
+}
+
+}  // namespace mca

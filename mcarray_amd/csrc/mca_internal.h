@@ -27,6 +27,9 @@ struct StftPhatArgs {
     int a_planes;            // 1 (fp32 / fp16) or 2 (fp16 hi plane + lo plane)
     float *power;            // [arrays][total_frames] linear FFTPower per frame, or NULL (ungated)
     int total_frames;
+    // any-N kernels only (kernels_generic.hip)
+    int N, logH, kg, ula;    // frame length, log2(N/2), K-slots per delay group (= N/2 + 1), delay-group merging on/off
+    const float2 *tw;        // [N/2] exp(-j 2 pi i / N)
 };
 
 __device__ __forceinline__ void store_a(float *row, const StftPhatArgs &, int cidx, float2 v)
@@ -100,6 +103,9 @@ struct BeamformArgs {
     float *out;              // [arrays][S][n_frames*hop]
     const float *tail_in;    // [arrays][S][hop] overlap-add carry at entry
     float *tail_out;         // at exit
+    // any-N kernel only (kernels_generic.hip)
+    int N, logH;
+    const float2 *tw;        // [N/2] exp(-j 2 pi i / N)
 };
 
 struct Gcc2ScanArgs {

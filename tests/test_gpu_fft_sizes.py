@@ -1,0 +1,131 @@
+"""GPU parity for the stream API at frame lengths other than 1024 (kernels_generic.hip), through
+the C ABI, against the CPU oracle.  The reference derives the frame length from the sample rate
+(calculateOrderFromSampleRate): 8 kHz -> 256, 16 kHz -> 512, 96 kHz -> 2048, 192 kHz -> 4096.
+
+Tolerances as in test_gpu_parity.py: DOA bins exact (flagged ties +-1), energy map
+<= TOL_E * max|E|, audio <= 2e-5 * max|out| + 1e-7.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mcarray_amd import api, synth
+from oracle import pyoracle as po
+from test_gpu_parity import TOL_E, _assert_bins
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3])
+@pytest.mark.parametrize("fs,N,step", [(8000, 256, 5.0), (16000, 512, 5.0), (96000, 2048, 0.5), (192000, 4096, 5.0)])
+def test_stream_other_frame_lengths_ula8(fs, N, step, prec):
+    xs, F, A = synth.ULA8, 24, 2
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-50.0 + 75.0 * a), fs, (F + 1) * N // 2, 31 + a) for a in range(A)])
+    ctx = api.Context(fs, xs, N, step, 1, srp_precision=prec, max_arrays=A)
+    assert ctx.G == 7
+    r = ctx.process_frames_host(pcm, want_energy=True)
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, step, want_map=True)
+        _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=2)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= TOL_E[prec] * np.abs(o["energy"]).max()
+        assert np.abs(r["out"][a] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+
+
+def test_other_frame_length_irregular_array_two_sources_and_state():
+    # Reem-C (no delay-group merging), 2 sources, N = 512; then the same stream in two calls
+    fs, N, F = 16000, 512, 30
+    xs = synth.REEM_C
+    pcm = synth.noise_source_stream(xs, np.deg2rad(35.0), fs, (F + 1) * N // 2, 12)
+    ctx = api.Context(fs, xs, N, 5.0, 2)
+    assert ctx.G == ctx.P == 6
+    r = ctx.process_frames_host(pcm[None], want_energy=True)
+    o = po.ssl_stream(fs, N, xs, pcm.astype(np.float64), 2, 5.0, want_map=True)
+    _assert_bins(r["bin"][0], o["bin"], o["energy"], 6, max_ties=1)
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+    assert np.abs(r["out"][0] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+    ctx = api.Context(fs, xs, N, 5.0, 2)
+    h, hop = 13, N // 2
+    ra = ctx.process_frames_host(pcm[None, :, :(h + 1) * hop], want_energy=True)
+    rb = ctx.process_frames_host(pcm[None, :, h * hop:], want_energy=True)
+    assert np.array_equal(np.concatenate([ra["bin"], rb["bin"]], axis=1), r["bin"])
+    np.testing.assert_allclose(np.concatenate([ra["energy"], rb["energy"]], axis=1), r["energy"], rtol=0, atol=1e-6 * np.abs(r["energy"]).max())
+    np.testing.assert_allclose(np.concatenate([ra["out"], rb["out"]], axis=2), r["out"], rtol=0, atol=1e-6 * np.abs(r["out"]).max())
+    ctx.close()
+
+
+def test_other_frame_length_power_gate():
+    # the gate's floor estimation counts fft_size samples per frame (BeamformingSeparationAndLocalisation.cpp:58-66):
+    # 3 s at 16 kHz = 94 frames of 512 samples
+    fs, N, F = 16000, 512, 200
+    xs, hop = synth.ULA8, N // 2
+    rng = np.random.default_rng(3)
+    L = (F + 1) * hop
+    src = synth.noise_source_stream(xs, np.deg2rad(20.0), fs, L, 21).astype(np.float64)
+    env = np.zeros(L)
+    for a, b in ((105, 125), (131, 140), (150, F - 1)):
+        env[a * hop:b * hop] = 1.0
+    pcm = (rng.standard_normal((len(xs), L)) * 0.001 + src * env).astype(np.float32)
+    o = po.ssl_stream_gated(fs, N, xs, pcm.astype(np.float64), 1, 5.0, True)
+    assert 0 < o["fired"].sum() < F and o["fired"][:94].sum() == 0
+    ctx = api.Context(fs, xs, N, 5.0, 1, use_power_floor=True)
+    r = ctx.process_frames_host(pcm[None], want_energy=True)
+    assert np.array_equal(r["voiced"][0], o["fired"])
+    np.testing.assert_allclose(r["power"][0][94:], o["power"][94:], rtol=0, atol=2e-3)          # dB
+    np.testing.assert_allclose(r["power"][0][:93], o["power"][:93], rtol=2e-5)                  # running sum (linear)
+    assert np.array_equal(r["bin"][0], o["bin"])
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+    assert np.abs(r["out"][0] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+
+
+def test_any_length_kernels_agree_with_tuned_kernels_at_1024():
+    # MCA_HIP_FORCE_GENERIC routes N = 1024 through kernels_generic.hip: same A layout, same contraction
+    fs, N, F, A = 48000, 1024, 40, 2
+    xs = synth.ULA8
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-20.0 + 60 * a), fs, (F + 1) * N // 2, 70 + a) for a in range(A)])
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP32, max_arrays=A)
+    r = ctx.process_frames_host(pcm, want_energy=True)
+    ctx.close()
+    os.environ["MCA_HIP_FORCE_GENERIC"] = "1"
+    try:
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP32, max_arrays=A)
+    finally:
+        del os.environ["MCA_HIP_FORCE_GENERIC"]
+    g = ctx.process_frames_host(pcm, want_energy=True)
+    ctx.close()
+    assert (g["bin"] != r["bin"]).sum() <= 1
+    assert np.abs(g["energy"] - r["energy"]).max() <= 4e-6 * np.abs(r["energy"]).max()
+    assert np.abs(g["out"] - r["out"]).max() <= 4e-6 * np.abs(r["out"]).max()
+
+
+def test_two_microphone_gcc_at_512():
+    fs, N, F = 16000, 512, 90
+    pcm = synth.noise_source_stream(synth.BINAURAL, np.deg2rad(33.0), fs, (F + 1) * N // 2, 4)
+    ctx = api.Context(fs, synth.BINAURAL, N, 3.0, 1)
+    r = ctx.gcc2_frames_host(pcm[None], want_corr=True)
+    og = po.FreqGCC(fs, synth.BINAURAL, N + 2, False, 3.0)
+    X = po.stft_frames(pcm.astype(np.float64), N)
+    nbad = 0
+    for t in range(F):
+        voiced, corr, idx, doa, power = og.process(X[t, 0], X[t, 1])
+        if idx != r["argmax"][0, t]:
+            assert abs(corr[idx] - corr[r["argmax"][0, t]]) < 1e-5 * np.abs(corr).max()
+            nbad += 1
+        assert np.abs(r["corr"][0, t] - corr).max() <= 2e-5 * np.abs(corr).max()
+        assert abs(r["doa"][0, t] - doa) <= 2e-5 + 0.06 * nbad
+    assert nbad <= 1
+    ctx.close()
+
+
+def test_unsupported_stream_sizes_say_why():
+    ctx = api.Context(48000, synth.ULA8, 1000, 5.0, 1)             # even but not a power of two: frame API only
+    with pytest.raises(api.MCArrayHipError, match="power-of-two"):
+        ctx.process_frames_host(np.zeros((1, 8, 3 * 500), np.float32))
+    ctx.close()
+    ctx = api.Context(48000, synth.ULA16, 4096, 5.0, 1)            # 16 spectra of 2049 bins exceed the LDS
+    with pytest.raises(api.MCArrayHipError, match="LDS"):
+        ctx.process_frames_host(np.zeros((1, 16, 3 * 2048), np.float32))
+    ctx.close()

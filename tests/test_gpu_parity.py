@@ -214,9 +214,9 @@ def test_invalid_arguments_are_rejected():
         api.Context(48000, [0.0], 1024)                       # one microphone
     with pytest.raises(api.MCArrayHipError):
         api.Context(48000, synth.ULA8, 1024, doa_step_deg=0.1)   # > 512 steering angles
-    ctx = api.Context(48000, synth.ULA8, 2048, 5.0)
-    with pytest.raises(api.MCArrayHipError):                   # stream API is N = 1024 only
-        ctx.process_frames_host(np.zeros((1, 8, 4096), dtype=np.float32))
+    ctx = api.Context(48000, synth.ULA8, 1536, 5.0)
+    with pytest.raises(api.MCArrayHipError):                   # stream API needs a power-of-two frame length
+        ctx.process_frames_host(np.zeros((1, 8, 3 * 768), dtype=np.float32))
     ctx = api.Context(48000, synth.ULA8, 1024, 5.0, max_arrays=1)
     with pytest.raises(api.MCArrayHipError):
         ctx.process_frames_host(np.zeros((2, 8, 2048), dtype=np.float32))   # more arrays than max_arrays
