@@ -231,14 +231,25 @@ class Beamformer:
         return self.ctx.beamformer_process_frame(analysis_frames, doa)
 
 
+def calculate_order_from_sample_rate(sample_rate, frame_seconds):
+    """[BUILD-DEFINES] stand-in for dsp::STFT::calculateOrderFromSampleRate (SURVEY A.1): the frame length the
+    reference's stream modules derive from the sample rate, N = 2^order."""
+    order = int(np.floor(np.log2(sample_rate * frame_seconds) + 0.5))
+    return min(max(order, 8), 14)
+
+
 class SourceSeparationAndLocalisation:
     """mca::SourceSeparationAndLocalisation(int sampleRate, ArrayDescription, unsigned numOfSources,
     bool usePowerFloor) (SourceSeparationAndLocalisation.h:47) driven over whole buffers: process()
     takes channel-major PCM, returns the beamformed audio and calls the callback once per frame
     like LocalisationCallback::setDOA(doaDegrees, prob, power, numOfSources) (SoundLocalisationCallback.h:53)."""
 
-    def __init__(self, sample_rate, mic_positions, n_sources=1, use_power_floor=False, doa_step_deg=5.0, fft_size=1024,
+    FRAME_SECONDS = 0.025        # _frameRate (SourceSeparationAndLocalisation.h:60)
+
+    def __init__(self, sample_rate, mic_positions, n_sources=1, use_power_floor=False, doa_step_deg=5.0, fft_size=None,
                  srp_precision=SRP_FP32, device=0):
+        if fft_size is None:
+            fft_size = 1 << calculate_order_from_sample_rate(sample_rate, self.FRAME_SECONDS)   # .cpp:52
         self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, n_sources, use_power_floor, srp_precision, 1, device)
         self.callback = None
 
@@ -261,8 +272,12 @@ class FreqGCCBinauralLocalisation:
     (BinauralLocalisation.h:191), deterministic part: smoothed GCC-PHAT correlation, first-max argmax,
     DOA smoothing and setProbability.  The reference's grid is 3 degrees (BinauralLocalisation.cpp:328)."""
 
-    def __init__(self, sample_rate, mic_positions, use_power_floor=False, doa_step_deg=3.0, fft_size=1024,
+    FRAME_SECONDS = 0.075        # _frameRate (BinauralLocalisation.h:196)
+
+    def __init__(self, sample_rate, mic_positions, use_power_floor=False, doa_step_deg=3.0, fft_size=None,
                  srp_precision=SRP_FP32, max_arrays=1, device=0):
+        if fft_size is None:
+            fft_size = 1 << calculate_order_from_sample_rate(sample_rate, self.FRAME_SECONDS)
         if use_power_floor:
             raise MCArrayHipError("the stream API runs ungated (usePowerFloor=false)")
         self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, 1, False, srp_precision, max_arrays, device)

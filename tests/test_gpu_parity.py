@@ -492,12 +492,14 @@ def test_workspace_chunking_gives_identical_results():
     assert a.stdout.strip().splitlines()[-1] == b.stdout.strip().splitlines()[-1]
 
 
-def test_mcbeam_cli_wav_roundtrip(tmp_path):
-    """tools/mcbeam.py (the counterpart of src/programs/mcabeamf.cpp): 4-channel 16-bit WAV in, mono WAV + DOA text out."""
+@pytest.mark.parametrize("fs,N", [(48000, 1024), (16000, 512)])
+def test_mcbeam_cli_wav_roundtrip(tmp_path, fs, N):
+    """tools/mcbeam.py (the counterpart of src/programs/mcabeamf.cpp): 4-channel 16-bit WAV in, mono WAV + DOA text out;
+    the frame length follows the sample rate like the reference's module (SourceSeparationAndLocalisation.cpp:52)."""
     import subprocess, sys, wave, os
-    fs, F = 48000, 40
+    F, hop = 40, N // 2
     xs = synth.REEM_C
-    x = synth.noise_source_stream(xs, np.deg2rad(25.0), fs, (F + 1) * 512, 12)
+    x = synth.noise_source_stream(xs, np.deg2rad(25.0), fs, (F + 1) * hop, 12)
     pcm16 = np.clip(np.round(x * 32768), -32768, 32767).astype("<i2")
     wav_in, wav_out, doa_txt = str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), str(tmp_path / "doa.txt")
     with wave.open(wav_in, "wb") as w:
@@ -509,7 +511,7 @@ def test_mcbeam_cli_wav_roundtrip(tmp_path):
     doa = np.loadtxt(doa_txt)
     assert doa.shape == (F, 2) and np.all(np.abs(doa[5:, 0] - 25.0) <= 5.0)
     with wave.open(wav_out, "rb") as w:
-        assert w.getnchannels() == 1 and w.getframerate() == fs and w.getnframes() == F * 512
-        y = np.frombuffer(w.readframes(F * 512), dtype="<i2").astype(np.float64) / 32768
-    o = po.ssl_stream(fs, 1024, xs, pcm16.astype(np.float64) / 32768, 1, 5.0)
+        assert w.getnchannels() == 1 and w.getframerate() == fs and w.getnframes() == F * hop
+        y = np.frombuffer(w.readframes(F * hop), dtype="<i2").astype(np.float64) / 32768
+    o = po.ssl_stream(fs, N, xs, pcm16.astype(np.float64) / 32768, 1, 5.0)
     assert np.abs(y - o["out"][0]).max() <= 1.5 / 32768 + 2e-5

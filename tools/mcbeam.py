@@ -48,10 +48,12 @@ def main():
     a = ap.parse_args()
     fs, x = read_wav(a.input)
     xs = [float(v) for v in a.mics.split(",")]
-    hop = 512
+    # frame length from the sample rate, like the reference's modules (N = 2^order, hop N/2)
+    seconds = api.FreqGCCBinauralLocalisation.FRAME_SECONDS if a.binaural else api.SourceSeparationAndLocalisation.FRAME_SECONDS
+    hop = (1 << api.calculate_order_from_sample_rate(fs, seconds)) // 2
     F = x.shape[1] // hop - 1
     if F < 1:
-        raise SystemExit("input shorter than one 1024-sample frame")
+        raise SystemExit("input shorter than one %d-sample frame" % (2 * hop))
     x = np.ascontiguousarray(x[:, :(F + 1) * hop])
     out = sys.stdout if not a.doa_file else open(a.doa_file, "w")
     if a.binaural:
