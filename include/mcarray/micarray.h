@@ -5,6 +5,7 @@
 #include "ArrayModules.h"
 #include "BinauralLocalisation.h"
 #include "FastBinauralMasking.h"
+#include "MultibandBinarualLocalisation.h"
 #include "Beamformer.h"
 #include "BeamformingSeparationAndLocalistaion.h"
 #include "SoundLocalisationCallback.h"

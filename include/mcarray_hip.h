@@ -209,6 +209,40 @@ int mca_hip_mask_frames_host(mca_hip_mask_ctx *ctx, const float *pcm, int n_stre
 /* the DSPONE hook itself: one frame, left/right CCS double[N+2] modified in place (:199-200), double on the GPU */
 int mca_hip_mask_process_frame(mca_hip_mask_ctx *ctx, double *left, double *right, int ccs_len, int *decisions);
 
+/* ---- MultibandBinarualLocalisation (2 microphones) ---------------------------
+ * Replaces mca::MultibandBinarualLocalisation(int sampleRate, ArrayDescription, int nbins = 15, bool usePowerFloor = 1)
+ * (include/mcarray/MultibandBinarualLocalisation.h:38) with its per-frame hooks processSetup / processOneSubband /
+ * processSumamry (src/mcarray/MultibandBinarualLocalisation.cpp:145-258) for batches of frames.  The sub-band
+ * splitting (dsp::SubBandSTFTAnalysis, DSPONE) is [BUILD-DEFINES]: nbins unit-peak triangular filters, edges
+ * linearly spaced between 100 Hz and maxFreqForSpatialAliasing(distance(0,1)) (ctor call :54-60). */
+typedef struct mca_hip_mb_ctx mca_hip_mb_ctx;
+typedef struct {
+    int struct_size;
+    int device;
+    int sample_rate;
+    int fft_size;            /* N = 2^calculateOrderFromSampleRate(fs, 0.025) (MultibandBinarualLocalisation.h:43); power of two 64..8192 */
+    const double *mic_xyz;   /* [2][3] metres */
+    int nbins;               /* sub-bands, reference default 15; 1..27 */
+    int use_power_floor;     /* usePowerFloor (reference default true) */
+    int max_arrays;          /* independent module objects (streams) this context holds state for */
+} mca_hip_mb_config;
+int  mca_hip_mb_create(const mca_hip_mb_config *cfg, mca_hip_mb_ctx **out);
+void mca_hip_mb_destroy(mca_hip_mb_ctx *ctx);
+const char *mca_hip_mb_last_error(const mca_hip_mb_ctx *ctx);
+int  mca_hip_mb_reset(mca_hip_mb_ctx *ctx, void *stream);
+int  mca_hip_mb_num_steps(const mca_hip_mb_ctx *ctx);                 /* _numSteps = floor(pi/step)+1 = 37 (:63) */
+int  mca_hip_mb_get_filters(const mca_hip_mb_ctx *ctx, double *out);  /* [nbins][N/2+1] filter magnitudes */
+/* n_frames frames of n_arrays independent 2-channel streams; pcm_dev as in mca_hip_mask_frames_dev.
+ * Per frame (all [arrays][F]): doa_rad = _currentDOA[0] after the frame (:239/:254), prob = _prob[0] (:233/:255),
+ * voiced (may be NULL) = 1 where setDOA fires (:225,:248), power (may be NULL) = the value handed to setDOA.
+ * Optional: band_idx [arrays][F][nbins] first-max delay index per band (:184), energy_in_doa [arrays][F][D]
+ * (_energyInDOA :190), band_corr [arrays][F][nbins][D] smoothed band correlations (:180-183). */
+int mca_hip_mb_frames_dev(mca_hip_mb_ctx *ctx, const float *pcm_dev, long long array_stride, long long ch_stride,
+                          int n_arrays, int n_frames, float *doa_rad_dev, float *prob_dev, unsigned char *voiced_dev,
+                          float *power_dev, int *band_idx_dev, float *energy_in_doa_dev, float *band_corr_dev, void *stream);
+int mca_hip_mb_frames_host(mca_hip_mb_ctx *ctx, const float *pcm, int n_arrays, int n_frames, float *doa_rad, float *prob,
+                           unsigned char *voiced, float *power, int *band_idx, float *energy_in_doa, float *band_corr);
+
 /* ---- measurement ------------------------------------------------------------ */
 typedef enum {
     MCA_HIP_K_STFT_PHAT = 0,   /* STFT + PHAT whitening + pair-group sums */

@@ -49,6 +49,19 @@ class MaskConfig(C.Structure):
     ]
 
 
+class MbConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int),
+        ("device", C.c_int),
+        ("sample_rate", C.c_int),
+        ("fft_size", C.c_int),
+        ("mic_xyz", c_dp),
+        ("nbins", C.c_int),
+        ("use_power_floor", C.c_int),
+        ("max_arrays", C.c_int),
+    ]
+
+
 # every symbol include/mcarray_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mca_hip_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
@@ -90,6 +103,17 @@ SYMBOLS = [
      [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mca_hip_mask_frames_host", C.c_int, [C.c_void_p, c_fp, C.c_int, C.c_int, c_fp, c_ip]),
     ("mca_hip_mask_process_frame", C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, c_ip]),
+    ("mca_hip_mb_create", C.c_int, [C.POINTER(MbConfig), C.POINTER(C.c_void_p)]),
+    ("mca_hip_mb_destroy", None, [C.c_void_p]),
+    ("mca_hip_mb_last_error", C.c_char_p, [C.c_void_p]),
+    ("mca_hip_mb_reset", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mca_hip_mb_num_steps", C.c_int, [C.c_void_p]),
+    ("mca_hip_mb_get_filters", C.c_int, [C.c_void_p, c_dp]),
+    ("mca_hip_mb_frames_dev", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mca_hip_mb_frames_host", C.c_int,
+     [C.c_void_p, c_fp, C.c_int, C.c_int, c_fp, c_fp, C.c_void_p, c_fp, c_ip, c_fp, c_fp]),
     ("mca_hip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("mca_hip_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
     ("mca_hip_reset_timing", C.c_int, [C.c_void_p]),

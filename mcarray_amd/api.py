@@ -288,6 +288,90 @@ class FreqGCCBinauralLocalisation:
         return self.ctx.gcc2_frames_host(pcm, want_corr)
 
 
+class MultibandBinarualLocalisation:
+    """mca::MultibandBinarualLocalisation(int sampleRate, ArrayDescription, int nbins = 15, bool usePowerFloor = 1)
+    (MultibandBinarualLocalisation.h:38): per sub-band GCC-PHAT + energy-weighted DOA histogram over whole buffers."""
+
+    FRAME_SECONDS = 0.025        # _frameRate (MultibandBinarualLocalisation.h:43)
+
+    def __init__(self, sample_rate, mic_positions, nbins=15, use_power_floor=True, fft_size=None, max_arrays=1, device=0):
+        self._lib = _lib.load()
+        xyz = _xyz(mic_positions)
+        if len(xyz) != 2:
+            raise MCArrayHipError("MultibandBinarualLocalisation needs exactly 2 microphones")
+        if fft_size is None:
+            fft_size = 1 << calculate_order_from_sample_rate(sample_rate, self.FRAME_SECONDS)
+        cfg = _lib.MbConfig()
+        cfg.struct_size = C.sizeof(_lib.MbConfig)
+        cfg.device = device
+        cfg.sample_rate = sample_rate
+        cfg.fft_size = fft_size
+        cfg.mic_xyz = xyz.ctypes.data_as(_lib.c_dp)
+        cfg.nbins = nbins
+        cfg.use_power_floor = int(use_power_floor)
+        cfg.max_arrays = max_arrays
+        h = C.c_void_p()
+        rc = self._lib.mca_hip_mb_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise MCArrayHipError("mca_hip_mb_create failed (%d): %s" % (rc, self._lib.mca_hip_mb_last_error(None).decode()))
+        self.h = h
+        self.N, self.hop, self.nbins = fft_size, fft_size // 2, nbins
+        self.D = self._lib.mca_hip_mb_num_steps(h)
+        self.callback = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.mca_hip_mb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MCArrayHipError("libmcarray_hip error %d: %s" % (rc, self._lib.mca_hip_mb_last_error(self.h).decode()))
+
+    def set_callback(self, cb):
+        self.callback = cb
+
+    def reset(self):
+        self._check(self._lib.mca_hip_mb_reset(self.h, None))
+
+    def filters(self):
+        out = np.empty((self.nbins, self.N // 2 + 1))
+        self._check(self._lib.mca_hip_mb_get_filters(self.h, out.ctypes.data_as(_lib.c_dp)))
+        return out
+
+    def process(self, pcm, want_bands=False):
+        """pcm float32 [A][2][(F+1)*hop] -> dict(doa [A][F] rad, prob, voiced, power[, band_idx [A][F][nbins],
+        energy_in_doa [A][F][D], band_corr [A][F][nbins][D]]); the callback fires per voiced frame of array 0
+        as setDOA(degrees, prob, power, 1) (MultibandBinarualLocalisation.cpp:248)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if pcm.ndim == 2:
+            pcm = pcm[None]
+        A, ch, L = pcm.shape
+        F = L // self.hop - 1
+        if ch != 2 or F < 1 or (F + 1) * self.hop != L:
+            raise MCArrayHipError("pcm must be [A][2][(F+1)*hop]")
+        doa = np.empty((A, F), dtype=np.float32)
+        prob = np.empty((A, F), dtype=np.float32)
+        voiced = np.empty((A, F), dtype=np.uint8)
+        power = np.empty((A, F), dtype=np.float32)
+        bi = np.empty((A, F, self.nbins), dtype=np.int32) if want_bands else None
+        eid = np.empty((A, F, self.D), dtype=np.float32) if want_bands else None
+        bc = np.empty((A, F, self.nbins, self.D), dtype=np.float32) if want_bands else None
+        fp = _lib.c_fp
+        self._check(self._lib.mca_hip_mb_frames_host(
+            self.h, pcm.ctypes.data_as(fp), A, F, doa.ctypes.data_as(fp), prob.ctypes.data_as(fp),
+            voiced.ctypes.data_as(C.c_void_p), power.ctypes.data_as(fp), bi.ctypes.data_as(_lib.c_ip) if want_bands else None,
+            eid.ctypes.data_as(fp) if want_bands else None, bc.ctypes.data_as(fp) if want_bands else None))
+        if self.callback is not None:
+            for t in range(F):
+                if voiced[0, t]:
+                    self.callback(np.array([np.rad2deg(float(doa[0, t]))]), np.array([prob[0, t]]), float(power[0, t]), 1)
+        return dict(doa=doa, prob=prob, voiced=voiced, power=power, band_idx=bi, energy_in_doa=eid, band_corr=bc)
+
+
 FACTOR, RELATIVE, FULL, NOISY, NOTHING = 0, 1, 3, 4, 5      # BinauralMasking::MaskingMethod (ArrayModules.h:81)
 BOTH, SPATIAL, TEMPORAL = 0, 1, 2                           # BinauralMasking::MaskingAlg (ArrayModules.h:89)
 

@@ -31,5 +31,8 @@ template <typename T> __global__ void k_frame_power(const C2<T> *X, int M, int K
 __global__ void k_gcc2_scan(Gcc2ScanArgs p);
 __global__ void k_mask_stream(MaskArgs p);
 __global__ void k_mask_frame(MaskFrameArgs p);
+__global__ void k_mb_analyse(MbAnalyseArgs p);
+__global__ void k_mb_scan(MbScanArgs p);
+__global__ void k_mb_summary(MbSummaryArgs p);
 
 }  // namespace mca

@@ -1,0 +1,172 @@
+// kernels_multiband.hip -- MultibandBinarualLocalisation (src/mcarray/MultibandBinarualLocalisation.cpp:145-258)
+// for batches of frames (gfx950).
+//
+//   k_mb_analyse   PCM (2 ch) -> windowed FFT -> PHAT cross-spectrum -> per band b: un-smoothed GCC-PHAT at the D
+//                  steering delays restricted to the band's bins (processOneSubband :175-177: the band filter only
+//                  selects bins, PHAT discards its magnitude), band energies (:188), frame powers for the gate
+//   k_mb_scan      per (band, delay): corr = (1-m) corr + m prev (:180-183), first-max per band (:184), the
+//                  energy-weighted DOA histogram (:190) and its argmax / share (:227-233)
+//   k_mb_summary   the power gate (:125-143, :214-225) and _currentDOA / _prob (:237-255), in frame order
+#include "fft_block.h"
+#include "mca_internal.h"
+
+namespace mca {
+
+constexpr int MB_WARM = 64;     // frames of recursion warm-up per scan chunk (0.4^64 = 3e-26)
+
+// grid (frames, arrays), 256 threads.  LDS: xs [2][H+1] float2, G [K] float2, pw [K] float, red [8] float
+__global__ __launch_bounds__(256) void k_mb_analyse(MbAnalyseArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int logH = p.logH, H = 1 << logH, zs = H + 1, K = H + 1;
+    float2 *xs = reinterpret_cast<float2 *>(smem_raw);
+    float2 *G = xs + 2 * zs;
+    float *pw = reinterpret_cast<float *>(G + K);
+    float *red = pw + K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.y, f = blockIdx.x;
+    const long long row = (long long)a * p.n_frames + f;
+    const float *base = p.pcm + (long long)a * p.array_stride;
+
+    load_frames(xs, zs, 2, logH, base, p.ch_stride, (long long)f, p.window, tid, 256);
+    block_fft_dit(xs, zs, 2, logH, p.tw, p.N, tid, 256);
+    split_forward(xs, zs, 2, logH, p.tw, tid, 256);
+
+    // per-bin power and PHAT cross-spectrum G = L conj(R) / |L conj(R)|
+    const int Kh = K / 2;                                      // bins FFTPower sees when handed (N+2)/2 doubles (:216)
+    float full = 0.f, half = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float2 l = xs[k], r = xs[zs + k];
+        const float pk = l.x * l.x + l.y * l.y + r.x * r.x + r.y * r.y;
+        pw[k] = pk;
+        full += (k == 0 || k == K - 1) ? pk : 2.f * pk;
+        if (k < Kh) half += (k == 0 || k == Kh - 1) ? pk : 2.f * pk;
+        G[k] = whiten_g(cmulc(l, r));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { full += __shfl_down(full, off); half += __shfl_down(half, off); }
+    if (lane == 0) { red[wave] = full; red[4 + wave] = half; }
+    __syncthreads();
+    if (tid == 0) {
+        const float n2 = (float)p.N * (float)p.N, h2 = (float)(K - 2) * (float)(K - 2);
+        p.p_full[row] = (red[0] + red[1] + red[2] + red[3]) / n2 * 0.5f;     // mean over the 2 channels
+        p.p_half[row] = (red[4] + red[5] + red[6] + red[7]) / h2 * 0.5f;
+    }
+    // band energies: FFTPower of the sub-band frames = (1/N^2) sum_k w_k H_b[k]^2 (|L|^2 + |R|^2) / 2
+    for (int b = wave; b < p.nbins; b += 4) {
+        float s = 0.f;
+        for (int k = p.lo[b] + lane; k <= p.hi[b]; k += 64) {
+            const float h = p.coef[(long long)b * K + k];
+            const float w = (k == 0 || k == K - 1) ? 1.f : 2.f;
+            s += w * h * h * pw[k];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) p.band_energy[row * p.nbins + b] = s / ((float)p.N * (float)p.N) * 0.5f;
+    }
+    // band correlations at the steering delays
+    const int BD = p.nbins * p.D;
+    for (int e = tid; e < BD; e += 256) {
+        const int b = e / p.D, d = e - b * p.D;
+        float s = 0.f;
+        for (int k = p.lo[b]; k <= p.hi[b]; ++k) {
+            const float2 g = G[k], t = p.T[(long long)k * p.D + d];
+            s += g.x * t.x - g.y * t.y;
+        }
+        p.raw[row * BD + e] = s;
+    }
+}
+
+// grid (chunks, arrays), blockDim = roundup(nbins * D, 64).  LDS: sC [chunk][BD] float, sE [chunk][D] float, sIdx [chunk][nbins] int
+__global__ __launch_bounds__(1024) void k_mb_scan(MbScanArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int D = p.D, nb = p.nbins, BD = nb * D;
+    float *sC = reinterpret_cast<float *>(smem_raw);
+    float *sE = sC + p.chunk * BD;
+    int *sIdx = reinterpret_cast<int *>(sE + p.chunk * D);
+    const int e = threadIdx.x, lane = e & 63, wave = e >> 6, nwaves = blockDim.x >> 6;
+    const int a = blockIdx.y;
+    const int t_start = blockIdx.x * p.chunk, t_end = min(t_start + p.chunk, p.n_frames), nt = t_end - t_start;
+    const int warm_start = max(0, t_start - MB_WARM);
+    const float *raw = p.raw + (long long)a * p.n_frames * BD;
+    if (e < BD) {
+        float c = warm_start == 0 ? p.corr_in[(long long)a * BD + e] : 0.f;
+        for (int t = warm_start; t < t_end; ++t) {
+            c = p.one_minus_mem * raw[(long long)t * BD + e] + p.mem * c;                 // :180-183
+            if (t >= t_start) {
+                sC[(t - t_start) * BD + e] = c;
+                if (p.band_corr) p.band_corr[((long long)a * p.n_frames + t) * BD + e] = c;
+            }
+        }
+        if (t_end == p.n_frames) p.corr_out[(long long)a * BD + e] = c;
+    }
+    __syncthreads();
+    for (int q = wave; q < nt * nb; q += nwaves) {                                        // maxidx per (frame, band) :184
+        const float *cr = sC + q * D;                                                     // q = tl * nb + b
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int dd = lane; dd < D; dd += 64) { const float v = cr[dd]; if (v > bv) { bv = v; bi = dd; } }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off); const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) sIdx[q] = bi < D ? bi : 0;        // all-NaN row: stay in range
+    }
+    __syncthreads();
+    if (e < nt) {
+        const int t = t_start + e;
+        const long long row = (long long)a * p.n_frames + t;
+        float *E = sE + e * D;
+        for (int d = 0; d < D; ++d) E[d] = 0.f;                                           // processSetup :147
+        for (int b = 0; b < nb; ++b) {
+            const int idx = sIdx[e * nb + b];
+            E[idx] += p.band_energy[row * nb + b];                                        // :190
+            if (p.band_idx) p.band_idx[row * nb + b] = idx;
+        }
+        float sum = 0.f, mx = E[0]; int idx = 0;
+        for (int d = 0; d < D; ++d) { sum += E[d]; if (E[d] > mx) { mx = E[d]; idx = d; } }   // :227-228
+        p.hist_idx[row] = idx;
+        p.hist_prob[row] = sum != 0.f ? E[idx] / sum : 0.f;                               // :230-233
+        if (p.energy_in_doa) for (int d = 0; d < D; ++d) p.energy_in_doa[row * D + d] = E[d];
+    }
+}
+
+// grid (arrays), 64 threads; thread 0 walks the frames in order (the gate's floor estimation and the
+// hold-over of _currentDOA on gated-out frames are sequential by nature and a few flops per frame)
+__global__ __launch_bounds__(64) void k_mb_summary(MbSummaryArgs p)
+{
+    if (threadIdx.x != 0) return;
+    const int a = blockIdx.x;
+    double *g = p.gate + (long long)a * 4;
+    double acc = g[0], consumed = g[1], floor_db = g[2];
+    bool est = g[3] != 0.0;
+    float cur = p.cur[a * 2], pr = p.cur[a * 2 + 1];
+    const double per_frame = (double)(2 * p.K - 2);
+    for (int t = 0; t < p.n_frames; ++t) {
+        const long long row = (long long)a * p.n_frames + t;
+        double power, thr;
+        if (!est) {                                                                       // setPowerFloor :125-143
+            acc += (double)p.p_half[row] * per_frame;
+            consumed += per_frame;
+            if (consumed >= (double)p.needed_samples) {
+                est = true;
+                floor_db = 10.0 * log10(acc / consumed) + (double)p.margin_db;
+                acc = floor_db;
+            }
+            power = acc; thr = acc;                                                       // returns _powerFloor itself
+        } else {
+            power = (double)p.p_full[row]; thr = floor_db;                                // :221 (linear vs the dB floor)
+        }
+        const bool fire = power > thr || !p.use_floor;                                    // :225
+        if (fire) { cur = p.grid[p.hist_idx[row]]; pr = p.hist_prob[row]; }               // :237-239, _doaMemoryFactor = 0
+        else pr = -100000.f;                                                              // :254-255, _doaMemoryFactorSilence = 1
+        p.doa_rad[row] = cur; p.prob[row] = pr;
+        if (p.voiced) p.voiced[row] = fire ? 1 : 0;
+        if (p.power) p.power[row] = (float)power;
+    }
+    g[0] = acc; g[1] = consumed; g[2] = floor_db; g[3] = est ? 1.0 : 0.0;
+    p.cur[a * 2] = cur; p.cur[a * 2 + 1] = pr;
+}
+
+}  // namespace mca

@@ -154,4 +154,39 @@ struct MaskFrameArgs {
     int *decisions;
 };
 
+// ---- MultibandBinarualLocalisation (kernels_multiband.hip) ----
+struct MbAnalyseArgs {
+    const float *pcm;
+    long long array_stride, ch_stride;
+    int n_frames, N, logH, nbins, D;
+    const float *window;
+    const float2 *tw;         // [N/2]
+    const float *coef;        // [nbins][K] filter magnitudes (0 outside the support)
+    const int *lo, *hi;       // [nbins] support of band b (bins with H_b > 0, inclusive), lo > hi if empty
+    const float2 *T;          // [K][D] exp(+j 2 pi k tau_d / N)
+    float *raw;               // [arrays][n_frames][nbins * D] un-smoothed band correlations
+    float *band_energy;       // [arrays][n_frames][nbins] FFTPower of the sub-band frames
+    float *p_full, *p_half;   // [arrays][n_frames] FFTPower(frames, N+2) and FFTPower(frames, (N+2)/2)
+};
+
+struct MbScanArgs {
+    const float *raw, *band_energy;
+    int n_frames, nbins, D, chunk;
+    float mem, one_minus_mem;               // _corrMemoryFactor 0.4f and 1 - 0.4f (float arithmetic)
+    const float *corr_in; float *corr_out;  // [arrays][nbins * D] _prevCorrelationsReal
+    int *hist_idx; float *hist_prob;        // [arrays][n_frames] argmax of _energyInDOA and its share
+    int *band_idx; float *energy_in_doa; float *band_corr;   // optional outputs
+};
+
+struct MbSummaryArgs {
+    const float *p_full, *p_half;
+    const int *hist_idx; const float *hist_prob;
+    int n_frames, K, needed_samples, use_floor;
+    float margin_db;
+    const float *grid;        // [D]
+    double *gate;             // [arrays][4] {_powerFloor, _samplesConsumedForNoise, floor dB, _noiseEstimated}
+    float *cur;               // [arrays][2] {_currentDOA[0], _prob[0]}
+    float *doa_rad, *prob, *power; unsigned char *voiced;   // [arrays][n_frames]
+};
+
 }  // namespace mca

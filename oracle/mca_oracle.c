@@ -929,3 +929,156 @@ void mca_or_masking_stream(mca_or_masking *m, const double *pl, const double *pr
     }
     free(win); free(L); free(R); free(y); free(tl);
 }
+
+/* ======================================================================= */
+/* MultibandBinarualLocalisation -- src/mcarray/MultibandBinarualLocalisation.cpp */
+/* ======================================================================= */
+
+/* [BUILD-DEFINES] stand-in for the LINEAR filter bank of dsp::SubBandSTFTAnalysis: nbins unit-peak triangles,
+ * edges linearly spaced between fmin and fmax, sampled on the K = N/2+1 bin frequencies. */
+void mca_or_linear_filterbank(int N, int nbins, int fs, double fmin, double fmax, double *coefs)
+{
+    const int K = N / 2 + 1;
+    for (int b = 0; b < nbins; ++b) {
+        double f0 = fmin + (fmax - fmin) * (double)b / (double)(nbins + 1);
+        double f1 = fmin + (fmax - fmin) * (double)(b + 1) / (double)(nbins + 1);
+        double f2 = fmin + (fmax - fmin) * (double)(b + 2) / (double)(nbins + 1);
+        for (int k = 0; k < K; ++k) {
+            double f = (double)k * (double)fs / (double)N, h = 0;
+            if (f > f0 && f <= f1) h = (f - f0) / (f1 - f0);
+            else if (f > f1 && f < f2) h = (f2 - f) / (f2 - f1);
+            coefs[(size_t)b * K + k] = h;
+        }
+    }
+}
+
+struct mca_or_multiband {
+    int fs, ccs_len, K, N, D, nbins, use_floor;
+    float doaStep;
+    double micDist;
+    double *delays;            /* _samplesDelay[D] */
+    double *coefs;             /* [nbins][K] */
+    double *prev;              /* _prevCorrelationsReal [nbins][D] */
+    double *bandL, *bandR;     /* sub-band frames */
+    double curDOA, prob;       /* _currentDOA[0], _prob[0] */
+    double powerFloor; int noiseEstimated, samplesConsumed;
+};
+
+/* the class's own doaIdx2angle (MultibandBinarualLocalisation.h:96-100): float result */
+static float mb_idx2angle(int idx, float step) { return (float)((double)((float)idx * step) - M_PI_2); }
+
+mca_or_multiband *mca_or_multiband_create(int fs, const double *xyz, int M, int ccs_len, int nbins, int use_floor)
+{
+    (void)M;
+    mca_or_multiband *m = (mca_or_multiband *)calloc(1, sizeof(*m));
+    m->fs = fs; m->ccs_len = ccs_len; m->K = ccs_len / 2; m->N = ccs_len - 2; m->nbins = nbins; m->use_floor = use_floor;
+    m->micDist = mca_or_distance(xyz, 0, 1);                                   /* :61 */
+    m->doaStep = (float)(5 * M_PI / 180);                                      /* :62 */
+    m->D = (int)(floor(M_PI / (double)m->doaStep) + 1);                        /* :63 */
+    /* maxFreqForSpatialAliasing takes and returns float (microhponeArrayHelpers.cpp:85-89) */
+    float fmax = (float)(mca_or_speed_of_sound() / (double)(2 * (float)m->micDist));
+    m->coefs = (double *)malloc(sizeof(double) * (size_t)nbins * (size_t)m->K);
+    mca_or_linear_filterbank(m->N, nbins, fs, 100.0, (double)fmax, m->coefs);  /* :54-60 */
+    m->delays = (double *)malloc(sizeof(double) * (size_t)m->D);
+    for (int i = 0; i < m->D; ++i)                                             /* :101-104 */
+        m->delays[i] = (double)mca_or_doa_to_delay_samples(mb_idx2angle(i, m->doaStep), (float)m->micDist, fs);
+    m->prev = (double *)calloc((size_t)nbins * (size_t)m->D, sizeof(double)); /* :106-110 */
+    m->bandL = (double *)malloc(sizeof(double) * (size_t)ccs_len);
+    m->bandR = (double *)malloc(sizeof(double) * (size_t)ccs_len);
+    m->curDOA = 0; m->prob = -1;                                               /* :81-82 */
+    return m;
+}
+
+void mca_or_multiband_destroy(mca_or_multiband *m)
+{
+    if (!m) return;
+    free(m->coefs); free(m->delays); free(m->prev); free(m->bandL); free(m->bandR); free(m);
+}
+
+int mca_or_multiband_num_steps(const mca_or_multiband *m) { return m->D; }
+const double *mca_or_multiband_filters(const mca_or_multiband *m) { return m->coefs; }
+
+/* setPowerFloor :125-143 -- called with analysisLength/2 (:216), so FFTPower sees the first half of the CCS
+ * buffer and the sample count per frame is 2*(analysisLength/2) - 2 */
+static double mb_set_power_floor(mca_or_multiband *m, const double *const *frames, int length)
+{
+    const double durationToEstimatePowerFloor = 3;       /* SoundLocalisationImpl.h:77 */
+    const double noiseMarginDB = 3.0;                    /* MultibandBinarualLocalisation.h:47 */
+    int neededSamples = (int)(durationToEstimatePowerFloor * m->fs);
+    double power = mca_or_fft_power(frames, 2, length) * (2 * length - 2);
+    m->powerFloor += power;
+    m->samplesConsumed += (2 * length - 2);
+    if (m->samplesConsumed >= neededSamples) {
+        m->noiseEstimated = 1;
+        m->powerFloor /= m->samplesConsumed;
+        m->powerFloor = 10 * log10(m->powerFloor) + noiseMarginDB;
+    }
+    return m->powerFloor;
+}
+
+int mca_or_multiband_process(mca_or_multiband *m, const double *left, const double *right, int *band_idx,
+                             double *band_energy, double *band_corr, double *energy_in_doa, double *doa_rad,
+                             double *prob, double *power_out)
+{
+    const int D = m->D, K = m->K;
+    const float corrMem = 0.4f;                                                /* _corrMemoryFactor .h:46 */
+    const float doaMem = 0.f, doaMemSilence = 1.f;                             /* .h:44-45 */
+    double *E = (double *)calloc((size_t)D, sizeof(double));                   /* processSetup :147 */
+    for (int b = 0; b < m->nbins; ++b) {
+        const double *h = m->coefs + (size_t)b * K;
+        for (int k = 0; k < K; ++k) {
+            m->bandL[2 * k] = left[2 * k] * h[k]; m->bandL[2 * k + 1] = left[2 * k + 1] * h[k];
+            m->bandR[2 * k] = right[2 * k] * h[k]; m->bandR[2 * k + 1] = right[2 * k + 1] * h[k];
+        }
+        /* calculateCorrelationsForTauVector(left, right, out, K, delays, D, ONESIDEDFFT) :175-176 [INFERRED, A.3] */
+        double *prev = m->prev + (size_t)b * D;
+        int idx = 0; double mx = 0;
+        for (int d = 0; d < D; ++d) {
+            double re = 0;
+            for (int k = 0; k < K; ++k) {
+                double gr = m->bandL[2 * k] * m->bandR[2 * k] + m->bandL[2 * k + 1] * m->bandR[2 * k + 1];
+                double gi = m->bandL[2 * k + 1] * m->bandR[2 * k] - m->bandL[2 * k] * m->bandR[2 * k + 1];
+                double mag = sqrt(gr * gr + gi * gi);
+                if (mag <= 1e-30) continue;
+                double ph = 2.0 * M_PI * (double)k * m->delays[d] / (double)m->N;
+                re += (gr * cos(ph) - gi * sin(ph)) / mag;
+            }
+            double c = re * (double)(1 - corrMem);                             /* :180 (float arithmetic on the constant) */
+            prev[d] *= (double)corrMem;                                        /* :181 */
+            c += prev[d];                                                      /* :182 */
+            prev[d] = c;                                                       /* :183 */
+            if (band_corr) band_corr[(size_t)b * D + d] = c;
+            if (d == 0 || c > mx) { mx = c; idx = d; }                         /* maxidx :184, first maximum */
+        }
+        const double *fr[2] = {m->bandL, m->bandR};
+        double e = mca_or_fft_power(fr, 2, m->ccs_len);                        /* :188 */
+        E[idx] += e;                                                           /* :190 */
+        if (band_idx) band_idx[b] = idx;
+        if (band_energy) band_energy[b] = e;
+    }
+    /* processSumamry :198-258 */
+    const double *frames[2] = {left, right};
+    double power;
+    if (!m->noiseEstimated) power = mb_set_power_floor(m, frames, m->ccs_len / 2);   /* :214-217 */
+    else power = mca_or_fft_power(frames, 2, m->ccs_len);                     /* :221 (linear, compared with a dB floor) */
+    int fired = 0;
+    if (power > m->powerFloor || !m->use_floor) {                              /* :225 */
+        double sum = 0, mx = 0; int idx = 0;
+        for (int d = 0; d < D; ++d) sum += E[d];                               /* :227 */
+        for (int d = 0; d < D; ++d) if (d == 0 || E[d] > mx) { mx = E[d]; idx = d; }   /* :228 */
+        m->prob = sum;
+        if (m->prob != 0) m->prob = E[idx] / m->prob;                          /* :230-233 */
+        double DOA = (double)mb_idx2angle(idx, m->doaStep);                    /* :237 */
+        m->curDOA = (double)doaMem * m->curDOA + (double)(1 - doaMem) * DOA;   /* :239 */
+        fired = 1;
+    } else {
+        m->curDOA = m->curDOA * (double)doaMemSilence + (double)(1 - doaMemSilence) * 0;   /* :254 */
+        m->prob = -100000;                                                     /* :255 */
+    }
+    if (energy_in_doa) memcpy(energy_in_doa, E, sizeof(double) * (size_t)D);
+    if (doa_rad) *doa_rad = m->curDOA;
+    if (prob) *prob = m->prob;
+    if (power_out) *power_out = power;
+    free(E);
+    return fired;
+}

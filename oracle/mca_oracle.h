@@ -163,6 +163,26 @@ void mca_or_masking_stream(mca_or_masking *m, const double *pcm_l, const double 
 void mca_or_mel_filterbank(int N, int nbins, int fs, double fmin, double fmax,
                            double *coefs /* nbins*K */, double *center_cyc /* nbins */);
 
+/* ---- MultibandBinarualLocalisation: src/mcarray/MultibandBinarualLocalisation.cpp:52-258 ----
+ * The sub-band splitting is DSPONE's dsp::SubBandSTFTAnalysis(nbins, fs, order, 2, 100 Hz, fmax, LINEAR)
+ * (ctor call :54-60), absent here.  [BUILD-DEFINES]: nbins unit-peak triangular filters with linearly spaced
+ * edges between 100 Hz and maxFreqForSpatialAliasing(d) = c / (2 d) (microhponeArrayHelpers.cpp:85-89), sampled
+ * on the FFT bins; sub-band b of a frame = the channel spectra times filter b, handed to processOneSubband
+ * as full-length CCS; processSetup before and processSumamry after the bands of every frame.            */
+typedef struct mca_or_multiband mca_or_multiband;
+void mca_or_linear_filterbank(int N, int nbins, int fs, double fmin, double fmax, double *coefs /* nbins*K */);
+mca_or_multiband *mca_or_multiband_create(int fs, const double *xyz, int M, int fft_ccs_length, int nbins,
+                                          int use_power_floor);               /* :52-123 */
+void mca_or_multiband_destroy(mca_or_multiband *m);
+int  mca_or_multiband_num_steps(const mca_or_multiband *m);                   /* floor(pi/step)+1 :62 */
+const double *mca_or_multiband_filters(const mca_or_multiband *m);            /* nbins*K */
+/* one frame: processSetup :145-151, processOneSubband per band :164-196, processSumamry :198-258.
+ * Returns 1 if the callback would fire.  band_idx[nbins] first-max index per band, band_energy[nbins],
+ * energy_in_doa[D], *doa_rad = _currentDOA, *prob = _prob[0], *power as handed to setDOA.  Any may be NULL. */
+int  mca_or_multiband_process(mca_or_multiband *m, const double *left, const double *right,
+                              int *band_idx, double *band_energy, double *band_corr /* nbins*D */,
+                              double *energy_in_doa, double *doa_rad, double *prob, double *power);
+
 #ifdef __cplusplus
 }
 #endif

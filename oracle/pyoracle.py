@@ -95,6 +95,15 @@ def lib():
         L.mca_or_freqgcc_process.restype = C.c_int
         L.mca_or_freqgcc_process.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp]
         L.mca_or_freqgcc_set_probability.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int]
+        L.mca_or_multiband_create.restype = C.c_void_p
+        L.mca_or_multiband_create.argtypes = [C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mca_or_multiband_destroy.argtypes = [C.c_void_p]
+        L.mca_or_multiband_num_steps.restype = C.c_int
+        L.mca_or_multiband_num_steps.argtypes = [C.c_void_p]
+        L.mca_or_multiband_filters.restype = c_dp
+        L.mca_or_multiband_filters.argtypes = [C.c_void_p]
+        L.mca_or_multiband_process.restype = C.c_int
+        L.mca_or_multiband_process.argtypes = [C.c_void_p, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
         L.mca_or_masking_create.restype = C.c_void_p
         L.mca_or_masking_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_int, C.c_int]
         L.mca_or_masking_destroy.argtypes = [C.c_void_p]
@@ -355,6 +364,40 @@ class FreqGCC:
         probs = np.empty(len(doas))
         lib().mca_or_freqgcc_set_probability(self.h, _dp(doas), _dp(probs), len(doas))
         return probs
+
+
+class Multiband:
+    """mca::MultibandBinarualLocalisation restatement (MultibandBinarualLocalisation.cpp:52-258)."""
+
+    def __init__(self, fs, xyz, ccs_len, nbins=15, use_power_floor=True):
+        self.xyz = _xyz(xyz)
+        self.nbins = nbins
+        self.K = ccs_len // 2
+        self.h = lib().mca_or_multiband_create(fs, _dp(self.xyz), len(self.xyz), ccs_len, nbins, int(use_power_floor))
+        self.D = lib().mca_or_multiband_num_steps(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mca_or_multiband_destroy(self.h)
+            self.h = None
+
+    def filters(self):
+        p = lib().mca_or_multiband_filters(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.nbins, self.K)).copy()
+
+    def process(self, left, right):
+        """one frame -> dict(fired, band_idx [nbins], band_energy [nbins], band_corr [nbins][D], energy_in_doa [D], doa, prob, power)"""
+        left = np.ascontiguousarray(left, dtype=np.float64)
+        right = np.ascontiguousarray(right, dtype=np.float64)
+        bi = np.zeros(self.nbins, dtype=np.int32)
+        be = np.zeros(self.nbins)
+        bc = np.zeros((self.nbins, self.D))
+        eid = np.zeros(self.D)
+        doa, prob, power = C.c_double(0), C.c_double(0), C.c_double(0)
+        v = lib().mca_or_multiband_process(self.h, _dp(left), _dp(right), _ip(bi), _dp(be), _dp(bc), _dp(eid),
+                                           C.byref(doa), C.byref(prob), C.byref(power))
+        return dict(fired=bool(v), band_idx=bi, band_energy=be, band_corr=bc, energy_in_doa=eid, doa=doa.value,
+                    prob=prob.value, power=power.value)
 
 
 FACTOR, RELATIVE, FULL, NOISY, NOTHING = 0, 1, 3, 4, 5

@@ -265,6 +265,29 @@ static void testBinauralModules()
     }
 }
 
+static void testMultibandBinauralLocalisation()
+{
+    // test/test_mcarray.cpp:344-383: 1 kHz sine, 48 kHz, 0.086 m pair, 25 bins, ungated, +-15 degrees
+    const int fs = 48000, tolerance = 15;
+    ArrayDescription mics = ArrayDescription::make_linear_array_description({0, 0.086});
+    for (int doa = -90; doa <= 90; doa += 30) {
+        MultibandBinarualLocalisation mbl(fs, mics, 25, false);
+        RangeCallback cb(doa - tolerance, doa + tolerance);
+        mbl.setCallback(&cb);
+        const int n = 20 * mbl.getFrameSize();
+        std::vector<std::vector<double> > ch(2, std::vector<double>(n));
+        for (int c = 0; c < 2; ++c) {
+            const double adv = (c ? 0.086 : 0.0) * std::sin(doa * M_PI / 180) / 346.1;
+            for (int t = 0; t < n; ++t) ch[c][t] = 5000.0 * std::cos(2 * M_PI * 1000.0 * (static_cast<double>(t) / fs + adv));
+        }
+        std::vector<double *> in = {ch[0].data(), ch[1].data()};
+        const int frames = mbl.process(in, n);
+        EXPECT(frames == 19 && cb.calls == 19);
+        EXPECT(cb.bad == 0);
+        std::printf("Multiband DOA %d: %d callbacks, %d out of range\n", doa, cb.calls, cb.bad);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const bool cpu_only = argc > 1 && std::string(argv[1]) == "--cpu";
@@ -277,6 +300,7 @@ int main(int argc, char **argv)
             testBeamformingSoundLocalisation(96000);
             testHookMatchesStream();
             testBinauralModules();
+            testMultibandBinauralLocalisation();
         } catch (const MCArrayException &e) {
             std::printf("FAIL: MCArrayException: %s\n", e.what());
             ++g_fail;

@@ -5,6 +5,7 @@ for the hot path.  CPU only.
 * SRP-PHAT DOA within +-7 deg on 1 kHz sines, 4-mic Reem-C, -80..80 deg -- :384-423
 * delay-and-sum inter-source attenuation >= 5.5 dB, 3 two-tone scenes    -- :631-800
 * masking band-power windows 70+-10 dB, 2+-0.5 dB -> 5+-1 dB              -- :892-1065
+* multiband 2-mic localiser within +-15 deg on 1 kHz sines, -90..90 deg   -- :344-383
 """
 import numpy as np
 import pytest
@@ -148,3 +149,20 @@ def test_temporal_masking_power_windows():
     after = diff(ol)
     assert abs(before - 2) < 0.5, before     # :1039-1045
     assert abs(after - 5) < 1.0, after       # :1061-1064
+
+
+@pytest.mark.parametrize("doa_deg", list(range(-90, 91, 10)))
+def test_multiband_sine_within_15_degrees(doa_deg):
+    """test/test_mcarray.cpp:344-383 (testMultibandBinauralLocalisation): 1 kHz sine, 48 kHz, 0.086 m pair,
+    25 sub-bands, usePowerFloor=false, every callback within +-15 degrees of the true angle."""
+    fs, N, F = 48000, 1024, 40
+    xs = [0.0, 0.086]
+    pcm = synth.sine_stream(xs, np.deg2rad(doa_deg), fs, (F + 1) * N // 2, 1000.0, 5000.0)
+    X = po.stft_frames(pcm, N)
+    m = po.Multiband(fs, xs, N + 2, 25, False)
+    assert m.D == 37
+    for t in range(F):
+        r = m.process(X[t, 0], X[t, 1])
+        assert r["fired"]
+        assert abs(np.rad2deg(r["doa"]) - doa_deg) <= 15.0, (t, np.rad2deg(r["doa"]))
+        assert 0.0 <= r["prob"] <= 1.0
