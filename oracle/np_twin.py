@@ -289,3 +289,76 @@ class Masking:
         if self.first < 2:
             self.noise = self.Q.copy()
         return oL, oR, dec
+
+
+# ---- multiband 2-mic localiser (MultibandBinarualLocalisation.cpp:52-258) -------------------
+def linear_filterbank(N, nbins, fs, fmin, fmax):
+    """[BUILD-DEFINES] LINEAR bank of dsp::SubBandSTFTAnalysis: unit-peak triangles, linearly spaced edges."""
+    K = N // 2 + 1
+    edges = fmin + (fmax - fmin) * np.arange(nbins + 2) / (nbins + 1)
+    f = np.arange(K) * fs / N
+    H = np.zeros((nbins, K))
+    for b in range(nbins):
+        f0, f1, f2 = edges[b], edges[b + 1], edges[b + 2]
+        up = (f > f0) & (f <= f1)
+        dn = (f > f1) & (f < f2)
+        H[b, up] = (f[up] - f0) / (f1 - f0)
+        H[b, dn] = (f2 - f[dn]) / (f2 - f1)
+    return H
+
+
+def fft_power(X, ccs_len):
+    """dsp::SignalPower::FFTPower over the first ccs_len doubles of each channel's CCS buffer (SURVEY A.8)."""
+    n, k = ccs_len - 2, ccs_len // 2
+    w = np.full(k, 2.0)
+    w[0] = w[-1] = 1.0
+    return float(np.mean([(w * np.abs(x[:k]) ** 2).sum() / n ** 2 for x in X]))
+
+
+def multiband_stream(fs, N, xs, pcm, nbins=15, use_power_floor=True):
+    """whole stream; returns dict(fired, doa, prob, power, band_idx, band_corr, energy_in_doa) per frame."""
+    xyz = xyz_of(xs)
+    dist = distance(xyz, 0, 1)
+    step = f32(5 * np.pi / 180)
+    D = int(np.floor(np.pi / float(step)) + 1)
+    ang = np.array([f32(float(f32(i) * step) - np.pi / 2) for i in range(D)], dtype=np.float32)
+    tau = np.array([float(f32(f32((float(f32(dist)) * np.sin(float(a))) / 346.1) * f32(fs))) for a in ang])
+    fmax = float(f32(346.1 / float(f32(2) * f32(dist))))
+    H = linear_filterbank(N, nbins, fs, 100.0, fmax)
+    X = stft_frames(np.asarray(pcm, dtype=np.float64), N)
+    F, K = X.shape[0], N // 2 + 1
+    mem, omm = float(f32(0.4)), float(f32(1) - f32(0.4))
+    prev = np.zeros((nbins, D))
+    acc, consumed, est, cur, pr = 0.0, 0, False, 0.0, -1.0
+    out = dict(fired=np.zeros(F, bool), doa=np.zeros(F), prob=np.zeros(F), power=np.zeros(F),
+               band_idx=np.zeros((F, nbins), np.int32), band_corr=np.zeros((F, nbins, D)), energy_in_doa=np.zeros((F, D)))
+    for t in range(F):
+        E = np.zeros(D)
+        for b in range(nbins):
+            L, R = X[t, 0] * H[b], X[t, 1] * H[b]
+            c = omm * gcc_phat(L, R, tau, K).real + mem * prev[b]
+            prev[b] = c
+            idx = int(np.argmax(c))
+            E[idx] += fft_power([L, R], N + 2)
+            out["band_idx"][t, b] = idx
+            out["band_corr"][t, b] = c
+        if not est:
+            half = (N + 2) // 2
+            acc += fft_power([X[t, 0], X[t, 1]], half) * (2 * half - 2)
+            consumed += 2 * half - 2
+            if consumed >= int(3 * fs):
+                est = True
+                acc = 10 * np.log10(acc / consumed) + 3.0
+            power = acc
+        else:
+            power = fft_power([X[t, 0], X[t, 1]], N + 2)
+        if power > acc or not use_power_floor:
+            s = E.sum()
+            i = int(np.argmax(E))
+            pr = E[i] / s if s != 0 else 0.0
+            cur = float(ang[i])
+            out["fired"][t] = True
+        else:
+            pr = -100000.0
+        out["doa"][t], out["prob"][t], out["power"][t], out["energy_in_doa"][t] = cur, pr, power, E
+    return out

@@ -83,6 +83,16 @@ def freqgcc_case(name, fs, N, d, step_deg, theta_deg, F, seed):
     print(name, "argmax", idxs, "expected angle", [float(np.rad2deg(tw.doaidx2angle(i, step))) for i in idxs[:2]])
 
 
+def multiband_case(name, fs, N, d, nbins, theta_deg, F, seed):
+    xs = [0.0, d]
+    pcm = synth.noise_source_stream(xs, np.deg2rad(theta_deg), fs, (F + 1) * N // 2, seed)
+    r = tw.multiband_stream(fs, N, xs, pcm.astype(np.float64), nbins, False)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), xs=np.asarray(xs), fs=fs, N=N, nbins=nbins, theta_deg=theta_deg,
+                        pcm=pcm, doa=r["doa"], prob=r["prob"], power=r["power"], band_idx=r["band_idx"],
+                        band_corr=r["band_corr"], energy_in_doa=r["energy_in_doa"])
+    print(name, "doa", np.rad2deg(r["doa"]))
+
+
 if __name__ == "__main__":
     ssl_case("ssl_reemc_d37", synth.REEM_C, 48000, 1024, 5.0, 20.0, 8, 11)
     ssl_case("ssl_ula8_d361", synth.ULA8, 48000, 1024, 0.5, -33.0, 6, 12)
@@ -92,3 +102,4 @@ if __name__ == "__main__":
     masking_case("mask_factor_temporal", 16000, 1024, 0.086, 500.0, 5000.0, 0, 2, 7, 23)
     masking_case("mask_noisy_spatial", 16000, 1024, 0.086, 500.0, 5000.0, 4, 1, 7, 24, delay=1, nlev=0.003)
     freqgcc_case("freqgcc_16k_d61", 16000, 1024, 0.086, 3.0, 30.0, 6, 31)
+    multiband_case("multiband_48k_b15", 48000, 1024, 0.086, 15, -35.0, 8, 41)

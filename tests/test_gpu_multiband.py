@@ -125,3 +125,17 @@ def test_multiband_invalid_arguments():
         loc.process(np.zeros((2, 2, 3 * 512), np.float32))                         # more arrays than max_arrays
     with pytest.raises(api.MCArrayHipError):
         loc.process(np.zeros((1, 2, 1000), np.float32))                            # not (F+1)*hop samples
+
+
+def test_multiband_matches_golden(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "multiband_48k_b15.npz"))
+    loc = api.MultibandBinarualLocalisation(int(g["fs"]), g["xs"], int(g["nbins"]), False)
+    r = loc.process(g["pcm"], want_bands=True)
+    assert np.array_equal(r["band_idx"][0], g["band_idx"])
+    scale = np.abs(g["band_corr"]).max()
+    assert np.abs(r["band_corr"][0] - g["band_corr"]).max() <= 2e-5 * scale
+    np.testing.assert_allclose(r["energy_in_doa"][0], g["energy_in_doa"], rtol=1e-4, atol=1e-7 * g["energy_in_doa"].max())
+    assert np.array_equal(r["doa"][0], g["doa"].astype(np.float32))
+    np.testing.assert_allclose(r["prob"][0], g["prob"], atol=1e-4)
+    np.testing.assert_allclose(r["power"][0], g["power"], rtol=1e-4)

@@ -66,10 +66,47 @@ def test_freqgcc_matches_golden(golden_dir):
     assert min(ref[40], ref[41]) - 1e-9 <= mid[0] <= max(ref[40], ref[41]) + 1e-9
 
 
+def test_multiband_matches_golden(golden_dir):
+    g = _load(golden_dir, "multiband_48k_b15")
+    N, nb = int(g["N"]), int(g["nbins"])
+    m = po.Multiband(int(g["fs"]), g["xs"], N + 2, nb, False)
+    X = po.stft_frames(g["pcm"].astype(np.float64), N)
+    for t in range(X.shape[0]):
+        r = m.process(X[t, 0], X[t, 1])
+        assert r["fired"]
+        assert np.array_equal(r["band_idx"], g["band_idx"][t])
+        np.testing.assert_allclose(r["band_corr"], g["band_corr"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(r["energy_in_doa"], g["energy_in_doa"][t], rtol=1e-12, atol=0)
+        assert r["doa"] == g["doa"][t]
+        np.testing.assert_allclose(r["prob"], g["prob"][t], rtol=1e-12)
+        np.testing.assert_allclose(r["power"], g["power"][t], rtol=1e-12)
+
+
+def test_multiband_oracle_vs_twin_gated():
+    # floor estimation (3 s), the linear-vs-dB comparison and the hold-over on gated-out frames
+    fs, N, F = 16000, 512, 130
+    xs = [0.0, 0.086]
+    rng = np.random.default_rng(8)
+    L = (F + 1) * N // 2
+    src = synth.noise_source_stream(xs, np.deg2rad(50.0), fs, L, 9).astype(np.float64)
+    env = np.zeros(L)
+    env[100 * 256:115 * 256] = 1.0
+    pcm = 2.0 * rng.standard_normal((2, L)) + 100.0 / src.std() * src * env
+    b = tw.multiband_stream(fs, N, xs, pcm, 15, True)
+    m = po.Multiband(fs, xs, N + 2, 15, True)
+    X = po.stft_frames(pcm, N)
+    for t in range(F):
+        r = m.process(X[t, 0], X[t, 1])
+        assert r["fired"] == b["fired"][t], t
+        assert r["doa"] == b["doa"][t] and np.isclose(r["prob"], b["prob"][t], rtol=1e-12)
+        np.testing.assert_allclose(r["power"], b["power"][t], rtol=1e-12)
+    assert 0 < b["fired"].sum() < 20 and not b["fired"][:94].any()
+
+
 def test_all_golden_files_are_covered(golden_dir):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_dir, "*.npz")))
     assert names == sorted(["ssl_reemc_d37", "ssl_ula8_d361", "ssl_reemc_d37_s2", "mask_relative_both", "mask_full_both",
-                            "mask_factor_temporal", "mask_noisy_spatial", "freqgcc_16k_d61"])
+                            "mask_factor_temporal", "mask_noisy_spatial", "freqgcc_16k_d61", "multiband_48k_b15"])
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
