@@ -9,6 +9,7 @@
 #include "Beamformer.h"
 #include "BeamformingSeparationAndLocalistaion.h"
 #include "SoundLocalisationCallback.h"
+#include "SourceLocalisation.h"
 #include "SourceSeparationAndLocalisation.h"
 #include "SteeringBeamforming.h"
 #include "mcadefs.h"

@@ -267,6 +267,22 @@ class SourceSeparationAndLocalisation:
         return r["out"][0], r
 
 
+class SourceLocalisation(SourceSeparationAndLocalisation):
+    """mca::SourceLocalisation(int sampleRate, ArrayDescription, unsigned numOfSources, bool usePowerFloor)
+    (SourceLocalisation.h:43): the analysis-only sibling -- localisation and callbacks, no audio out
+    (SourceLocalisation.cpp:63-79 calls processFrameLocalisation only)."""
+
+    def process(self, pcm):
+        r = self.ctx.process_frames_host(np.asarray(pcm, dtype=np.float32)[None], want_energy=False, want_audio=False)
+        if self.callback is not None:
+            deg = r["doa"][0].astype(np.float64) * (180.0 / np.pi)
+            for t in range(deg.shape[0]):
+                if "voiced" in r and not r["voiced"][0, t]:
+                    continue
+                self.callback(deg[t], r["prob"][0, t], r["power"][0, t] if "power" in r else None, self.ctx.S)
+        return r
+
+
 class FreqGCCBinauralLocalisation:
     """mca::FreqGCCBinauralLocalisation(int sampleRate, ArrayDescription, bool usePowerFloor)
     (BinauralLocalisation.h:191), deterministic part: smoothed GCC-PHAT correlation, first-max argmax,

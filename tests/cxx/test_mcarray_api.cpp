@@ -265,6 +265,30 @@ static void testBinauralModules()
     }
 }
 
+static void testSourceLocalisation()
+{
+    // the analysis-only module reports the same DOAs as SourceSeparationAndLocalisation on the same input
+    const int fs = 48000;
+    const std::vector<double> xs = {0, 0.07, 0.175, 0.21};
+    ArrayDescription mics = ArrayDescription::make_linear_array_description(xs);
+    std::vector<std::vector<double> > ch;
+    SourceLocalisation sl(fs, mics, 1, false);
+    SourceSeparationAndLocalisation ssl(fs, mics, 1, false);
+    const int n = 14 * sl.getFrameSize() + 123;
+    make_source(xs, 55 * M_PI / 180, fs, n, 9u, ch);
+    LastCallback ca, cb;
+    sl.setCallback(ca); ssl.setCallback(cb);
+    std::vector<double *> in; std::vector<std::vector<double> > ob(4, std::vector<double>(n + 1024));
+    std::vector<double *> out;
+    for (int c = 0; c < 4; ++c) { in.push_back(ch[c].data()); out.push_back(ob[c].data()); }
+    const int frames = sl.process(in, n);
+    ssl.process(in, n, out, n + 1024);
+    EXPECT(frames == 13 && ca.doa.size() == 13u && cb.doa.size() == 13u);
+    for (size_t t = 0; t < ca.doa.size() && t < cb.doa.size(); ++t) EXPECT(ca.doa[t] == cb.doa[t]);
+    EXPECT(std::fabs(ca.doa.back() - 55.0) <= 7.0);
+    std::printf("SourceLocalisation: %d frames, last DOA %.1f deg\n", frames, ca.doa.back());
+}
+
 static void testMultibandBinauralLocalisation()
 {
     // test/test_mcarray.cpp:344-383: 1 kHz sine, 48 kHz, 0.086 m pair, 25 bins, ungated, +-15 degrees
@@ -300,6 +324,7 @@ int main(int argc, char **argv)
             testBeamformingSoundLocalisation(96000);
             testHookMatchesStream();
             testBinauralModules();
+            testSourceLocalisation();
             testMultibandBinauralLocalisation();
         } catch (const MCArrayException &e) {
             std::printf("FAIL: MCArrayException: %s\n", e.what());

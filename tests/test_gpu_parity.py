@@ -515,3 +515,18 @@ def test_mcbeam_cli_wav_roundtrip(tmp_path, fs, N):
         y = np.frombuffer(w.readframes(F * hop), dtype="<i2").astype(np.float64) / 32768
     o = po.ssl_stream(fs, N, xs, pcm16.astype(np.float64) / 32768, 1, 5.0)
     assert np.abs(y - o["out"][0]).max() <= 1.5 / 32768 + 2e-5
+
+
+def test_source_localisation_is_the_analysis_only_sibling():
+    # mca::SourceLocalisation (SourceLocalisation.cpp:63-79): processFrameLocalisation only -- same DOAs, no audio
+    fs, F = 48000, 25
+    xs = synth.REEM_C
+    pcm = synth.noise_source_stream(xs, np.deg2rad(-15.0), fs, (F + 1) * 512, 19)
+    got = []
+    sl = api.SourceLocalisation(fs, xs, 2, False)
+    sl.set_callback(lambda doa, prob, power, n: got.append((doa.copy(), n)))
+    r = sl.process(pcm)
+    assert r["out"] is None and len(got) == F and got[0][1] == 2
+    o = po.ssl_stream(fs, 1024, xs, pcm.astype(np.float64), 2, 5.0, want_map=True, want_audio=False)
+    _assert_bins(r["bin"][0], o["bin"], o["energy"], 6, max_ties=1)
+    np.testing.assert_allclose(np.array([g[0] for g in got]), np.rad2deg(r["doa"][0].astype(np.float64)), rtol=0, atol=0)
