@@ -89,7 +89,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # MCA_BENCH_FORCE_DIST=1 runs the RCCL gather with a single rank too (exercises the N > 1 code path on a 1-GPU box)
+    use_dist = world > 1 or (os.environ.get("MCA_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -101,41 +103,58 @@ def main():
     ctx = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=A, device=local_rank)
     assert ctx.D == D and ctx.P == P
     ctx.reserve(A, F)
-    doa_bin = torch.empty(A, F, 1, dtype=torch.int32, device=dev)
+    # DOA bin (int32) and probability (fp32) share one 4-byte-word buffer so that the only exchange of the path is ONE
+    # all_gather per step; two buffers alternate so that step i+1 can run while the gather of step i is in flight
+    packed = [torch.empty(2, A, F, 1, dtype=torch.int32, device=dev) for _ in range(2)]
     doa_rad = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
-    prob = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
     out = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
-    all_bin = torch.empty(A * world, F, 1, dtype=torch.int32, device=dev) if world > 1 else None
-    all_prob = torch.empty(A * world, F, 1, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = [torch.empty(world, 2, A, F, 1, dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
+    pending = [None, None]
+    state = {"i": 0}
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
+        b = state["i"] & 1
+        state["i"] += 1
+        if pending[b] is not None:          # the gather that last read this buffer pair (two steps ago)
+            pending[b].wait()
+            pending[b] = None
+        doa_bin, prob = packed[b][0], packed[b][1].view(torch.float32)
         ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=stream)
-        if world > 1:   # the only exchange of the path: gather DOA buffers (RCCL over xGMI)
-            dist.all_gather_into_tensor(all_bin, doa_bin)
-            dist.all_gather_into_tensor(all_prob, prob)
+        if use_dist:    # RCCL over xGMI, asynchronous: overlaps the next step's kernels
+            pending[b] = dist.all_gather_into_tensor(gathered[b], packed[b], async_op=True)
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     ctx.set_timing(True)
     ctx.reset_timing()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_timing(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    last = (state["i"] - 1) & 1
+    last_bin = packed[last][0]
     frames_per_step = A * F * world
     value = frames_per_step * args.steps / elapsed
 
@@ -171,7 +190,7 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             nf = min(args.cpu_frames, F)
             fps, dt, ref = cpu_baseline(pcm[0].cpu().numpy(), nf)
-            gb = doa_bin[0, :nf, 0].cpu().numpy()
+            gb = last_bin[0, :nf, 0].cpu().numpy()
             mism = int((gb != ref["bin"][:, 0]).sum())
             cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "array 0, first %d frames of the same input, %.1f s, double-precision scalar C restatement "
@@ -190,7 +209,10 @@ def main():
             "kernels": kt, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
+        # the gathered buffers hold every rank's block at its global position
+        if not torch.equal(gathered[last][rank], packed[last]):
+            print("rank %d: gathered DOA buffers do not contain this rank's block" % rank, file=sys.stderr)
         dist.destroy_process_group()
 
 
