@@ -50,7 +50,7 @@ __device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, 
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = i + 1; j < MT; ++j) acc[j - i - 1] = cadd(acc[j - i - 1], cmulc(r[i], r[j]));
+                for (int j = i + 1; j < MT; ++j) acc[j - i - 1] = cmacc(acc[j - i - 1], r[i], r[j]);
 #pragma unroll
             for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * KG + k, acc[g]);
         } else {
@@ -64,7 +64,7 @@ __device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, 
         if (ULA) {
             for (int g = 0; g < M - 1; ++g) {
                 float2 acc = make_float2(0.f, 0.f);
-                for (int i = 0; i + g + 1 < M; ++i) acc = cadd(acc, cmulc(x[i * xstride], x[(i + g + 1) * xstride]));
+                for (int i = 0; i + g + 1 < M; ++i) acc = cmacc(acc, x[i * xstride], x[(i + g + 1) * xstride]);
                 store_a(arow, p, g * KG + k, acc);
             }
         } else {
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
                     for (int c = 0; c < M; ++c) {
                         const float2 *tb2 = steer + (s * M + c) * 49;
                         const float2 ph = cmul(tb2[32 + (k >> 5)], tb2[k & 31]);
-                        acc = cadd(acc, cmul(xs[c * FFT_SCRATCH + k], ph));
+                        acc = cmac(acc, xs[c * FFT_SCRATCH + k], ph);
                     }
                     ys[(j * S + s) * FFT_SCRATCH + k] = make_float2(acc.x * inv, acc.y * inv);   // divC :70
                 }
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
         if (tid < nb * S) {
             const int j = tid / S, s = tid - j * S;
             float2 acc = make_float2(0.f, 0.f);
-            for (int c = 0; c < M; ++c) acc = cadd(acc, cmul(xn[j * M + c], pn[(j * S + s) * M + c]));
+            for (int c = 0; c < M; ++c) acc = cmac(acc, xn[j * M + c], pn[(j * S + s) * M + c]);
             ys[tid * FFT_SCRATCH + FFT_H] = make_float2(acc.x * inv, acc.y * inv);
         }
         __syncthreads();
