@@ -4,7 +4,7 @@
 // sequence z[m] = x[2m] + j x[2m+1] plus a split step.  512 = 8*8*8: every lane owns 8
 // complex points and does three radix-8 butterflies in registers; between them the wave
 // exchanges data through its own LDS scratch (two transposes).  The LDS layouts
-// (row stride 72 complex words, inner stride 9 in the second exchange) make every
+// (row stride 72 complex words in the first exchange, q + 66*l0 + 8*s in the second) make every
 // ds_write_b64 / ds_read_b64 of the exchanges bank-conflict free (MI355X LDS: 64 banks x 4 B;
 // b64 reads are serviced in two 32-lane groups, b64 writes in four 16-lane groups).
 //
@@ -109,7 +109,7 @@ __device__ __forceinline__ constexpr int br3(int i) { return ((i & 1) << 2) | (i
 //   t1[q][lane] = W512^(lane*q)        q = 0..7   (index q*64 + lane)
 //   t2[s][l0]   = W64^(l0*s)           s, l0 = 0..7 (index 512 + s*8 + l0)
 //   ts[i][lane] = W1024^(lane + 64 i)  i = 0..3   (index 576 + i*64 + lane)
-//   win[r][lane] = (w[2m], w[2m+1]), m = lane + 64 r (index 832 + r*64 + lane), periodic Hann
+//   win[r][lane] = (w[2m], w[2m+1]) / 2, m = lane + 64 r (index 832 + r*64 + lane), periodic Hann
 // Forward values; the inverse transform uses their conjugates.  Every read is lane-contiguous
 // (conflict-free) or a broadcast.  Keeping them here instead of in registers frees ~58 VGPRs per
 // lane, which is what lets two 512-thread workgroups share a CU.
@@ -133,7 +133,10 @@ __device__ __forceinline__ void fft_table_init(float2 *tab, const float *window,
         else { const int i = (e - TW_TS) >> 6, l = (e - TW_TS) & 63; v = twiddle(l + 64 * i, 1024, false); }
         tab[e] = v;
     }
-    for (int e = tid; e < 512; e += nthreads) tab[TW_WIN + e] = reinterpret_cast<const float2 *>(window)[e];
+    for (int e = tid; e < 512; e += nthreads) {   // half the window: carries the 1/2 of rfft1024's split step (exact in fp32)
+        const float2 w = reinterpret_cast<const float2 *>(window)[e];
+        tab[TW_WIN + e] = make_float2(0.5f * w.x, 0.5f * w.y);
+    }
 }
 
 // wave-level ordering of LDS traffic: LDS instructions of one wave execute in order, so only
@@ -145,10 +148,11 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 512-point complex FFT of v[r] = z[lane + 64 r]; result Z[k] is written in natural order to
-// buf[k], k = 0..511 (buf = this wave's scratch, FFT_SCRATCH words).
+// 512-point complex FFT of v[r] = z[lane + 64 r] through buf (this wave's scratch, FFT_SCRATCH words).
+// The result stays in registers with the same distribution as the input, register index bit-reversed:
+// on return v[i] = Z[lane + 64 * br3(i)].
 template <bool INV>
-__device__ __forceinline__ void cfft512_to_lds(float2 (&v)[8], float2 *buf, int lane, const FftTw &tw)
+__device__ __forceinline__ void cfft512_regs(float2 (&v)[8], float2 *buf, int lane, const FftTw &tw)
 {
     // stage A: DFT over r, twiddle W512^(lane*q), exchange 1: buf[q*72 + lane]
     fft8<INV>(v);
@@ -162,46 +166,52 @@ __device__ __forceinline__ void cfft512_to_lds(float2 (&v)[8], float2 *buf, int 
 #pragma unroll
     for (int l1 = 0; l1 < 8; ++l1) v[l1] = buf[qq * FFT_ROW + l0 + 8 * l1];
     wave_lds_fence();
-    // stage B: DFT over l1, twiddle W64^(l0*s), exchange 2: buf[q*72 + 9*l0 + s]
+    // stage B: DFT over l1, twiddle W64^(l0*s), exchange 2: buf[q + 66*l0 + 8*s].  The layout makes the
+    // 16-lane write groups (q pair x l0) hit 16 distinct bank pairs and turns the read-back into
+    // contiguous rows: the reading lane is (s, q) = (lane >> 3, lane & 7), address lane + 66*l0.
     fft8<INV>(v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int s = br3(i);
-        buf[qq * FFT_ROW + 9 * l0 + s] = (s == 0) ? v[i] : (INV ? cmulc(v[i], tw.t2(s, lane)) : cmul(v[i], tw.t2(s, lane)));
+        buf[qq + 66 * l0 + 8 * s] = (s == 0) ? v[i] : (INV ? cmulc(v[i], tw.t2(s, lane)) : cmul(v[i], tw.t2(s, lane)));
     }
     wave_lds_fence();
-    const int ss = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = buf[qq * FFT_ROW + 9 * j + ss];
+    for (int j = 0; j < 8; ++j) v[j] = buf[lane + 66 * j];
     wave_lds_fence();
-    // stage C: DFT over l0 -> t ; k = q + 8 s + 64 t
+    // stage C: DFT over l0 -> t ; k = q + 8 s + 64 t = lane + 64 t
     fft8<INV>(v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) buf[qq + 8 * ss + 64 * br3(i)] = v[i];
-    wave_lds_fence();
 }
 
-// Forward real FFT.  v[r] = (x[2m], x[2m+1]) (already windowed), m = lane + 64 r.
+// Forward real FFT.  v[r] = (x[2m], x[2m+1]) windowed with HALF the analysis window (the table of
+// fft_table_init carries the 1/2 of the split step), m = lane + 64 r.
 // On return buf[k], k = 0..512, holds X[k] (buf must have >= FFT_SCRATCH words; word 512 is used).
 __device__ __forceinline__ void rfft1024(float2 (&v)[8], float2 *buf, int lane, const FftTw &tw)
 {
-    cfft512_to_lds<false>(v, buf, lane, tw);
-    // split step, in place on pairs (k, 512-k):  X[k] = a + W b,  X[512-k] = conj(a - W b),
-    // a = (Z[k] + conj Z[512-k])/2,  b = -j (Z[k] - conj Z[512-k])/2,  W = W1024^k.
+    cfft512_regs<false>(v, buf, lane, tw);
+    // split step on pairs (k, 512-k):  X[k] = a + W b,  X[512-k] = conj(a - W b),
+    // a = Z[k] + conj Z[512-k],  b = -j (Z[k] - conj Z[512-k]),  W = W1024^k  (Z already halved).
+    // Z[k], k = lane + 64 i < 256, is in this lane's registers; its partner lives in lane 64 - lane,
+    // rows 4..7, so only those rows go through LDS.
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (br3(i) >= 4) buf[lane + 64 * br3(i)] = v[i];
+    wave_lds_fence();
     float2 xk[4], xp[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;
-        float2 zk = buf[k];
+        const float2 zk = v[br3(i)];
         float2 zp = buf[(512 - k) & 511];
-        float2 a = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));
-        float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));   // (Z[k] - conj Zp)/2
-        float2 b = make_float2(d.y, -d.x);                                      // -j d
-        float2 wb = cmul(tw.ts(i, lane), b);
+        if (k == 0) zp = zk;                                                    // Z[512] = Z[0]
+        const float2 a = make_float2(zk.x + zp.x, zk.y - zp.y);
+        const float2 d = make_float2(zk.x - zp.x, zk.y + zp.y);                 // Z[k] - conj Zp
+        const float2 b = make_float2(d.y, -d.x);                                // -j d
+        const float2 wb = cmul(tw.ts(i, lane), b);
         xk[i] = cadd(a, wb);
         xp[i] = cconj(csub(a, wb));
     }
-    float2 z256 = buf[256];
+    const float2 z256 = v[br3(4)];                                              // lane 0: Z[256]
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -210,8 +220,8 @@ __device__ __forceinline__ void rfft1024(float2 (&v)[8], float2 *buf, int lane, 
         buf[512 - k] = xp[i];      // k = 0 writes X[512]
     }
     if (lane == 0) {
-        // k = 256: Zp = Zk, W = -j:  a = (Re z, 0), b = -j (0, Im z) = (Im z, 0); X = a + W b = (Re z, -Im z)
-        buf[256] = make_float2(z256.x, -z256.y);
+        // k = 256: Zp = Zk, W = -j:  a = (2 Re z, 0), b = (2 Im z, 0); X = a + W b = 2 (Re z, -Im z)
+        buf[256] = make_float2(2.f * z256.x, -2.f * z256.y);
     }
     wave_lds_fence();
 }
@@ -221,48 +231,41 @@ __device__ __forceinline__ void rfft1024(float2 (&v)[8], float2 *buf, int lane, 
 // scaled by 1/1024 overall.
 __device__ __forceinline__ void irfft1024(float2 *buf, int lane, const FftTw &tw)
 {
-    // build Z[k] = a + j b, Z[512-k] = conj(a) + j conj(b) with a = (X[k] + conj X[512-k])/2,
-    // b = conj(W1024^k) (X[k] - conj X[512-k])/2.
-    float2 zk[4], zp[4];
+    // Z[k] = a + j b, Z[512-k] = conj(a) + j conj(b) with a = X[k] + conj X[512-k],
+    // b = conj(W1024^k) (X[k] - conj X[512-k]); the 1/2 of both is folded into the final scale.
+    // Z[k], k = lane + 64 i < 256, stays in this lane's registers; Z[512-k] belongs to lane 64 - lane.
+    float2 v[8], zp[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;
         float2 xk = buf[k];
         float2 xp = buf[512 - k];
         if (k == 0) { xk.y = 0.f; xp.y = 0.f; }
-        float2 a = make_float2(0.5f * (xk.x + xp.x), 0.5f * (xk.y - xp.y));
-        float2 d = make_float2(0.5f * (xk.x - xp.x), 0.5f * (xk.y + xp.y));
-        float2 b = cmulc(d, tw.ts(i, lane));
-        zk[i] = make_float2(a.x - b.y, a.y + b.x);          // a + j b
+        const float2 a = make_float2(xk.x + xp.x, xk.y - xp.y);
+        const float2 d = make_float2(xk.x - xp.x, xk.y + xp.y);
+        const float2 b = cmulc(d, tw.ts(i, lane));
+        v[i] = make_float2(a.x - b.y, a.y + b.x);           // a + j b
         zp[i] = make_float2(a.x + b.y, -a.y + b.x);         // conj(a) + j conj(b)
     }
-    float2 x256 = buf[256];
+    const float2 x256 = buf[256];
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;
         if (k != 0) buf[512 - k] = zp[i];
-        buf[k] = zk[i];
     }
     if (lane == 0) {
-        // k = 256: a = (Re x, 0), d = (0, Im x), b = conj(W) d = (+j)(0, Im x) = (-Im x, 0); Z = a + j b = (Re x, -Im x)
-        buf[256] = make_float2(x256.x, -x256.y);
-    }
-    wave_lds_fence();
-    float2 v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
-    wave_lds_fence();
-    cfft512_to_lds<true>(v, buf, lane, tw);
-    const float sc = 1.0f / 512.0f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        float2 z = buf[lane + 64 * r];
-        v[r] = make_float2(z.x * sc, z.y * sc);
+        // k = 256: a = (2 Re x, 0), d = (0, 2 Im x), b = conj(W) d = (-2 Im x, 0); Z = a + j b = 2 (Re x, -Im x)
+        buf[256] = make_float2(2.f * x256.x, -2.f * x256.y);
     }
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
+    for (int r = 4; r < 8; ++r) v[r] = buf[lane + 64 * r];
+    wave_lds_fence();
+    cfft512_regs<true>(v, buf, lane, tw);
+    const float sc = 1.0f / 1024.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[lane + 64 * br3(i)] = make_float2(v[i].x * sc, v[i].y * sc);
     wave_lds_fence();
 }
 
