@@ -39,7 +39,7 @@ struct mca_hip_ctx {
     float2 *d_tw = nullptr;       // [N/2] exp(-j 2 pi i / N), any-N kernels
     double *d_micx = nullptr;
     int2 *d_pairs = nullptr;
-    void *d_B = nullptr;
+    void *d_B = nullptr, *d_Bt = nullptr;
     // stream state (double buffered: kernels read [cur], write [cur^1])
     float *d_E[2] = {nullptr, nullptr};
     float *d_tail[2] = {nullptr, nullptr};
@@ -110,7 +110,7 @@ void free_ctx(mca_hip_ctx *c)
 {
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B);
+    F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]);
     F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
@@ -173,6 +173,19 @@ int build_steering_table(mca_hip_ctx *c)
                 }
         HIP_TRY(c, hipMalloc(&c->d_B, B.size() * sizeof(_Float16)));
         HIP_TRY(c, hipMemcpy(c->d_B, B.data(), B.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        if (Dp == 384) {
+            // the same table tiled for the 256 x 384 kernel: one 16-deep K slice of all 384 columns is 12 KiB
+            // contiguous, so every LDS-DMA instruction of that kernel moves one contiguous KiB (32 rows x 32 B
+            // pieces out of the row-major table cost 0.26 ms per launch instead of 0.16 ms)
+            const int ns = Kp / 16;
+            std::vector<_Float16> Bt(B.size());
+            for (int pl = 0; pl < planes; ++pl)
+                for (int sl = 0; sl < ns; ++sl)
+                    for (int d = 0; d < Dp; ++d)
+                        std::memcpy(&Bt[(((size_t)pl * ns + sl) * Dp + d) * 16], &B[((size_t)pl * Dp + d) * Kp + (size_t)sl * 16], 16 * sizeof(_Float16));
+            HIP_TRY(c, hipMalloc(&c->d_Bt, Bt.size() * sizeof(_Float16)));
+            HIP_TRY(c, hipMemcpy(c->d_Bt, Bt.data(), Bt.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        }
     }
     return MCA_HIP_OK;
 }
@@ -510,7 +523,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         if (rc) return rc;
 
         GemmArgs ga{};
-        ga.A = c->d_A; ga.B = c->d_B; ga.C = c->d_C;
+        ga.A = c->d_A; ga.B = c->d_B; ga.C = c->d_C; ga.Bt = c->d_Bt;
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
         ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
         ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
@@ -528,8 +541,9 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
                 hipLaunchKernelGGL(K, gv, dim3(512), smem, st, ga);                                                       \
             } while (0)
-            if (c->prec == MCA_HIP_SRP_FP16X3) V2_LAUNCH((k_srp_gemm_f16_v2<true, 8, 3>));
-            else V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3>));
+            static const bool roll = std::getenv("MCA_HIP_GEMM_NOROLL") == nullptr;    // A/B switch for measurements
+            if (c->prec == MCA_HIP_SRP_FP16X3) { if (roll) V2_LAUNCH((k_srp_gemm_f16_v2<true, 8, 3, true>)); else V2_LAUNCH((k_srp_gemm_f16_v2<true, 8, 3, false>)); }
+            else { if (roll) V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3, true>)); else V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3, false>)); }
 #undef V2_LAUNCH
         } else {
             dim3 g2((ga.rows + 127) / 128, c->Dp / 192);

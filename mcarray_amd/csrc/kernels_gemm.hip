@@ -223,7 +223,7 @@ constexpr int V2_BM = 256, V2_BN = 384, V2_BK = 16, V2_ROWB = 32;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <bool SPLIT, int NLOAD, int NSTAGE>
+template <bool SPLIT, int NLOAD, int NSTAGE, bool ROLL>
 __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
 {
     constexpr int NP = SPLIT ? 2 : 1;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     const int wm = wave >> 1, wn = wave & 1;
     const int row0 = blockIdx.x * V2_BM;
     const unsigned char *A = reinterpret_cast<const unsigned char *>(p.A);
-    const unsigned char *B = reinterpret_cast<const unsigned char *>(p.B);
+    const unsigned char *B = reinterpret_cast<const unsigned char *>(p.Bt);   // tiled table [plane][slice][384][16]
 
     // K slices of this workgroup
     const int nslices = p.Kp / V2_BK;
@@ -251,9 +251,9 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     const int lr = (wave & 3) * 32 + (lane >> 1);
     const int lc = (lane & 1) ^ ((lane >> 4) & 1);             // logical chunk stored at this lane's physical position
     const unsigned char *a_lane = A + ((long long)(row0 + lr) * p.a_row_elems + lc * 8) * 2;
-    const unsigned char *b_lane = B + ((long long)lr * p.Kp + lc * 8) * 2;
+    const unsigned char *b_lane = B + lr * V2_ROWB + lc * 16;
     const long long a_blk = (long long)128 * p.a_row_elems * 2, a_pl = (long long)p.Kp * 2;
-    const long long b_blk = (long long)128 * p.Kp * 2, b_pl = (long long)p.Dp * p.Kp * 2;
+    const long long b_blk = 128 * V2_ROWB, b_pl = (long long)(p.Kp / V2_BK) * B_BYTES;
     const int dst_lane_blk = (wave & 3) * 1024;
 
     f32x16 acc[2][6];
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     // NLOAD == 8: every wave moves A block w and B block w of every plane, waves 0..3 also B block w+8.
     auto issue = [&](int s, int buf) {
         const long long koff = (long long)(s_beg + s) * V2_BK * 2;
+        const long long koff_b = (long long)(s_beg + s) * B_BYTES;
         unsigned char *sb = smem_g + buf * STAGE + dst_lane_blk;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
@@ -278,16 +279,16 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
                                                      (lds_void_t *)(sb + pl * A_BYTES + i * 4096), 16, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + i * b_blk + koff),
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + i * b_blk + koff_b),
                                                      (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + i * 4096), 16, 0, 0);
             } else {
                 const int hi = wave >> 2;                       // 0: blocks w, 1: blocks w (= (w&3)+4)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + hi * a_blk + koff),
                                                  (lds_void_t *)(sb + pl * A_BYTES + hi * 4096), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + hi * b_blk + koff),
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + hi * b_blk + koff_b),
                                                  (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + hi * 4096), 16, 0, 0);
                 if (wave < 4)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + 2 * b_blk + koff),
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + 2 * b_blk + koff_b),
                                                      (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + 2 * 4096), 16, 0, 0);
             }
         }
@@ -327,6 +328,58 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
         if (loader && s + NSTAGE - 1 < ns) issue(s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);   // that buffer was last read in slice s-1
         const unsigned char *st = smem_g + (s % NSTAGE) * STAGE;
         f16x8 af[NP][2];
+        if constexpr (ROLL) {
+            // Rolling B fragments: three register slots.  All of A and column blocks 0..2 are requested up front;
+            // as soon as the MFMAs of block j have issued, block j+3 is requested into the slot they read.  The
+            // LDS reads of a slice are thereby spread under the matrix work instead of two read-then-compute
+            // phases in which all eight waves hit the LDS at once while the matrix cores idle.
+            // The reads and their waits are inline asm: the compiler waits for lgkmcnt(0) before every MFMA
+            // group (it does not count outstanding ds_read_b128), which would re-serialise the schedule.  LDS
+            // reads of one wave return in order, so "at most N younger reads outstanding" is exact; every wait
+            // lists the registers it releases as in/out operands so that nothing can read them earlier.
+            f16x8 bs[3][NP];
+            const unsigned a_addr = (unsigned)(uintptr_t)((lds_void_t *)(st)) + a_off[0];
+            const unsigned b_addr = (unsigned)(uintptr_t)((lds_void_t *)(st)) + NP * A_BYTES + b_off[0];
+#define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                LDS_RD(af[pl][0], a_addr, pl * A_BYTES);
+                LDS_RD(af[pl][1], a_addr, pl * A_BYTES + 32 * V2_ROWB);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j][pl], b_addr, pl * B_BYTES + j * 32 * V2_ROWB);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                // younger reads allowed in flight while block j computes: blocks j+1, j+2 (NP reads each)
+                constexpr int Y2 = 2 * NP, Y1 = NP;
+                if constexpr (SPLIT) {
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]) : "n"(Y2));
+                    else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y2));
+                    else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y1));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]));
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][1], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][1], acc[1][j], 0, 0, 0);
+                } else {
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bs[0][0]) : "n"(Y2));
+                    else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y2));
+                    else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y1));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]));
+                }
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 3 < 6) {
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j % 3][pl], b_addr, pl * B_BYTES + (j + 3) * 32 * V2_ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef LDS_RD
+        } else {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -350,6 +403,7 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][jj], acc[i][j], 0, 0, 0);
                 }
         }
+        }
     }
     float *Cp = p.C + (long long)blockIdx.y * p.c_plane_elems;
 #pragma unroll
@@ -366,7 +420,9 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
         }
 }
 
-template __global__ void k_srp_gemm_f16_v2<true, 8, 3>(GemmArgs);
-template __global__ void k_srp_gemm_f16_v2<false, 8, 3>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<true, 8, 3, false>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<false, 8, 3, false>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<true, 8, 3, true>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<false, 8, 3, true>(GemmArgs);
 
 }  // namespace mca
