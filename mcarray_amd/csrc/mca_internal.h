@@ -13,7 +13,7 @@ constexpr int BF_NB = 4;           // frames per inverse-FFT batch of k_beamform
 constexpr int GCC2_DOAWARM = 64;   // frames of DOA-recursion warm-up in k_gcc2_scan (0.6^64 = 6e-15)
 constexpr int SCAN_WARM = 96;     // frames of IIR warm-up per scan chunk (0.8^96 = 5e-10 << fp32 epsilon)
 constexpr int KG = 513;            // complex K-slots per delay group in the A / B contraction index (g * KG + k)
-constexpr int SCAN_CHUNK = 128;   // frames per chunk of the exact chunked scan
+constexpr int SCAN_CHUNK = 64;    // frames per chunk of the exact chunked scan
 constexpr int SCAN_SUB = 32;      // frames per LDS sub-batch of k_scan_pick
 
 struct StftPhatArgs {
