@@ -39,14 +39,18 @@ __device__ __forceinline__ void store_a(float *row, const StftPhatArgs &, int ci
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void store_a(_Float16 *row, const StftPhatArgs &p, int cidx, float2 v)
 {
-    half2_t hi;
-    hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y;
+    // hi = fp16(v), lo = fp16(v - hi): vector conversions so that one packed convert serves both the store
+    // of hi and the residual
+    const float2_t vv = {v.x, v.y};
+    const half2_t hi = __builtin_convertvector(vv, half2_t);
     reinterpret_cast<half2_t *>(row)[cidx] = hi;
     if (p.a_planes == 2) {
-        half2_t lo;
-        lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+        const float2_t back = __builtin_convertvector(hi, float2_t);
+        const half2_t lo = __builtin_convertvector(vv - back, half2_t);
         reinterpret_cast<half2_t *>(row + p.Kp)[cidx] = lo;
     }
 }
