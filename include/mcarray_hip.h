@@ -251,7 +251,8 @@ typedef enum {
     MCA_HIP_K_BEAMFORM = 3,    /* STFT + delay-and-sum + inverse FFT + overlap-add */
     MCA_HIP_K_GCC2_SCAN = 4,   /* 2-mic correlation smoothing + argmax + probability */
     MCA_HIP_K_MASK = 5,        /* binaural masking */
-    MCA_HIP_K_COUNT = 6
+    MCA_HIP_K_FOLD = 6,        /* sum of the partial maps of a deep split-K contraction (small batches only) */
+    MCA_HIP_K_COUNT = 7
 } mca_hip_kernel_id;
 /* enable = 1: bracket every launch of the stream API with hipEvents on its stream */
 int mca_hip_set_timing(mca_hip_ctx *ctx, int enable);

@@ -14,8 +14,9 @@ from . import _lib
 from ._lib import MCArrayHipError
 
 SRP_FP32, SRP_FP16X3, SRP_FP16 = 0, 1, 2
-K_STFT_PHAT, K_SRP_GEMM, K_SCAN_PICK, K_BEAMFORM = 0, 1, 2, 3
-KERNEL_NAMES = {K_STFT_PHAT: "k_stft_phat", K_SRP_GEMM: "k_srp_gemm", K_SCAN_PICK: "k_scan_pick", K_BEAMFORM: "k_beamform_ola"}
+K_STFT_PHAT, K_SRP_GEMM, K_SCAN_PICK, K_BEAMFORM, K_GCC2_SCAN, K_MASK, K_FOLD = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = {K_STFT_PHAT: "k_stft_phat", K_SRP_GEMM: "k_srp_gemm", K_SCAN_PICK: "k_scan_pick", K_BEAMFORM: "k_beamform_ola",
+                K_FOLD: "k_sum_planes"}
 
 
 def _xyz(x):

@@ -56,7 +56,7 @@ struct mca_hip_ctx {
     // workspace
     void *d_A = nullptr; size_t a_bytes = 0;
     float *d_C = nullptr; size_t c_bytes = 0;
-    bool c_split = false;          // the last contraction left two partial maps (split-K) in d_C
+    int c_planes = 1;              // partial maps (split-K) the last contraction left in d_C
     long long c_plane = 0;
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
@@ -205,6 +205,30 @@ void time_end(mca_hip_ctx *c, hipStream_t st)
     (void)hipEventRecord(c->events.back().b, st);
 }
 
+// which contraction kernel a chunk of `rows` frames runs on, and over how many workgroups its K range is split
+struct GemmPlan { bool v2; int ksplit; };
+GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
+{
+    GemmPlan g;
+    g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= c->v2_min_rows && !c->force_v1;
+    if (g.v2) {
+        g.ksplit = rows >= 65536 ? 1 : 2;   // 256 x 384 tiles need >= ~256 workgroups to fill the chip
+    } else {
+        // 128 x 192 tiles: small batches (a single stream) would leave most CUs idle and walk the whole K range
+        // in a handful of workgroups (0.29 ms however few frames); split K until ~512 workgroups exist, keeping
+        // at least 8 K steps per workgroup
+        const long long wgs = (rows + 127) / 128 * (c->Dp / 192);
+        const int nk = c->Kp / (c->prec == MCA_HIP_SRP_FP32 ? 16 : 32);
+        long long ks = 512 / (wgs > 0 ? wgs : 1);
+        if (ks > nk / 8) ks = nk / 8;
+        if (ks > 16) ks = 16;
+        if (ks < 1) ks = 1;
+        static const bool nosplit = std::getenv("MCA_HIP_V1_NOSPLIT") != nullptr;    // A/B switch for measurements
+        g.ksplit = nosplit ? 1 : (int)ks;
+    }
+    return g;
+}
+
 int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
 {
     // rows rounded up to the 256-row tile of the split-K MFMA kernel, which loads whole tiles unclamped
@@ -216,7 +240,8 @@ int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
         HIP_TRY(c, hipMemset(c->d_A, 0, need_a));       // the Kp padding columns stay zero forever
         c->a_bytes = need_a;
     }
-    size_t need_c = (size_t)rows_total * c->Dp * sizeof(float) * 2;   // room for the two partial maps of the split-K kernel
+    const int planes = std::max(2, plan_gemm(c, rows_chunk).ksplit);
+    size_t need_c = (size_t)rows_total * c->Dp * sizeof(float) * planes;   // room for the partial maps of a split-K contraction
     if (need_c > c->c_bytes) {
         if (c->d_C) (void)hipFree(c->d_C);
         c->d_C = nullptr; c->c_bytes = 0;
@@ -527,10 +552,11 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
         ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
         ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
-        // 256 x 384 tiles need >= ~256 workgroups to fill the chip: split K in two below 65 536 rows
-        const bool v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && ga.rows >= c->v2_min_rows && !c->force_v1;
-        const int ksplit = ga.rows >= 65536 ? 1 : 2;
-        c->c_split = v2 && ksplit == 2; c->c_plane = ga.c_plane_elems;
+        // one split factor per call (the scan sums the same number of partial maps for every frame): the one that
+        // suits the full-size chunks; a shorter last chunk may still fall back to the 128 x 192 kernel
+        const bool v2 = plan_gemm(c, ga.rows).v2;
+        const int ksplit = plan_gemm(c, (long long)n_arrays * fc).ksplit;
+        c->c_planes = ksplit; c->c_plane = ga.c_plane_elems;
         time_begin(c, MCA_HIP_K_SRP_GEMM, st);
         if (v2) {
             const int np = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
@@ -546,13 +572,21 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             else { if (roll) V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3, true>)); else V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3, false>)); }
 #undef V2_LAUNCH
         } else {
-            dim3 g2((ga.rows + 127) / 128, c->Dp / 192);
+            dim3 g2((ga.rows + 127) / 128, c->Dp / 192, ksplit);
             if (c->prec == MCA_HIP_SRP_FP32) hipLaunchKernelGGL(k_srp_gemm_f32, g2, dim3(256), 0, st, ga);
             else if (c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL(k_srp_gemm_f16<true>, g2, dim3(256), 0, st, ga);
             else hipLaunchKernelGGL(k_srp_gemm_f16<false>, g2, dim3(256), 0, st, ga);
         }
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
+    }
+    if (c->c_planes > 2) {      // deep split-K of a small batch: fold the partial maps once, the scans read one map
+        const long long n4 = c->c_plane / 4;       // Dp is a multiple of 192
+        time_begin(c, MCA_HIP_K_FOLD, st);
+        hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, c->d_C, n4, c->c_planes, c->c_plane);
+        time_end(c, st);
+        HIP_TRY(c, hipGetLastError());
+        c->c_planes = 1;
     }
 
     return MCA_HIP_OK;
@@ -579,7 +613,7 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         hipLaunchKernelGGL(k_gate, dim3(n_arrays), dim3(256), 0, st, gg);
     }
     ScanPickArgs pa{};
-    pa.C = c->d_C; pa.C2 = c->c_split ? c->d_C + c->c_plane : nullptr; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
+    pa.C = c->d_C; pa.c_planes = c->c_planes; pa.c_plane_stride = c->c_plane; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
     pa.chunk = SCAN_CHUNK; pa.n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
     pa.state_in = c->d_E[c->e_cur]; pa.state_out = c->d_E[c->e_cur ^ 1];
@@ -711,7 +745,7 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
     Gcc2ScanArgs ga{};
-    ga.C = c->d_C; ga.C2 = c->c_split ? c->d_C + c->c_plane : nullptr; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D; ga.chunk = 32;
+    ga.C = c->d_C; ga.c_planes = c->c_planes; ga.c_plane_stride = c->c_plane; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D; ga.chunk = 32;
     ga.frames_done = c->gcc2_frames_done;
     ga.mu = 0.8f; ga.one_minus_mu = 1 - 0.8f;                      // _maxCorrMemoryFactor (BinauralLocalisation.h:198)
     ga.doa_mem = 0.6f; ga.one_minus_doa_mem = 1 - 0.6f;            // _maxDoaMemoryFactor (:199)

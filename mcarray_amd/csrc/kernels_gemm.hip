@@ -61,9 +61,11 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f32(GemmArgs p)
         rb1 = *reinterpret_cast<const float4 *>(pb1 + (long long)(k0) * p.Dp); \
         rb2 = *reinterpret_cast<const float4 *>(pb2 + (long long)(k0) * p.Dp); \
     } while (0)
-    G32_GLOAD(0);
-    const int nk = p.Kp / G32_BK;
-    for (int kt = 0; kt < nk; ++kt) {
+    // K range of this workgroup (split-K over blockIdx.z: partial map z goes to C + z * c_plane_elems)
+    const int nk_all = p.Kp / G32_BK, per = (nk_all + gridDim.z - 1) / gridDim.z;
+    const int kt0 = blockIdx.z * per, nk = min(kt0 + per, nk_all);
+    G32_GLOAD(kt0 * G32_BK);
+    for (int kt = kt0; kt < nk; ++kt) {
         As[akq * 4 + 0][ar] = ra0.x; As[akq * 4 + 1][ar] = ra0.y; As[akq * 4 + 2][ar] = ra0.z; As[akq * 4 + 3][ar] = ra0.w;
         As[akq * 4 + 0][ar + 64] = ra1.x; As[akq * 4 + 1][ar + 64] = ra1.y; As[akq * 4 + 2][ar + 64] = ra1.z; As[akq * 4 + 3][ar + 64] = ra1.w;
         *reinterpret_cast<float4 *>(&Bs[bkr[0]][bc4[0] * 4]) = rb0;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f32(GemmArgs p)
             const int frow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (frow < p.rows) {
                 const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
-                float *crow = p.C + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * 96 + (lane & 31);
+                float *crow = p.C + (long long)blockIdx.z * p.c_plane_elems + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * 96 + (lane & 31);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) crow[j * 32] = acc[i][j][r];
             }
@@ -145,9 +147,10 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                                          \
             rb[pl][i] = *reinterpret_cast<const f16x8 *>(B + ((long long)pl * p.Dp + col0 + lr + 64 * i) * p.Kp + (k0) + lc * 8); \
     }
-    G16_GLOAD(0)
-    const int nk = p.Kp / G16_BK;
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_all = p.Kp / G16_BK, per = (nk_all + gridDim.z - 1) / gridDim.z;   // split-K over blockIdx.z
+    const int kt0 = blockIdx.z * per, nk = min(kt0 + per, nk_all);
+    G16_GLOAD(kt0 * G16_BK)
+    for (int kt = kt0; kt < nk; ++kt) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             *reinterpret_cast<f16x8 *>(&As[pl][lr][lc * 8]) = ra[pl][0];
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
             const int frow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (frow < p.rows) {
                 const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
-                float *crow = p.C + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * 96 + (lane & 31);
+                float *crow = p.C + (long long)blockIdx.z * p.c_plane_elems + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * 96 + (lane & 31);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) crow[j * 32] = acc[i][j][r];
             }
@@ -200,24 +203,27 @@ template __global__ void k_srp_gemm_f16<false>(GemmArgs);
 template __global__ void k_srp_gemm_f16<true>(GemmArgs);
 
 // ---------------------------------------------------------------------------------------
-// v2 of the fp16 contraction for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction
-// is bound by how fast a CU can ingest operands from L2 (~10-13 B/clk/CU, ~18 GB/s/CU observed for any
-// ring depth, loader count or priority), not by the MFMA pipe: time = operand bytes per CU / ingest rate.
-// (A variant that computes the steering operand into LDS with sincospif + rotations instead of loading
-// it -- 2.5x fewer bytes per slice -- passed every parity test and ran at the SAME speed, so it is not the
-// byte count either: with 192 accumulator registers per lane there is no room to software-pipeline the
-// LDS fragment reads across the per-slice barrier, and that serialisation is what remains.)
-// The design goal is the fewest operand bytes per CU, i.e. the largest output tile the register
-// file can hold.  v1 (128 x 192 tiles, two workgroups per CU) moves 35 B per CU-cycle of MFMA work;
-// v2 holds a 256 x 384
-// output tile per workgroup (8 waves as 4 x 2, wave tile 64 x 192 = 2 x 6 MFMA tiles, 192
-// accumulator registers) -> 17 B/cycle, splits K over blockIdx.y (two partial maps, summed by the
-// scan kernel) so that 32 768 rows still give one workgroup per CU, and moves operands with
-// direct global->LDS loads (no staging registers, no ds_write) through a 3-stage ring of BK = 16
-// slices with ONE barrier per slice.  LDS rows are 32 B (two 16-B chunks); the physical chunk is
-// the logical one XOR ((row >> 3) & 1) -- applied on the per-lane SOURCE address of the LDS-DMA
-// and on the ds_read_b128 address -- which makes every 16-lane read group hit 16 distinct 4-bank
-// slots.
+// v2 of the fp16 contraction for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction is
+// bound by operand delivery into LDS, not by the MFMA pipe (ablation, ms per launch of the bench shape:
+// full 0.60, no MFMAs 0.43, no DMA 0.37).  The design goal is therefore the fewest
+// operand bytes per CU, i.e. the largest output tile the register file can hold, and request shapes the
+// memory system likes:
+//   * a 256 x 384 output tile per workgroup (8 waves as 4 x 2, wave tile 64 x 192 = 2 x 6 MFMA tiles, 192
+//     accumulator registers = 75 % of the CU's register file) -> 40 KB of operands per 16-deep slice;
+//     v1 (128 x 192 tiles, two workgroups per CU) moves twice that per flop;
+//   * K split over blockIdx.y (two partial maps, summed by the scan kernels) so that 32 768 rows still
+//     give one workgroup per CU;
+//   * operands by direct global->LDS loads (no staging registers, no ds_write) through a 3-stage ring of
+//     BK = 16 slices with ONE barrier per slice; the steering table is stored tiled [plane][slice][384][16]
+//     so that each of its DMA instructions is one contiguous KiB (out of a row-major table it is 32 pieces
+//     of 32 B: 0.26 ms instead of 0.16 ms per launch for B alone); A stays row-major because the tiled form
+//     costs its producer more than it saves here;
+//   * LDS rows are 32 B (two 16-B chunks); the physical chunk is the logical one XOR ((row >> 3) & 1) --
+//     applied on the per-lane SOURCE address of the LDS-DMA and on the ds_read_b128 address -- which makes
+//     every 16-lane read group hit 16 distinct 4-bank slots;
+//   * ROLL: B fragments in three rolling register slots (see the loop).
+// A variant that computed the steering operand into LDS with sincospif + rotations instead of loading it
+// passed every parity test and ran at the same speed (its VALU work took the place of the loads).
 // ---------------------------------------------------------------------------------------
 constexpr int V2_BM = 256, V2_BN = 384, V2_BK = 16, V2_ROWB = 32;
 

@@ -234,12 +234,38 @@ __device__ __forceinline__ float median3f(float a, float b, float c)
     return fmaxf(lo, fminf(hi, c));
 }
 
+// sum of the split-K partial maps at element o (plane 0 first: the same order for every kernel that reads C)
+__device__ __forceinline__ float csum(const float *C, long long o, int planes, long long stride)
+{
+    float v = C[o];
+    for (int pl = 1; pl < planes; ++pl) v += C[o + pl * stride];
+    return v;
+}
+
+// Folds the partial maps of a deep split-K contraction (small batches: up to 16 maps) into map 0, plane 0
+// first, four elements per thread; the scan kernels then read one map.  n4 = elements / 4.
+__global__ __launch_bounds__(256) void k_sum_planes(float *C, long long n4, int planes, long long stride)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 *c4 = reinterpret_cast<float4 *>(C);
+    const long long s4 = stride >> 2;
+    float4 acc = c4[i];
+    int pl = 1;
+    for (; pl + 3 < planes; pl += 4) {
+        const float4 a = c4[i + pl * s4], b = c4[i + (pl + 1) * s4], c = c4[i + (pl + 2) * s4], d = c4[i + (pl + 3) * s4];
+        acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x; acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
+        acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z; acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; pl < planes; ++pl) { const float4 a = c4[i + pl * s4]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+    c4[i] = acc;
+}
+
 __global__ __launch_bounds__(512) void k_scan_partial(ScanPickArgs p)
 {
     const int d = threadIdx.x, a = blockIdx.y, c = blockIdx.x;
     const int t_start = c * p.chunk, t_end = min(t_start + p.chunk, p.n_frames);
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
-    const float *C2 = p.C2 ? p.C2 + (long long)a * p.n_frames * p.Dp : nullptr;
     const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
     float b = 0.f;
     int nv = 0;
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(512) void k_scan_partial(ScanPickArgs p)
             for (int i = 0; i < 8; ++i) {
                 const int t = min(t0 + i, t_end - 1);
                 const long long o = (long long)t * p.Dp + d;
-                c8[i] = C2 ? C[o] + C2[o] : C[o];
+                c8[i] = csum(C, o, p.c_planes, p.c_plane_stride);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -301,7 +327,6 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
-    const float *C2 = p.C2 ? p.C2 + (long long)a * p.n_frames * p.Dp : nullptr;
     const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
     const float mn = -15.f * (float)p.P;
     float E = act ? p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d] : 0.f;
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 for (int i = 0; i < 8; ++i) {
                     const int t = min(t0 + i, te - 1);
                     const long long o = (long long)t * p.Dp + d;
-                    c8[i] = C2 ? C[o] + C2[o] : C[o];
+                    c8[i] = csum(C, o, p.c_planes, p.c_plane_stride);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -617,7 +642,7 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
         for (int t = warm_start; t < t_end; ++t) {
             const bool first = (p.frames_done + t) == 0;                // _corrMemoryFactor = 0 on the first frame
             const long long o = (long long)t * p.Dp + d;
-            const float r = p.C2 ? C[o] + (p.C2 + (long long)a * p.n_frames * p.Dp)[o] : C[o];
+            const float r = csum(C, o, p.c_planes, p.c_plane_stride);
             c = first ? r : (p.one_minus_mu * r + p.mu * c);            // :445-447
             if (t >= keep_start) sC[(t - keep_start) * Dl + d] = c;
             if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + t) * D + d] = c;

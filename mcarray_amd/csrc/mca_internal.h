@@ -67,8 +67,8 @@ struct GemmArgs {
 };
 
 struct ScanPickArgs {
-    const float *C;          // [arrays][n_frames][Dp]
-    const float *C2;         // second partial map of a split-K contraction (NULL if none)
+    const float *C;          // [c_planes][arrays][n_frames][Dp]: partial maps of a split-K contraction, summed here
+    int c_planes; long long c_plane_stride;
     int n_frames, Dp, D, P, S, chunk, n_chunks;
     float mu, one_minus_mu;
     const float *state_in;   // [arrays][D]  E_prev at entry
@@ -114,8 +114,8 @@ struct BeamformArgs {
 };
 
 struct Gcc2ScanArgs {
-    const float *C;          // [arrays][n_frames][Dp] un-smoothed GCC-PHAT R_t[d]
-    const float *C2;         // second partial map of a split-K contraction (NULL if none)
+    const float *C;          // [c_planes][arrays][n_frames][Dp] un-smoothed GCC-PHAT R_t[d] (split-K partial maps, summed here)
+    int c_planes; long long c_plane_stride;
     int n_frames, Dp, D, chunk;
     long long frames_done;   // frames this context has processed before this call (0 = stream start)
     float mu, one_minus_mu;  // _maxCorrMemoryFactor 0.8f and 1 - 0.8f (float arithmetic)
