@@ -522,7 +522,11 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         const int nf = (int)std::min<long long>(fc, n_frames - f0);
         StftPhatArgs sa{};
         sa.pcm = pcm; sa.array_stride = array_stride; sa.mic_stride = mic_stride;
-        sa.M = c->M; sa.n_frames = nf; sa.frame0 = f0; sa.fpb = 8;
+        sa.M = c->M; sa.n_frames = nf; sa.frame0 = f0;
+        // frames per workgroup: 8 amortises the table set-up and the shared half frames; small batches take fewer
+        // so that a few hundred workgroups exist
+        sa.fpb = 8;
+        while (sa.fpb > 1 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 256) sa.fpb >>= 1;
         sa.power = c->cfg.use_power_floor ? c->d_power : nullptr; sa.total_frames = n_frames;
         sa.window = c->d_window; sa.A = c->d_A; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
@@ -650,7 +654,11 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     hipStream_t st = (hipStream_t)stream;
     BeamformArgs ba{};
     ba.pcm = pcm; ba.array_stride = array_stride; ba.mic_stride = mic_stride;
-    ba.M = c->M; ba.Mpad = c->M; ba.S = c->S; ba.n_frames = n_frames; ba.ft = 16; ba.fs = c->cfg.sample_rate;
+    ba.M = c->M; ba.Mpad = c->M; ba.S = c->S; ba.n_frames = n_frames; ba.fs = c->cfg.sample_rate;
+    // frames per run: every run re-analyses one extra frame for its overlap-add carry, so long runs are cheaper per
+    // frame; small batches take shorter runs so that a few hundred workgroups exist (multiples of the 4-frame batch)
+    ba.ft = 16;
+    while (ba.ft > BF_NB && (long long)n_arrays * ((n_frames + ba.ft - 1) / ba.ft) < 256) ba.ft >>= 1;
     ba.window = c->d_window; ba.mic_x = c->d_micx; ba.doa_rad = doa_rad; ba.out = out_pcm;
     ba.tail_in = c->d_tail[c->tail_cur]; ba.tail_out = c->d_tail[c->tail_cur ^ 1];
     ba.N = c->N; ba.logH = c->logH; ba.tw = c->d_tw;
