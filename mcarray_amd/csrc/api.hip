@@ -6,6 +6,7 @@
 #include "../../include/mcarray_hip.h"
 #include "fft512.h"
 #include "kernels.h"
+#include "stage.h"
 
 #include <cmath>
 #include <cstdio>
@@ -66,6 +67,7 @@ struct mca_hip_ctx {
     int *d_bins = nullptr;
     double *d_out64 = nullptr; size_t out64_elems = 0;
     std::vector<double> h_stage;
+    StagePool stage;              // device staging of the host-pointer entry points
     // timing
     bool timing = false;
     std::vector<TimedEvent> events;
@@ -115,6 +117,7 @@ void free_ctx(mca_hip_ctx *c)
     F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
+    c->stage.release();
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pool) (void)hipEventDestroy(e);
     delete c;
@@ -715,29 +718,22 @@ int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, 
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const long long ms = (long long)(n_frames + 1) * c->H, as = ms * c->M;
     const size_t n_pcm = (size_t)as * n_arrays, n_fs = (size_t)n_arrays * n_frames * c->S;
-    float *d_pcm = nullptr, *d_rad = nullptr, *d_prob = nullptr, *d_en = nullptr, *d_out = nullptr;
-    int *d_bin = nullptr;
-    int rc = MCA_HIP_OK;
-    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_rad); (void)hipFree(d_prob); (void)hipFree(d_en); (void)hipFree(d_out); (void)hipFree(d_bin); };
-#define TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(c, MCA_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
-    TRY2(hipMalloc((void **)&d_pcm, n_pcm * 4));
-    TRY2(hipMalloc((void **)&d_bin, n_fs * 4));
-    TRY2(hipMalloc((void **)&d_rad, n_fs * 4));
-    TRY2(hipMalloc((void **)&d_prob, n_fs * 4));
-    if (energy) TRY2(hipMalloc((void **)&d_en, (size_t)n_arrays * n_frames * c->D * 4));
-    if (out_pcm) TRY2(hipMalloc((void **)&d_out, (size_t)n_arrays * c->S * n_frames * c->H * 4));
-    TRY2(hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
-    rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
+    const size_t n_en = energy ? (size_t)n_arrays * n_frames * c->D : 0, n_out = out_pcm ? (size_t)n_arrays * c->S * n_frames * c->H : 0;
+    float *d_pcm = (float *)c->stage.get(0, n_pcm * 4), *d_rad = (float *)c->stage.get(2, n_fs * 4), *d_prob = (float *)c->stage.get(3, n_fs * 4);
+    float *d_en = (float *)c->stage.get(4, n_en * 4), *d_out = (float *)c->stage.get(5, n_out * 4);
+    int *d_bin = (int *)c->stage.get(1, n_fs * 4);
+    if (!d_pcm || !d_bin || !d_rad || !d_prob || (energy && !d_en) || (out_pcm && !d_out))
+        return fail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
+    HIP_TRY(c, hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
+    int rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
     if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
-    if (rc) { cleanup(); return rc; }
-    TRY2(hipDeviceSynchronize());
-    TRY2(hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
-    if (doa_rad) TRY2(hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
-    if (prob) TRY2(hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
-    if (energy) TRY2(hipMemcpy(energy, d_en, (size_t)n_arrays * n_frames * c->D * 4, hipMemcpyDeviceToHost));
-    if (out_pcm) TRY2(hipMemcpy(out_pcm, d_out, (size_t)n_arrays * c->S * n_frames * c->H * 4, hipMemcpyDeviceToHost));
-#undef TRY2
-    cleanup();
+    if (rc) return rc;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
+    if (doa_rad) HIP_TRY(c, hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
+    if (prob) HIP_TRY(c, hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
+    if (energy) HIP_TRY(c, hipMemcpy(energy, d_en, n_en * 4, hipMemcpyDeviceToHost));
+    if (out_pcm) HIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
     return MCA_HIP_OK;
 }
 
@@ -782,26 +778,20 @@ int mca_hip_gcc2_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int
     if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const long long ms = (long long)(n_frames + 1) * c->H, as = ms * c->M;
-    const size_t n_pcm = (size_t)as * n_arrays, n_f = (size_t)n_arrays * n_frames;
-    float *d_pcm = nullptr, *d_rad = nullptr, *d_prob = nullptr, *d_corr = nullptr;
-    int *d_idx = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_rad); (void)hipFree(d_prob); (void)hipFree(d_corr); (void)hipFree(d_idx); };
-#define TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(c, MCA_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
-    TRY2(hipMalloc((void **)&d_pcm, n_pcm * 4));
-    TRY2(hipMalloc((void **)&d_idx, n_f * 4));
-    TRY2(hipMalloc((void **)&d_rad, n_f * 4));
-    TRY2(hipMalloc((void **)&d_prob, n_f * 4));
-    if (corr) TRY2(hipMalloc((void **)&d_corr, n_f * c->D * 4));
-    TRY2(hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
-    int rc = mca_hip_gcc2_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_idx, d_rad, d_prob, d_corr, nullptr);
-    if (rc) { cleanup(); return rc; }
-    TRY2(hipDeviceSynchronize());
-    TRY2(hipMemcpy(argmax, d_idx, n_f * 4, hipMemcpyDeviceToHost));
-    if (doa_rad) TRY2(hipMemcpy(doa_rad, d_rad, n_f * 4, hipMemcpyDeviceToHost));
-    if (prob) TRY2(hipMemcpy(prob, d_prob, n_f * 4, hipMemcpyDeviceToHost));
-    if (corr) TRY2(hipMemcpy(corr, d_corr, n_f * c->D * 4, hipMemcpyDeviceToHost));
-#undef TRY2
-    cleanup();
+    const size_t n_pcm = (size_t)as * n_arrays, n_f = (size_t)n_arrays * n_frames, n_corr = corr ? n_f * c->D : 0;
+    float *d_pcm = (float *)c->stage.get(0, n_pcm * 4), *d_rad = (float *)c->stage.get(2, n_f * 4), *d_prob = (float *)c->stage.get(3, n_f * 4);
+    float *d_corr = (float *)c->stage.get(4, n_corr * 4);
+    int *d_idx = (int *)c->stage.get(1, n_f * 4);
+    if (!d_pcm || !d_idx || !d_rad || !d_prob || (corr && !d_corr))
+        return fail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
+    HIP_TRY(c, hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
+    const int rc = mca_hip_gcc2_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_idx, d_rad, d_prob, d_corr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(argmax, d_idx, n_f * 4, hipMemcpyDeviceToHost));
+    if (doa_rad) HIP_TRY(c, hipMemcpy(doa_rad, d_rad, n_f * 4, hipMemcpyDeviceToHost));
+    if (prob) HIP_TRY(c, hipMemcpy(prob, d_prob, n_f * 4, hipMemcpyDeviceToHost));
+    if (corr) HIP_TRY(c, hipMemcpy(corr, d_corr, n_corr * 4, hipMemcpyDeviceToHost));
     return MCA_HIP_OK;
 }
 

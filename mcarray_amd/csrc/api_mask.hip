@@ -4,6 +4,7 @@
 #include "../../include/mcarray_hip.h"
 #include "fft512.h"
 #include "kernels.h"
+#include "stage.h"
 
 #include <cmath>
 #include <cstring>
@@ -26,6 +27,7 @@ struct mca_hip_mask_ctx {
     double *d_H = nullptr, *d_thr = nullptr, *d_Q64 = nullptr, *d_noise64 = nullptr, *d_io = nullptr;   // d_io: L, R, outL, outR
     int *d_dec = nullptr;
     int first_call = 0;
+    StagePool stage;
     std::string err;
 };
 
@@ -79,6 +81,7 @@ void free_mask(mca_hip_mask_ctx *c)
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_mp); F(c->d_window); F(c->d_Q[0]); F(c->d_Q[1]); F(c->d_noise); F(c->d_tail[0]); F(c->d_tail[1]);
     F(c->d_H); F(c->d_thr); F(c->d_Q64); F(c->d_noise64); F(c->d_io); F(c->d_dec);
+    c->stage.release();
     delete c;
 }
 
@@ -229,20 +232,16 @@ int mca_hip_mask_frames_host(mca_hip_mask_ctx *c, const float *pcm, int n_stream
     if (n_streams < 1 || n_frames < 1) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_streams/n_frames < 1");
     MHIP_TRY(c, hipSetDevice(c->cfg.device));
     const long long cs = (long long)(n_frames + 1) * FFT_H, ss = 2 * cs;
-    float *d_pcm = nullptr, *d_out = nullptr; int *d_dec = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_out); (void)hipFree(d_dec); };
-#define TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return mfail(c, MCA_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
-    TRY2(hipMalloc((void **)&d_pcm, (size_t)ss * n_streams * 4));
-    TRY2(hipMalloc((void **)&d_out, (size_t)n_streams * 2 * n_frames * FFT_H * 4));
-    if (decisions) TRY2(hipMalloc((void **)&d_dec, (size_t)n_streams * n_frames * 45 * 4));
-    TRY2(hipMemcpy(d_pcm, pcm, (size_t)ss * n_streams * 4, hipMemcpyHostToDevice));
-    int rc = mca_hip_mask_frames_dev(c, d_pcm, ss, cs, n_streams, n_frames, d_out, d_dec, nullptr);
-    if (rc) { cleanup(); return rc; }
-    TRY2(hipDeviceSynchronize());
-    TRY2(hipMemcpy(out_pcm, d_out, (size_t)n_streams * 2 * n_frames * FFT_H * 4, hipMemcpyDeviceToHost));
-    if (decisions) TRY2(hipMemcpy(decisions, d_dec, (size_t)n_streams * n_frames * 45 * 4, hipMemcpyDeviceToHost));
-#undef TRY2
-    cleanup();
+    const size_t n_out = (size_t)n_streams * 2 * n_frames * FFT_H, n_dec = decisions ? (size_t)n_streams * n_frames * 45 : 0;
+    float *d_pcm = (float *)c->stage.get(0, (size_t)ss * n_streams * 4), *d_out = (float *)c->stage.get(1, n_out * 4);
+    int *d_dec = (int *)c->stage.get(2, n_dec * 4);
+    if (!d_pcm || !d_out || (decisions && !d_dec)) return mfail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
+    MHIP_TRY(c, hipMemcpy(d_pcm, pcm, (size_t)ss * n_streams * 4, hipMemcpyHostToDevice));
+    const int rc = mca_hip_mask_frames_dev(c, d_pcm, ss, cs, n_streams, n_frames, d_out, d_dec, nullptr);
+    if (rc) return rc;
+    MHIP_TRY(c, hipDeviceSynchronize());
+    MHIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
+    if (decisions) MHIP_TRY(c, hipMemcpy(decisions, d_dec, n_dec * 4, hipMemcpyDeviceToHost));
     return MCA_HIP_OK;
 }
 

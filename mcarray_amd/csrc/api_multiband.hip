@@ -4,6 +4,7 @@
 #include "../../include/mcarray_hip.h"
 #include "fft512.h"
 #include "kernels.h"
+#include "stage.h"
 
 #include <cmath>
 #include <cstring>
@@ -26,6 +27,7 @@ struct mca_hip_mb_ctx {
     // workspace
     float *d_raw = nullptr, *d_be = nullptr, *d_pf = nullptr, *d_ph = nullptr, *d_hprob = nullptr; int *d_hidx = nullptr;
     size_t ws_rows = 0;
+    StagePool stage;
     std::string err;
 };
 
@@ -54,6 +56,7 @@ void free_mb(mca_hip_mb_ctx *c)
     F(c->d_window); F(c->d_coef); F(c->d_grid); F(c->d_tw); F(c->d_T); F(c->d_lo); F(c->d_hi);
     F(c->d_corr[0]); F(c->d_corr[1]); F(c->d_gate); F(c->d_cur);
     F(c->d_raw); F(c->d_be); F(c->d_pf); F(c->d_ph); F(c->d_hprob); F(c->d_hidx);
+    c->stage.release();
     delete c;
 }
 
@@ -264,31 +267,25 @@ int mca_hip_mb_frames_host(mca_hip_mb_ctx *c, const float *pcm, int n_arrays, in
     BHIP_TRY(c, hipSetDevice(c->cfg.device));
     const long long cs = (long long)(n_frames + 1) * c->H, as = 2 * cs;
     const size_t nf = (size_t)n_arrays * n_frames;
-    float *d_pcm = nullptr, *d_rad = nullptr, *d_prob = nullptr, *d_pow = nullptr, *d_eid = nullptr, *d_bc = nullptr;
-    unsigned char *d_v = nullptr; int *d_bi = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_rad); (void)hipFree(d_prob); (void)hipFree(d_pow); (void)hipFree(d_eid); (void)hipFree(d_bc); (void)hipFree(d_v); (void)hipFree(d_bi); };
-#define TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return bfail(c, MCA_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
-    TRY2(hipMalloc((void **)&d_pcm, (size_t)as * n_arrays * 4));
-    TRY2(hipMalloc((void **)&d_rad, nf * 4));
-    TRY2(hipMalloc((void **)&d_prob, nf * 4));
-    TRY2(hipMalloc((void **)&d_pow, nf * 4));
-    TRY2(hipMalloc((void **)&d_v, nf));
-    if (band_idx) TRY2(hipMalloc((void **)&d_bi, nf * c->nb * 4));
-    if (energy_in_doa) TRY2(hipMalloc((void **)&d_eid, nf * c->D * 4));
-    if (band_corr) TRY2(hipMalloc((void **)&d_bc, nf * c->nb * c->D * 4));
-    TRY2(hipMemcpy(d_pcm, pcm, (size_t)as * n_arrays * 4, hipMemcpyHostToDevice));
-    int rc = mca_hip_mb_frames_dev(c, d_pcm, as, cs, n_arrays, n_frames, d_rad, d_prob, d_v, d_pow, d_bi, d_eid, d_bc, nullptr);
-    if (rc) { cleanup(); return rc; }
-    TRY2(hipDeviceSynchronize());
-    TRY2(hipMemcpy(doa_rad, d_rad, nf * 4, hipMemcpyDeviceToHost));
-    TRY2(hipMemcpy(prob, d_prob, nf * 4, hipMemcpyDeviceToHost));
-    if (voiced) TRY2(hipMemcpy(voiced, d_v, nf, hipMemcpyDeviceToHost));
-    if (power) TRY2(hipMemcpy(power, d_pow, nf * 4, hipMemcpyDeviceToHost));
-    if (band_idx) TRY2(hipMemcpy(band_idx, d_bi, nf * c->nb * 4, hipMemcpyDeviceToHost));
-    if (energy_in_doa) TRY2(hipMemcpy(energy_in_doa, d_eid, nf * c->D * 4, hipMemcpyDeviceToHost));
-    if (band_corr) TRY2(hipMemcpy(band_corr, d_bc, nf * c->nb * c->D * 4, hipMemcpyDeviceToHost));
-#undef TRY2
-    cleanup();
+    const size_t n_bi = band_idx ? nf * c->nb : 0, n_eid = energy_in_doa ? nf * c->D : 0, n_bc = band_corr ? nf * c->nb * c->D : 0;
+    float *d_pcm = (float *)c->stage.get(0, (size_t)as * n_arrays * 4), *d_rad = (float *)c->stage.get(1, nf * 4);
+    float *d_prob = (float *)c->stage.get(2, nf * 4), *d_pow = (float *)c->stage.get(3, nf * 4);
+    unsigned char *d_v = (unsigned char *)c->stage.get(4, nf);
+    int *d_bi = (int *)c->stage.get(5, n_bi * 4);
+    float *d_eid = (float *)c->stage.get(6, n_eid * 4), *d_bc = (float *)c->stage.get(7, n_bc * 4);
+    if (!d_pcm || !d_rad || !d_prob || !d_pow || !d_v || (band_idx && !d_bi) || (energy_in_doa && !d_eid) || (band_corr && !d_bc))
+        return bfail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
+    BHIP_TRY(c, hipMemcpy(d_pcm, pcm, (size_t)as * n_arrays * 4, hipMemcpyHostToDevice));
+    const int rc = mca_hip_mb_frames_dev(c, d_pcm, as, cs, n_arrays, n_frames, d_rad, d_prob, d_v, d_pow, d_bi, d_eid, d_bc, nullptr);
+    if (rc) return rc;
+    BHIP_TRY(c, hipDeviceSynchronize());
+    BHIP_TRY(c, hipMemcpy(doa_rad, d_rad, nf * 4, hipMemcpyDeviceToHost));
+    BHIP_TRY(c, hipMemcpy(prob, d_prob, nf * 4, hipMemcpyDeviceToHost));
+    if (voiced) BHIP_TRY(c, hipMemcpy(voiced, d_v, nf, hipMemcpyDeviceToHost));
+    if (power) BHIP_TRY(c, hipMemcpy(power, d_pow, nf * 4, hipMemcpyDeviceToHost));
+    if (band_idx) BHIP_TRY(c, hipMemcpy(band_idx, d_bi, n_bi * 4, hipMemcpyDeviceToHost));
+    if (energy_in_doa) BHIP_TRY(c, hipMemcpy(energy_in_doa, d_eid, n_eid * 4, hipMemcpyDeviceToHost));
+    if (band_corr) BHIP_TRY(c, hipMemcpy(band_corr, d_bc, n_bc * 4, hipMemcpyDeviceToHost));
     return MCA_HIP_OK;
 }
 
