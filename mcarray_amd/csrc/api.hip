@@ -574,9 +574,8 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
                 hipLaunchKernelGGL(K, gv, dim3(512), smem, st, ga);                                                       \
             } while (0)
-            static const bool roll = std::getenv("MCA_HIP_GEMM_NOROLL") == nullptr;    // A/B switch for measurements
-            if (c->prec == MCA_HIP_SRP_FP16X3) { if (roll) V2_LAUNCH((k_srp_gemm_f16_v2<true, 8, 3, true>)); else V2_LAUNCH((k_srp_gemm_f16_v2<true, 8, 3, false>)); }
-            else { if (roll) V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3, true>)); else V2_LAUNCH((k_srp_gemm_f16_v2<false, 8, 3, false>)); }
+            if (c->prec == MCA_HIP_SRP_FP16X3) V2_LAUNCH((k_srp_gemm_f16_v2<true>));
+            else V2_LAUNCH((k_srp_gemm_f16_v2<false>));
 #undef V2_LAUNCH
         } else {
             dim3 g2((ga.rows + 127) / 128, c->Dp / 192, ksplit);

@@ -17,7 +17,7 @@ __global__ void k_beamform_gen(BeamformArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);
 template <bool SPLIT> __global__ void k_srp_gemm_f16(GemmArgs p);
-template <bool SPLIT, int NLOAD, int NSTAGE, bool ROLL> __global__ void k_srp_gemm_f16_v2(GemmArgs p);
+template <bool SPLIT> __global__ void k_srp_gemm_f16_v2(GemmArgs p);
 
 template <typename T> struct C2;
 template <typename T>

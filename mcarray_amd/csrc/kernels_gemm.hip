@@ -221,7 +221,7 @@ template __global__ void k_srp_gemm_f16<true>(GemmArgs);
 //   * LDS rows are 32 B (two 16-B chunks); the physical chunk is the logical one XOR ((row >> 3) & 1) --
 //     applied on the per-lane SOURCE address of the LDS-DMA and on the ds_read_b128 address -- which makes
 //     every 16-lane read group hit 16 distinct 4-bank slots;
-//   * ROLL: B fragments in three rolling register slots (see the loop).
+//   * B fragments in three rolling register slots (see the loop).
 // A variant that computed the steering operand into LDS with sincospif + rotations instead of loading it
 // passed every parity test and ran at the same speed (its VALU work took the place of the loads).
 // ---------------------------------------------------------------------------------------
@@ -229,10 +229,11 @@ constexpr int V2_BM = 256, V2_BN = 384, V2_BK = 16, V2_ROWB = 32;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <bool SPLIT, int NLOAD, int NSTAGE, bool ROLL>
+template <bool SPLIT>
 __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
 {
     constexpr int NP = SPLIT ? 2 : 1;
+    constexpr int NSTAGE = 3;
     constexpr int A_BYTES = V2_BM * V2_ROWB, B_BYTES = V2_BN * V2_ROWB;      // per plane
     constexpr int STAGE = NP * (A_BYTES + B_BYTES);
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g[];
@@ -248,19 +249,16 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     const int s_beg = blockIdx.y * per, s_end = min(s_beg + per, nslices);
     const int ns = s_end - s_beg;
 
-    // Operand movement: waves 0..3 are the LOADERS.  Each LDS-DMA instruction moves 32 rows x 32 B;
-    // loader w owns row blocks w, w+4, ... of every region (2 per A plane, 3 per B plane).  The other
-    // four waves go straight to their MFMAs, so on every SIMD (waves w and w+4 share one) the loader's
-    // DMA issue overlaps its partner's matrix work instead of both stalling in lock-step.
-    // The A workspace is allocated in multiples of 256 rows, so no row clamp is needed.
-    const bool loader = wave < NLOAD;
+    // Operand movement: every wave loads.  One LDS-DMA instruction moves 32 rows x 32 B (lane = row pair x
+    // 16-B chunk); per slice and plane wave w moves A row block w (of 8) and B row block w (of 12), waves
+    // 0..3 also B row block w + 8.  The A workspace is allocated in multiples of 256 rows, so no row clamp.
     const int lr = (wave & 3) * 32 + (lane >> 1);
     const int lc = (lane & 1) ^ ((lane >> 4) & 1);             // logical chunk stored at this lane's physical position
-    const unsigned char *a_lane = A + ((long long)(row0 + lr) * p.a_row_elems + lc * 8) * 2;
-    const unsigned char *b_lane = B + lr * V2_ROWB + lc * 16;
-    const long long a_blk = (long long)128 * p.a_row_elems * 2, a_pl = (long long)p.Kp * 2;
-    const long long b_blk = 128 * V2_ROWB, b_pl = (long long)(p.Kp / V2_BK) * B_BYTES;
-    const int dst_lane_blk = (wave & 3) * 1024;
+    const int hi = wave >> 2;                                  // which 128-row half of the A / B region this wave fills
+    const unsigned char *a_lane = A + ((long long)(row0 + lr + 128 * hi) * p.a_row_elems + lc * 8) * 2;
+    const unsigned char *b_lane = B + (lr + 128 * hi) * V2_ROWB + lc * 16;
+    const long long a_pl = (long long)p.Kp * 2, b_pl = (long long)nslices * B_BYTES;
+    const int dst_lane_blk = (wave & 3) * 1024 + hi * 4096;
 
     f32x16 acc[2][6];
 #pragma unroll
@@ -270,146 +268,89 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // NLOAD == 4: loader w moves A blocks {w, w+4} and B blocks {w, w+4, w+8} of every plane (5 * NP instructions);
-    // NLOAD == 8: every wave moves A block w and B block w of every plane, waves 0..3 also B block w+8.
     auto issue = [&](int s, int buf) {
-        const long long koff = (long long)(s_beg + s) * V2_BK * 2;
+        const long long koff_a = (long long)(s_beg + s) * V2_BK * 2;
         const long long koff_b = (long long)(s_beg + s) * B_BYTES;
         unsigned char *sb = smem_g + buf * STAGE + dst_lane_blk;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            if constexpr (NLOAD == 4) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + i * a_blk + koff),
-                                                     (lds_void_t *)(sb + pl * A_BYTES + i * 4096), 16, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + i * b_blk + koff_b),
-                                                     (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + i * 4096), 16, 0, 0);
-            } else {
-                const int hi = wave >> 2;                       // 0: blocks w, 1: blocks w (= (w&3)+4)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + hi * a_blk + koff),
-                                                 (lds_void_t *)(sb + pl * A_BYTES + hi * 4096), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + hi * b_blk + koff_b),
-                                                 (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + hi * 4096), 16, 0, 0);
-                if (wave < 4)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + 2 * b_blk + koff_b),
-                                                     (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + 2 * 4096), 16, 0, 0);
-            }
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + koff_a),
+                                             (lds_void_t *)(sb + pl * A_BYTES), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + koff_b),
+                                             (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES), 16, 0, 0);
+            if (wave < 4)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + 256 * V2_ROWB + koff_b),
+                                                 (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + 8192), 16, 0, 0);
         }
     };
 
-    // fragment byte offsets inside a plane (slice-independent)
-    int a_off[2], b_off[6];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wm * 64 + i * 32 + (lane & 31);
-        a_off[i] = r * V2_ROWB + (((lane >> 5) ^ ((r >> 3) & 1)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int r = wn * 192 + j * 32 + (lane & 31);
-        b_off[j] = r * V2_ROWB + (((lane >> 5) ^ ((r >> 3) & 1)) << 4);
-    }
+    // fragment byte offsets inside a plane (slice-independent); row blocks are 32 rows = 1 KiB apart
+    const int ra = wm * 64 + (lane & 31), rb = wn * 192 + (lane & 31);
+    const int a_off0 = ra * V2_ROWB + (((lane >> 5) ^ ((ra >> 3) & 1)) << 4);
+    const int b_off0 = rb * V2_ROWB + (((lane >> 5) ^ ((rb >> 3) & 1)) << 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t *)smem_g);
 
-    if (loader) {
 #pragma unroll
-        for (int q = 0; q < NSTAGE - 1; ++q)
-            if (q < ns) issue(q, q);
-    }
+    for (int q = 0; q < NSTAGE - 1; ++q)
+        if (q < ns) issue(q, q);
     for (int s = 0; s < ns; ++s) {
-        // slice s has landed once at most the loads of the NSTAGE-2 younger slices in flight are outstanding
-        // (per wave and slice: NLOAD == 4: 5 * NP; NLOAD == 8: at least 2 * NP -- waiting for the smaller count is safe)
-        {
-            constexpr int PERW = (NLOAD == 4 ? 5 : 2) * NP;
-            const int younger = min(NSTAGE - 2, ns - 1 - s);
-            if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERW) : "memory");
-            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERW) : "memory");
-            else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PERW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PERW) : "memory");
-        }
+        // slice s has landed once at most the loads of the NSTAGE-2 = 1 younger slice in flight are outstanding
+        // (a wave issues 2 * NP or 3 * NP loads per slice: waiting for the smaller count is safe)
+        if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (loader && s + NSTAGE - 1 < ns) issue(s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);   // that buffer was last read in slice s-1
-        const unsigned char *st = smem_g + (s % NSTAGE) * STAGE;
-        f16x8 af[NP][2];
-        if constexpr (ROLL) {
-            // Rolling B fragments: three register slots.  All of A and column blocks 0..2 are requested up front;
-            // as soon as the MFMAs of block j have issued, block j+3 is requested into the slot they read.  The
-            // LDS reads of a slice are thereby spread under the matrix work instead of two read-then-compute
-            // phases in which all eight waves hit the LDS at once while the matrix cores idle.
-            // The reads and their waits are inline asm: the compiler waits for lgkmcnt(0) before every MFMA
-            // group (it does not count outstanding ds_read_b128), which would re-serialise the schedule.  LDS
-            // reads of one wave return in order, so "at most N younger reads outstanding" is exact; every wait
-            // lists the registers it releases as in/out operands so that nothing can read them earlier.
-            f16x8 bs[3][NP];
-            const unsigned a_addr = (unsigned)(uintptr_t)((lds_void_t *)(st)) + a_off[0];
-            const unsigned b_addr = (unsigned)(uintptr_t)((lds_void_t *)(st)) + NP * A_BYTES + b_off[0];
+        if (s + NSTAGE - 1 < ns) issue(s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);   // that buffer was last read in slice s-1
+        // Rolling B fragments: three register slots.  All of A and column blocks 0..2 are requested up front;
+        // as soon as the MFMAs of block j have issued, block j+3 is requested into the slot they read.  The
+        // LDS reads of a slice are thereby spread under the matrix work instead of read-then-compute phases
+        // in which all eight waves hit the LDS at once while the matrix cores idle.
+        // The reads and their waits are inline asm: the compiler waits for lgkmcnt(0) before every MFMA
+        // group (it does not count outstanding ds_read_b128), which would re-serialise the schedule.  LDS
+        // reads of one wave return in order, so "at most N younger reads outstanding" is exact; every wait
+        // lists the registers it releases as in/out operands so that nothing can read them earlier.
+        f16x8 af[NP][2], bs[3][NP];
+        const unsigned a_addr = lds0 + (s % NSTAGE) * STAGE + a_off0;
+        const unsigned b_addr = lds0 + (s % NSTAGE) * STAGE + NP * A_BYTES + b_off0;
 #define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                LDS_RD(af[pl][0], a_addr, pl * A_BYTES);
-                LDS_RD(af[pl][1], a_addr, pl * A_BYTES + 32 * V2_ROWB);
+        for (int pl = 0; pl < NP; ++pl) {
+            LDS_RD(af[pl][0], a_addr, pl * A_BYTES);
+            LDS_RD(af[pl][1], a_addr, pl * A_BYTES + 32 * V2_ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j][pl], b_addr, pl * B_BYTES + j * 32 * V2_ROWB);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            // younger reads allowed in flight while block j computes: blocks j+1, j+2 (NP reads each)
+            constexpr int Y2 = 2 * NP, Y1 = NP;
+            if constexpr (SPLIT) {
+                if (j == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]) : "n"(Y2));
+                else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y2));
+                else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y1));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]));
+                // small terms first so they are not absorbed by the large partial sum
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][1], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][1], acc[1][j], 0, 0, 0);
+            } else {
+                if (j == 0) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bs[0][0]) : "n"(Y2));
+                else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y2));
+                else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y1));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]));
             }
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 3 < 6) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j][pl], b_addr, pl * B_BYTES + j * 32 * V2_ROWB);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                // younger reads allowed in flight while block j computes: blocks j+1, j+2 (NP reads each)
-                constexpr int Y2 = 2 * NP, Y1 = NP;
-                if constexpr (SPLIT) {
-                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]) : "n"(Y2));
-                    else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y2));
-                    else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y1));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]));
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][1], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][1], acc[1][j], 0, 0, 0);
-                } else {
-                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bs[0][0]) : "n"(Y2));
-                    else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y2));
-                    else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y1));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]));
-                }
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + 3 < 6) {
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j % 3][pl], b_addr, pl * B_BYTES + (j + 3) * 32 * V2_ROWB);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j % 3][pl], b_addr, pl * B_BYTES + (j + 3) * 32 * V2_ROWB);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #undef LDS_RD
-        } else {
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[pl][i] = *reinterpret_cast<const f16x8 *>(st + pl * A_BYTES + a_off[i]);
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-            f16x8 bf[NP][3];
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) bf[pl][jj] = *reinterpret_cast<const f16x8 *>(st + NP * A_BYTES + pl * B_BYTES + b_off[jh * 3 + jj]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) {
-                    const int j = jh * 3 + jj;
-                    if constexpr (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][jj], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][jj], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][jj], acc[i][j], 0, 0, 0);
-                }
-        }
-        }
     }
     float *Cp = p.C + (long long)blockIdx.y * p.c_plane_elems;
 #pragma unroll
@@ -426,9 +367,7 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
         }
 }
 
-template __global__ void k_srp_gemm_f16_v2<true, 8, 3, false>(GemmArgs);
-template __global__ void k_srp_gemm_f16_v2<false, 8, 3, false>(GemmArgs);
-template __global__ void k_srp_gemm_f16_v2<true, 8, 3, true>(GemmArgs);
-template __global__ void k_srp_gemm_f16_v2<false, 8, 3, true>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<true>(GemmArgs);
+template __global__ void k_srp_gemm_f16_v2<false>(GemmArgs);
 
 }  // namespace mca

@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256) void k_mask_frame(MaskFrameArgs p)
 {
     __shared__ double sred[4];
     __shared__ double sg[2];
-    __shared__ int sdec;
     const int tid = threadIdx.x, K = p.K, Kh = K - 1;    // Kh = N/2 complex bins = "first N doubles"
     const double dK = (double)K, dKh = (double)Kh;
     if (p.method == 5) return;                            // NOTHING :130-134
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(256) void k_mask_frame(MaskFrameArgs p)
                     gL = pl > 0 ? p.noise[b] / pl : 1; gR = pr > 0 ? p.noise[b] / pr : 1;
                 }
             }
-            sg[0] = gL; sg[1] = gR; sdec = dec;
+            sg[0] = gL; sg[1] = gR;
             if (p.decisions) p.decisions[b] = dec;
         }
         __syncthreads();
