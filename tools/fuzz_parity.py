@@ -1,0 +1,69 @@
+"""Randomised parity sweep of the stream API against the CPU oracle (a one-off check, not part of the test suite):
+random channel counts, geometries, frame lengths, frame counts, DOA grids, source counts, SRP precisions, chunked calls.
+usage (GPU box): python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcarray_amd import api, synth  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4}
+# a DOA-bin difference is a numerical tie if the ORACLE's normalised energies at the two bins are closer than this
+TIE = {api.SRP_FP32: 1e-5, api.SRP_FP16X3: 1e-5, api.SRP_FP16: 2e-4}
+
+
+def main(cases, seed):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(cases):
+        M = int(rng.choice([2, 3, 4, 5, 8, 8, 8, 16]))
+        ula = bool(rng.integers(0, 2))
+        xs = (0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))
+        fs, N = [(8000, 256), (16000, 512), (48000, 1024), (48000, 1024), (48000, 1024), (96000, 2048)][int(rng.integers(0, 6))]
+        step = float(rng.choice([5.0, 3.0, 1.0, 0.5]))
+        S = int(rng.integers(1, 3))
+        A = int(rng.integers(1, 4))
+        F = int(rng.integers(1, 200))
+        prec = [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16][int(rng.integers(0, 3))]
+        gate = bool(rng.integers(0, 4) == 0)
+        pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(rng.uniform(-80, 80)), fs, (F + 1) * N // 2, int(rng.integers(1, 1 << 30)))
+                        for _ in range(A)]).astype(np.float32)
+        tag = "case %d: M=%d %s fs=%d N=%d step=%.1f S=%d A=%d F=%d prec=%d gate=%d" % (case, M, "ula" if ula else "irr", fs, N, step, S, A, F, prec, gate)
+        try:
+            ctx = api.Context(fs, xs, N, step, S, use_power_floor=gate, srp_precision=prec, max_arrays=A)
+            cut = int(rng.integers(0, F)) if F > 1 and rng.integers(0, 2) else 0
+            hop = N // 2
+            if cut:
+                ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * hop], want_energy=True)
+                rb = ctx.process_frames_host(pcm[:, :, cut * hop:], want_energy=True)
+                r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out")}
+            else:
+                r = ctx.process_frames_host(pcm, want_energy=True)
+            ties = 0
+            for a in range(A):
+                o = po.ssl_stream_gated(fs, N, xs, pcm[a].astype(np.float64), S, step, gate)
+                scale = np.abs(o["energy"]).max() + 1e-300
+                err = np.abs(r["energy"][a] - o["energy"]).max() / scale
+                assert err <= TOL_E[prec], "energy error %.2e" % err
+                mism = np.argwhere(r["bin"][a] != o["bin"])
+                for t, s_ in mism:
+                    g, ob = int(r["bin"][a, t, s_]), int(o["bin"][t, s_])
+                    En = (o["energy"][t] + 15.0 * ctx.P) / (30.0 * ctx.P)
+                    assert abs(En[g] - En[ob]) < TIE[prec], "bin %d vs %d at frame %d (oracle energies differ by %.1e)" % (g, ob, t, abs(En[g] - En[ob]))
+                    ties += 1
+                oe = np.abs(r["out"][a] - o["out"]).max()
+                assert oe <= 2e-5 * np.abs(o["out"]).max() + 1e-7, "audio error %.2e" % oe
+            print("ok  ", tag, "ties", ties, "cut", cut)
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("FAIL", tag, "--", e)
+    print("%d cases, %d failures" % (cases, bad))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
