@@ -54,6 +54,8 @@ def main(cases, seed):
                     En = (o["energy"][t] + 15.0 * ctx.P) / (30.0 * ctx.P)
                     assert abs(En[g] - En[ob]) < TIE[prec], "bin %d vs %d at frame %d (oracle energies differ by %.1e)" % (g, ob, t, abs(En[g] - En[ob]))
                     ties += 1
+                if len(mism):
+                    continue            # a flipped near-tie steers the beamformer elsewhere: the audio is not comparable
                 oe = np.abs(r["out"][a] - o["out"]).max()
                 assert oe <= 2e-5 * np.abs(o["out"]).max() + 1e-7, "audio error %.2e" % oe
             print("ok  ", tag, "ties", ties, "cut", cut)
