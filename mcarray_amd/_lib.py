@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcarray_hip.so")
+LIB_PATH = os.environ.get("MCA_HIP_LIB", os.path.join(_HERE, "libmcarray_hip.so"))   # MCA_HIP_LIB: A/B builds side by side
 
 c_dp = C.POINTER(C.c_double)
 c_fp = C.POINTER(C.c_float)
