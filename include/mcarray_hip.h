@@ -98,6 +98,15 @@ int mca_hip_get_doa_grid(const mca_hip_ctx *ctx, float *out);
 int mca_hip_reset(mca_hip_ctx *ctx, void *stream);
 /* pre-size the internal workspace so later *_dev calls allocate nothing (graph capture) */
 int mca_hip_reserve(mca_hip_ctx *ctx, int n_arrays, int n_frames);
+/* Checkpoint / resume of everything a module object carries between process() calls, for all max_arrays
+ * arrays: E_prev (SteeringBeamforming.h:69), the overlap-add tails, the power-floor estimation
+ * (SoundLocalisationImpl.h:84-86), _currentDOA / _prob (BeamformingSeparationAndLocalisation.cpp:51-52), the 2-mic
+ * path's smoothed DOA and frame count, the frame API's E_prev.  A blob is only valid for a context created with
+ * the same geometry, grid, frame length, n_sources and max_arrays (checked: MCA_HIP_ERR_INVALID_ARGUMENT).
+ * mca_hip_state_size returns the number of bytes (or a negative status). */
+long long mca_hip_state_size(const mca_hip_ctx *ctx);
+int mca_hip_state_save(mca_hip_ctx *ctx, void *blob, long long blob_bytes);
+int mca_hip_state_load(mca_hip_ctx *ctx, const void *blob, long long blob_bytes);
 
 /* ---- stream API: batched frames, device pointers ---------------------------- */
 /* STFT analysis + SteeringBeamforming::processFrame (SteeringBeamforming.cpp:96-195) for

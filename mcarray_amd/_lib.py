@@ -74,6 +74,9 @@ SYMBOLS = [
     ("mca_hip_get_doa_grid", C.c_int, [C.c_void_p, c_fp]),
     ("mca_hip_reset", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mca_hip_reserve", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("mca_hip_state_size", C.c_longlong, [C.c_void_p]),
+    ("mca_hip_state_save", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    ("mca_hip_state_load", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
     ("mca_hip_localise_frames_dev", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
       C.c_void_p, C.c_void_p]),

@@ -89,6 +89,16 @@ class Context:
     def reserve(self, n_arrays, n_frames):
         self._check(self._lib.mca_hip_reserve(self.h, n_arrays, n_frames))
 
+    def state_save(self):
+        """checkpoint of the per-array stream state (E_prev, overlap-add tails, gate, last DOA ...) as bytes"""
+        n = self._lib.mca_hip_state_size(self.h)
+        buf = C.create_string_buffer(n)
+        self._check(self._lib.mca_hip_state_save(self.h, buf, n))
+        return buf.raw
+
+    def state_load(self, blob):
+        self._check(self._lib.mca_hip_state_load(self.h, blob, len(blob)))
+
     # ---- stream API, host buffers ----
     def process_frames_host(self, pcm, want_energy=False, want_audio=True):
         """pcm float32 [A][M][(F+1)*hop] -> dict(bin [A][F][S], doa, prob, energy [A][F][D], out [A][S][F*hop])"""

@@ -503,6 +503,77 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     return init_last_state(c, st);
 }
 
+namespace {
+
+struct StateHeader {
+    unsigned magic; int version, M, D, S, H, max_arrays, use_floor;
+    unsigned delays_hash;            // FNV-1a of the float delay tables: geometry + sample rate + grid
+    long long gcc2_frames_done;
+};
+constexpr unsigned STATE_MAGIC = 0x4d434153u;   // "MCAS"
+
+unsigned delays_hash(const mca_hip_ctx *c)
+{
+    unsigned h = 2166136261u;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(c->delays.data());
+    for (size_t i = 0; i < c->delays.size() * sizeof(float); ++i) { h ^= p[i]; h *= 16777619u; }
+    return h;
+}
+
+// the device buffers that make up the state, in blob order (current halves of the double buffers)
+struct StatePart { void *ptr; size_t bytes; };
+std::vector<StatePart> state_parts(mca_hip_ctx *c)
+{
+    const size_t na = (size_t)c->cfg.max_arrays;
+    return {
+        {c->d_E[c->e_cur], na * c->D * 4}, {c->d_tail[c->tail_cur], na * c->S * c->H * 4}, {c->d_gate_state, na * 4 * 8},
+        {c->d_last_bin, na * MCA_MAX_SOURCES * 4}, {c->d_last_rad, na * MCA_MAX_SOURCES * 4}, {c->d_last_prob, na * MCA_MAX_SOURCES * 4},
+        {c->d_doa[c->doa_cur], na * 4}, {c->d_E64[c->e64_cur], (size_t)c->D * 8},
+    };
+}
+
+}  // namespace
+
+long long mca_hip_state_size(const mca_hip_ctx *c)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    long long n = sizeof(StateHeader);
+    for (const StatePart &p : state_parts(const_cast<mca_hip_ctx *>(c))) n += (long long)p.bytes;
+    return n;
+}
+
+int mca_hip_state_save(mca_hip_ctx *c, void *blob, long long blob_bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!blob || blob_bytes < mca_hip_state_size(c)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is NULL or smaller than mca_hip_state_size()");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    StateHeader h{STATE_MAGIC, 1, c->M, c->D, c->S, c->H, c->cfg.max_arrays, c->cfg.use_power_floor, delays_hash(c), c->gcc2_frames_done};
+    unsigned char *out = static_cast<unsigned char *>(blob);
+    std::memcpy(out, &h, sizeof(h)); out += sizeof(h);
+    for (const StatePart &p : state_parts(c)) { HIP_TRY(c, hipMemcpy(out, p.ptr, p.bytes, hipMemcpyDeviceToHost)); out += p.bytes; }
+    return MCA_HIP_OK;
+}
+
+int mca_hip_state_load(mca_hip_ctx *c, const void *blob, long long blob_bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!blob || blob_bytes < (long long)sizeof(StateHeader)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is NULL or truncated");
+    StateHeader h;
+    std::memcpy(&h, blob, sizeof(h));
+    if (h.magic != STATE_MAGIC || h.version != 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "not a state blob of this library version");
+    if (h.M != c->M || h.D != c->D || h.S != c->S || h.H != c->H || h.max_arrays != c->cfg.max_arrays || h.use_floor != c->cfg.use_power_floor ||
+        h.delays_hash != delays_hash(c))
+        return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob was saved by a context with a different configuration");
+    if (blob_bytes < mca_hip_state_size(c)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is truncated");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    const unsigned char *in = static_cast<const unsigned char *>(blob) + sizeof(h);
+    for (const StatePart &p : state_parts(c)) { HIP_TRY(c, hipMemcpy(p.ptr, in, p.bytes, hipMemcpyHostToDevice)); in += p.bytes; }
+    c->gcc2_frames_done = h.gcc2_frames_done;
+    return MCA_HIP_OK;
+}
+
 int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     if (!c || n_arrays < 1 || n_frames < 1) return MCA_HIP_ERR_INVALID_ARGUMENT;

@@ -530,3 +530,30 @@ def test_source_localisation_is_the_analysis_only_sibling():
     o = po.ssl_stream(fs, 1024, xs, pcm.astype(np.float64), 2, 5.0, want_map=True, want_audio=False)
     _assert_bins(r["bin"][0], o["bin"], o["energy"], 6, max_ties=1)
     np.testing.assert_allclose(np.array([g[0] for g in got]), np.rad2deg(r["doa"][0].astype(np.float64)), rtol=0, atol=0)
+
+
+def test_state_save_and_load_resume_a_stream():
+    # checkpoint after the first half of a gated 2-source stream, resume in a NEW context: identical to one run
+    fs, N, F = 48000, 1024, 220
+    xs = synth.REEM_C
+    pcm = _gated_signal(xs, fs, F, 9)
+    one = api.Context(fs, xs, N, 5.0, 2, use_power_floor=True)
+    r = one.process_frames_host(pcm[None], want_energy=True)
+    a = api.Context(fs, xs, N, 5.0, 2, use_power_floor=True)
+    cut = 160                                        # inside the first burst, after the floor estimation
+    ra = a.process_frames_host(pcm[None, :, :(cut + 1) * 512], want_energy=True)
+    blob = a.state_save()
+    a.close()
+    b = api.Context(fs, xs, N, 5.0, 2, use_power_floor=True)
+    b.state_load(blob)
+    rb = b.process_frames_host(pcm[None, :, cut * 512:], want_energy=True)
+    for k in ("voiced", "bin", "doa", "prob"):
+        assert np.array_equal(np.concatenate([ra[k], rb[k]], axis=1), r[k]), k
+    np.testing.assert_allclose(np.concatenate([ra["energy"], rb["energy"]], axis=1), r["energy"], rtol=0, atol=1e-6 * np.abs(r["energy"]).max())
+    np.testing.assert_allclose(np.concatenate([ra["out"], rb["out"]], axis=2), r["out"], rtol=0, atol=1e-6)
+    # a blob from another configuration is refused
+    other = api.Context(fs, xs, N, 3.0, 2, use_power_floor=True)
+    with pytest.raises(api.MCArrayHipError, match="different configuration"):
+        other.state_load(blob)
+    with pytest.raises(api.MCArrayHipError):
+        b.state_load(blob[:100])

@@ -1,0 +1,50 @@
+"""Throughput of the stream API for shapes other than the official bench workload (not a bench line: a survey).
+usage (GPU box): python tools/bench_shapes.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcarray_amd import api, synth  # noqa: E402
+
+
+def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10):
+    xs = {2: synth.BINAURAL, 4: synth.REEM_C, 8: synth.ULA8, 16: synth.ULA16}[M]
+    dev = torch.device("cuda", 0)
+    hop = N // 2
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    pcm = (torch.randn(A, M, (F + 1) * hop, device=dev, generator=g) * 0.1).contiguous()
+    ctx = api.Context(fs, xs, N, step, S, srp_precision=prec, max_arrays=A)
+    doa_bin = torch.empty(A, F, S, dtype=torch.int32, device=dev)
+    doa_rad = torch.empty(A, F, S, dtype=torch.float32, device=dev)
+    prob = torch.empty(A, F, S, dtype=torch.float32, device=dev)
+    out = torch.empty(A, S, F * hop, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=st)
+    torch.cuda.synchronize()
+    ctx.set_timing(True); ctx.reset_timing()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kt = {name: round(ctx.get_timing(kid)[1] / max(ctx.get_timing(kid)[0], 1), 3) for kid, name in api.KERNEL_NAMES.items() if ctx.get_timing(kid)[0]}
+    print("M=%2d fs=%6d N=%4d D=%3d S=%d  %3d arrays x %5d frames: %6.2f M frames/s  %.3f ms/step  %s" %
+          (M, fs, N, ctx.D, S, A, F, A * F / dt / 1e6, dt * 1e3, kt))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    run(8, 48000, 1024, 0.5, 8, 4096)
+    run(8, 48000, 1024, 5.0, 8, 4096)
+    run(8, 48000, 1024, 0.5, 8, 4096, S=2)
+    run(16, 48000, 1024, 0.5, 8, 2048)
+    run(4, 48000, 1024, 0.5, 8, 4096)
+    run(2, 16000, 1024, 3.0, 32, 4096)
+    run(8, 16000, 512, 0.5, 8, 4096)
+    run(8, 96000, 2048, 0.5, 8, 2048)
+    run(8, 48000, 1024, 0.5, 128, 256)
