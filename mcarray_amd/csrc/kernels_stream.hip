@@ -7,7 +7,7 @@
 //
 // Data layout in HBM: PCM fp32 channel-major [array][mic][sample] (coalesced float2 loads along
 // time); A operand [frame][Kp] with Kp = roundup(G*1026, 32), flat index (g*513 + k)*2 + {re,im};
-// correlation map C [array][frame][Dp] fp32.  (Kp = roundup(G*KG*2, 32) with KG = 520 slots per group.)
+// correlation map C [split-K plane][array][frame][Dp] fp32.
 #include "fft512.h"
 #include "mca_internal.h"
 
