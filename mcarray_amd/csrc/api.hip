@@ -746,8 +746,9 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         c->tail_cur ^= 1;
         return MCA_HIP_OK;
     }
-    const size_t smem = ((size_t)ba.M + BF_NB * c->S) * FFT_SCRATCH * sizeof(float2) + (size_t)c->S * c->M * 49 * sizeof(float2) +
-                        TW_WORDS * sizeof(float2) + (size_t)BF_NB * c->M * (1 + c->S) * sizeof(float2) +
+    ba.nb = std::max(1, BF_NB / c->S);      // 4 beamformed slots in LDS whatever the number of sources
+    const size_t smem = ((size_t)ba.M + ba.nb * c->S) * FFT_SCRATCH * sizeof(float2) + (size_t)c->S * c->M * 49 * sizeof(float2) +
+                        TW_WORDS * sizeof(float2) + (size_t)ba.nb * c->M * (1 + c->S) * sizeof(float2) +
                         (size_t)(ba.ft + 1) * c->S * sizeof(double);
     if (smem > 160 * 1024) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "n_mics/n_sources combination exceeds the 160 KiB LDS of a CU");
     dim3 g((n_frames + ba.ft - 1) / ba.ft, n_arrays);

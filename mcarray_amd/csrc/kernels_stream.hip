@@ -461,7 +461,7 @@ __global__ __launch_bounds__(1024) void k_doa_fill(DoaFillArgs p)
 // k_beamform_ola
 // --------------------------------------------------------------------------------------
 // grid (frame runs, arrays), 512 threads.  A run is FT frames plus the frame before it (whose
-// second half is the overlap-add carry).  Frames are handled in batches of BF_NB: per frame the 8
+// second half is the overlap-add carry).  Frames are handled in batches of p.nb (<= BF_NB): per frame the 8
 // waves transform the channels and thread k applies the delay-and-sum to bin k < 512 with the
 // steering phasors factored as exp(j k s) = hi[k >> 5] * lo[k & 31] (49 sincos per channel and
 // frame instead of 513; the reference regenerates the whole ramp per frame, Beamformer.cpp:59-60);
@@ -474,12 +474,13 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int M = p.M, S = p.S, a = blockIdx.y;
     float2 *xs = reinterpret_cast<float2 *>(smem_raw);                 // [M][FFT_SCRATCH] channel spectra
-    float2 *ys = xs + M * FFT_SCRATCH;                                  // [BF_NB*S][FFT_SCRATCH] beamformed slots
-    float2 *steer = ys + BF_NB * S * FFT_SCRATCH;                       // [S][M][49] steering phasors (lo 0..31, hi 32..48)
+    const int NB = p.nb;
+    float2 *ys = xs + M * FFT_SCRATCH;                                  // [NB*S][FFT_SCRATCH] beamformed slots
+    float2 *steer = ys + NB * S * FFT_SCRATCH;                       // [S][M][49] steering phasors (lo 0..31, hi 32..48)
     float2 *tab = steer + S * M * 49;                                   // [TW_WORDS]
-    float2 *xn = tab + TW_WORDS;                                        // [BF_NB][M] Nyquist bins of the batch
-    float2 *pn = xn + BF_NB * M;                                        // [BF_NB][S][M] their steering phasors
-    double *cdoa = reinterpret_cast<double *>(pn + BF_NB * S * M);      // [ft+1][S] cos(DOA + pi/2) of the run
+    float2 *xn = tab + TW_WORDS;                                        // [NB][M] Nyquist bins of the batch
+    float2 *pn = xn + NB * M;                                           // [NB][S][M] their steering phasors
+    double *cdoa = reinterpret_cast<double *>(pn + NB * S * M);      // [ft+1][S] cos(DOA + pi/2) of the run
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = blockIdx.x * p.ft;
     const int t1 = min(t0 + p.ft, p.n_frames);
@@ -518,8 +519,8 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
     const double unit = (double)p.fs / (double)FFT_N / 346.1;          // Beamformer.cpp:59 without 2 pi
     const float inv = 1.0f / (float)M;
 
-    for (int tb = tfirst; tb < t1; tb += BF_NB) {
-        const int nb = min(BF_NB, t1 - tb);
+    for (int tb = tfirst; tb < t1; tb += NB) {
+        const int nb = min(NB, t1 - tb);
         for (int j = 0; j < nb; ++j) {
             const int t = tb + j;
             // the table only changes when a source moved to another steering angle: sources are slow

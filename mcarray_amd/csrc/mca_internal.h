@@ -102,6 +102,7 @@ struct BeamformArgs {
     const float *pcm;
     long long array_stride, mic_stride;
     int M, Mpad, S, n_frames, ft, fs;
+    int nb;                  // frames per inverse-FFT batch (<= BF_NB; fewer with several sources so that two workgroups still share a CU)
     const float *window;
     const double *mic_x;     // [M] x coordinate (Beamformer.cpp:59 steers with x only)
     const float *doa_rad;    // [arrays][n_frames][S]

@@ -39,6 +39,10 @@ def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sources":
+        for S in (1, 2, 3, 4):
+            run(8, 48000, 1024, 0.5, 8, 4096, S=S)
+        sys.exit(0)
     run(8, 48000, 1024, 0.5, 8, 4096)
     run(8, 48000, 1024, 5.0, 8, 4096)
     run(8, 48000, 1024, 0.5, 8, 4096, S=2)
