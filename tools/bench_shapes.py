@@ -38,7 +38,32 @@ def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10):
     ctx.close()
 
 
+def run_two_channel():
+    """host-pointer calls of the 2-channel modules on batches already in host memory (kernel time by HIP events is not
+    exposed for these contexts; the figure includes the PCIe copies, so it is a lower bound of the device rate)"""
+    rng = np.random.default_rng(0)
+    for name, make, call in (
+        ("FastBinauralMasking 16 kHz", lambda A: api.FastBinauralMasking(16000, 0.086, 500.0, 5000.0, max_streams=A), lambda m, x: m.process(x, want_decisions=False)),
+        ("MultibandBinarualLocalisation 48 kHz, 15 bands", lambda A: api.MultibandBinarualLocalisation(48000, synth.BINAURAL, 15, False, max_arrays=A), lambda m, x: m.process(x)),
+        ("FreqGCCBinauralLocalisation 16 kHz", lambda A: api.FreqGCCBinauralLocalisation(16000, synth.BINAURAL, False, 3.0, max_arrays=A), lambda m, x: m.process(x)),
+    ):
+        A, F = 64, 1024
+        m = make(A)
+        hop = m.hop if hasattr(m, "hop") else m.ctx.hop
+        x = (rng.standard_normal((A, 2, (F + 1) * hop)) * 0.1).astype(np.float32)
+        for _ in range(2):
+            call(m, x)
+        t0 = time.perf_counter(); n = 5
+        for _ in range(n):
+            call(m, x)
+        dt = (time.perf_counter() - t0) / n
+        print("%-50s %3d streams x %4d frames: %6.2f M frames/s incl. host copies (%.2f ms per call)" % (name, A, F, A * F / dt / 1e6, dt * 1e3))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "two":
+        run_two_channel()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sources":
         for S in (1, 2, 3, 4):
             run(8, 48000, 1024, 0.5, 8, 4096, S=S)
