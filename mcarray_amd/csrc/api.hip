@@ -208,6 +208,16 @@ void time_end(mca_hip_ctx *c, hipStream_t st)
     (void)hipEventRecord(c->events.back().b, st);
 }
 
+// threads per workgroup of the any-length kernels, measured per frame length (a workgroup's spectra fill half a
+// CU's LDS from N = 2048 on, so more waves per workgroup are the only way to more waves per CU): analysis
+// 256 / 1024 / 1024, synthesis 256 / 512 / 1024 threads for N <= 1024 / 2048 / 4096+
+int gen_threads(const mca_hip_ctx *c, bool synthesis)
+{
+    if (c->N >= 4096) return 1024;
+    if (c->N >= 2048) return synthesis ? 512 : 1024;
+    return 256;
+}
+
 // which contraction kernel a chunk of `rows` frames runs on, and over how many workgroups its K range is split
 struct GemmPlan { bool v2; int ksplit; };
 GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
@@ -611,7 +621,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             do {                                                                                                          \
                 if (smem1 > 64 * 1024)                                                                                    \
                     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1)); \
-                hipLaunchKernelGGL(K, dim3(nf, n_arrays), dim3(256), smem1, st, sa);                                      \
+                hipLaunchKernelGGL(K, dim3(nf, n_arrays), dim3(gen_threads(c, false)), smem1, st, sa);                                      \
             } while (0)
             if (c->prec == MCA_HIP_SRP_FP32) GEN_LAUNCH(k_stft_phat_gen<float>);
             else GEN_LAUNCH(k_stft_phat_gen<_Float16>);
@@ -740,7 +750,7 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         if (smem > 64 * 1024)
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_beamform_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         time_begin(c, MCA_HIP_K_BEAMFORM, st);
-        hipLaunchKernelGGL(k_beamform_gen, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(256), smem, st, ba);
+        hipLaunchKernelGGL(k_beamform_gen, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(gen_threads(c, true)), smem, st, ba);
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
         c->tail_cur ^= 1;

@@ -15,29 +15,31 @@
 
 namespace mca {
 
+// threads per workgroup of the any-length kernels: blockDim.x (256 ... 1024, chosen by the host per frame length)
+
 // --------------------------------------------------------------------------------------
-// k_stft_phat_gen: grid (frames of the chunk, arrays), 256 threads, LDS = M * (H + 1) float2 (+ 4 floats)
+// k_stft_phat_gen: grid (frames of the chunk, arrays), 256 ... 1024 threads, LDS = M * (H + 1) float2 (+ 4 floats)
 // --------------------------------------------------------------------------------------
 template <typename OutT>
-__global__ __launch_bounds__(256) void k_stft_phat_gen(StftPhatArgs p)
+__global__ __launch_bounds__(1024) void k_stft_phat_gen(StftPhatArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int M = p.M, logH = p.logH, H = 1 << logH, zs = H + 1;
     float2 *xs = reinterpret_cast<float2 *>(smem_raw);                  // [M][H + 1]
     float *spow = reinterpret_cast<float *>(xs + M * zs);               // [1]
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
     const int a = blockIdx.y, f = blockIdx.x;
     const float *base = p.pcm + (long long)a * p.array_stride;
     if (tid == 0) spow[0] = 0.f;
 
-    load_frames(xs, zs, M, logH, base, p.mic_stride, (long long)p.frame0 + f, p.window, tid, 256);
-    block_fft_dit(xs, zs, M, logH, p.tw, p.N, tid, 256);
-    split_forward(xs, zs, M, logH, p.tw, tid, 256);
+    load_frames(xs, zs, M, logH, base, p.mic_stride, (long long)p.frame0 + f, p.window, tid, NT);
+    block_fft_dit(xs, zs, M, logH, p.tw, p.N, tid, NT);
+    split_forward(xs, zs, M, logH, p.tw, tid, NT);
 
     if (p.power) {
         // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
         float acc = 0.f;
-        for (int k = tid; k <= H; k += 256) {
+        for (int k = tid; k <= H; k += NT) {
             float s = 0.f;
             for (int m = 0; m < M; ++m) { const float2 z = xs[m * zs + k]; s += z.x * z.x + z.y * z.y; }
             acc += (k == 0 || k == H) ? s : 2.f * s;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_stft_phat_gen(StftPhatArgs p)
     // PHAT whitening in place (each thread its own bins), then the pair products of those bins
     OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f) * (long long)p.a_row_elems;
     const int kg = p.kg;
-    for (int k = tid; k <= H; k += 256) {
+    for (int k = tid; k <= H; k += NT) {
         for (int m = 0; m < M; ++m) xs[m * zs + k] = whiten_g(xs[m * zs + k]);
         if (p.ula) {
             for (int g = 0; g < M - 1; ++g) {
@@ -73,12 +75,12 @@ template __global__ void k_stft_phat_gen<float>(StftPhatArgs);
 template __global__ void k_stft_phat_gen<_Float16>(StftPhatArgs);
 
 // --------------------------------------------------------------------------------------
-// k_beamform_gen: grid (runs of ft frames, arrays), 256 threads,
+// k_beamform_gen: grid (runs of ft frames, arrays), 256 ... 1024 threads,
 // LDS = (M + S) * (H + 1) float2 + S * H floats (overlap-add carry) + (ft + 1) * S doubles
 // --------------------------------------------------------------------------------------
 // A run starts one frame early (tfirst = t0 - 1) to rebuild the overlap-add carry the previous run
 // leaves; the very first run of a call takes it from tail_in and the last one leaves it in tail_out.
-__global__ __launch_bounds__(256) void k_beamform_gen(BeamformArgs p)
+__global__ __launch_bounds__(1024) void k_beamform_gen(BeamformArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int M = p.M, S = p.S, a = blockIdx.y, logH = p.logH, H = 1 << logH, zs = H + 1;
@@ -86,16 +88,16 @@ __global__ __launch_bounds__(256) void k_beamform_gen(BeamformArgs p)
     float2 *ys = xs + M * zs;                                           // [S][H + 1]
     float *carry = reinterpret_cast<float *>(ys + S * zs);             // [S][H]
     double *cdoa = reinterpret_cast<double *>(carry + S * H + ((S * H) & 1));   // [ft + 1][S]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
     const int t0 = blockIdx.x * p.ft;
     const int t1 = min(t0 + p.ft, p.n_frames);
     const int tfirst = t0 > 0 ? t0 - 1 : 0;
 
-    for (int e = tid; e < (t1 - tfirst) * S; e += 256) {
+    for (int e = tid; e < (t1 - tfirst) * S; e += NT) {
         const double doa = (double)p.doa_rad[((long long)a * p.n_frames + tfirst) * S + e];
         cdoa[e] = cos(doa + 1.57079632679489661923);                    // cos(DOA + M_PI/2), Beamformer.cpp:59
     }
-    for (int e = tid; e < S * H; e += 256) carry[e] = t0 == 0 ? p.tail_in[(long long)a * S * H + e] : 0.f;
+    for (int e = tid; e < S * H; e += NT) carry[e] = t0 == 0 ? p.tail_in[(long long)a * S * H + e] : 0.f;
     __syncthreads();
 
     const float *base = p.pcm + (long long)a * p.array_stride;
@@ -104,11 +106,11 @@ __global__ __launch_bounds__(256) void k_beamform_gen(BeamformArgs p)
     const float sc = 1.0f / (float)H;
 
     for (int t = tfirst; t < t1; ++t) {
-        load_frames(xs, zs, M, logH, base, p.mic_stride, (long long)t, p.window, tid, 256);
-        block_fft_dit(xs, zs, M, logH, p.tw, p.N, tid, 256);
-        split_forward(xs, zs, M, logH, p.tw, tid, 256);
+        load_frames(xs, zs, M, logH, base, p.mic_stride, (long long)t, p.window, tid, NT);
+        block_fft_dit(xs, zs, M, logH, p.tw, p.N, tid, NT);
+        split_forward(xs, zs, M, logH, p.tw, tid, NT);
         // delay-and-sum: Y[k] = (1/M) sum_c X_c[k] exp(j 2 pi k unit x_c cos(DOA + pi/2))
-        for (int e = tid; e < S * (H + 1); e += 256) {
+        for (int e = tid; e < S * (H + 1); e += NT) {
             const int s = e / (H + 1), k = e - s * (H + 1);
             const double cd = cdoa[(t - tfirst) * S + s];
             float2 acc = make_float2(0.f, 0.f);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_beamform_gen(BeamformArgs p)
         }
         __syncthreads();
         // one-sided spectrum -> packed Z (imaginary parts of DC and Nyquist ignored, like a CCS inverse)
-        for (int e = tid; e < S * (H / 2 + 1); e += 256) {
+        for (int e = tid; e < S * (H / 2 + 1); e += NT) {
             const int s = e / (H / 2 + 1), k = e - s * (H / 2 + 1);
             float2 *yy = ys + s * zs;
             float2 xk = yy[k], xp = yy[H - k];
@@ -135,9 +137,9 @@ __global__ __launch_bounds__(256) void k_beamform_gen(BeamformArgs p)
             if (k != 0 && k != H - k) yy[H - k] = make_float2(ev.x + od.y, -ev.y + od.x);   // conj(E) + j conj(O)
         }
         __syncthreads();
-        block_ifft_dif(ys, zs, S, logH, p.tw, p.N, tid, 256);
+        block_ifft_dif(ys, zs, S, logH, p.tw, p.N, tid, NT);
         // overlap-add: y[2n], y[2n+1] = Re, Im of z[n] / H, z[n] stored at bitrev(n)
-        for (int e = tid; e < S * (H / 2); e += 256) {
+        for (int e = tid; e < S * (H / 2); e += NT) {
             const int s = e / (H / 2), n = e - s * (H / 2);              // sample pair (2n, 2n+1) of the hop
             const float2 lo = ys[s * zs + (int)(__brev((unsigned)n) >> (32 - logH))];
             const float2 hi = ys[s * zs + (int)(__brev((unsigned)(n + H / 2)) >> (32 - logH))];
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_beamform_gen(BeamformArgs p)
         __syncthreads();
     }
     if (t1 == p.n_frames)
-        for (int e = tid; e < S * H; e += 256) p.tail_out[(long long)a * S * H + e] = carry[e];
+        for (int e = tid; e < S * H; e += NT) p.tail_out[(long long)a * S * H + e] = carry[e];
 }
 
 }  // namespace mca
