@@ -518,6 +518,10 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
 
     const double unit = (double)p.fs / (double)FFT_N / 346.1;          // Beamformer.cpp:59 without 2 pi
     const float inv = 1.0f / (float)M;
+    const bool one_source = CPW == 1 && S == 1 && M <= 8;
+    float2 phc[8];                                                      // one_source: this bin's steering phasor per channel
+#pragma unroll
+    for (int c = 0; c < 8; ++c) phc[c] = make_float2(1.f, 0.f);
 
     for (int tb = tfirst; tb < t1; tb += NB) {
         const int nb = min(NB, t1 - tb);
@@ -563,6 +567,20 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
             // delay-and-sum: Y[k] = (1/M) sum_c X_c[k] exp(j k s_c), s_c = 2 pi unit x_c cos(DOA+pi/2)
             {
                 const int k = tid;   // bins 0..511
+                if (one_source) {
+                    // one source, <= 8 channels: this thread's bin never changes, so its phasors stay in registers
+                    // until the source moves (8 LDS reads per frame instead of 24)
+                    if (!same) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (c < M) phc[c] = cmul(steer[c * 49 + 32 + (k >> 5)], steer[c * 49 + (k & 31)]);
+                    }
+                    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < M) acc = cmac(acc, xs[c * FFT_SCRATCH + k], phc[c]);
+                    ys[j * FFT_SCRATCH + k] = make_float2(acc.x * inv, acc.y * inv);             // divC :70
+                } else
                 for (int s = 0; s < S; ++s) {
                     float2 acc = make_float2(0.f, 0.f);
                     for (int c = 0; c < M; ++c) {
