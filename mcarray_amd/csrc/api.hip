@@ -177,15 +177,14 @@ int build_steering_table(mca_hip_ctx *c)
         HIP_TRY(c, hipMalloc(&c->d_B, B.size() * sizeof(_Float16)));
         HIP_TRY(c, hipMemcpy(c->d_B, B.data(), B.size() * sizeof(_Float16), hipMemcpyHostToDevice));
         if (Dp == 384) {
-            // the same table tiled for the 256 x 384 kernel: one 16-deep K slice of all 384 columns is 12 KiB
-            // contiguous, so every LDS-DMA instruction of that kernel moves one contiguous KiB (32 rows x 32 B
-            // pieces out of the row-major table cost 0.26 ms per launch instead of 0.16 ms)
-            const int ns = Kp / 16;
+            // the same table tiled for the 256 x 384 kernel: one 32-deep K stage of all 384 columns is 24 KiB
+            // contiguous, so every LDS-DMA instruction of that kernel moves one contiguous KiB
+            const int ns32 = Kp / 32;
             std::vector<_Float16> Bt(B.size());
             for (int pl = 0; pl < planes; ++pl)
-                for (int sl = 0; sl < ns; ++sl)
+                for (int sl = 0; sl < ns32; ++sl)
                     for (int d = 0; d < Dp; ++d)
-                        std::memcpy(&Bt[(((size_t)pl * ns + sl) * Dp + d) * 16], &B[((size_t)pl * Dp + d) * Kp + (size_t)sl * 16], 16 * sizeof(_Float16));
+                        std::memcpy(&Bt[(((size_t)pl * ns32 + sl) * Dp + d) * 32], &B[((size_t)pl * Dp + d) * Kp + (size_t)sl * 32], 32 * sizeof(_Float16));
             HIP_TRY(c, hipMalloc(&c->d_Bt, Bt.size() * sizeof(_Float16)));
             HIP_TRY(c, hipMemcpy(c->d_Bt, Bt.data(), Bt.size() * sizeof(_Float16), hipMemcpyHostToDevice));
         }
@@ -648,7 +647,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         time_begin(c, MCA_HIP_K_SRP_GEMM, st);
         if (v2) {
             const int np = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
-            const size_t smem = (size_t)3 * np * (256 + 384) * 32;
+            const size_t smem = (size_t)2 * np * (256 + 384) * 64;        // two 32-deep stages: all 160 KiB with hi + lo planes
             dim3 gv((ga.rows + 255) / 256, ksplit);
 #define V2_LAUNCH(K)                                                                                                      \
             do {                                                                                                          \

@@ -203,62 +203,67 @@ template __global__ void k_srp_gemm_f16<false>(GemmArgs);
 template __global__ void k_srp_gemm_f16<true>(GemmArgs);
 
 // ---------------------------------------------------------------------------------------
-// v2 of the fp16 contraction for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction is
-// bound by operand delivery into LDS, not by the MFMA pipe (ablation, ms per launch of the bench shape:
-// full 0.60, no MFMAs 0.43, no DMA 0.37).  The design goal is therefore the fewest
-// operand bytes per CU, i.e. the largest output tile the register file can hold, and request shapes the
-// memory system likes:
+// The 256 x 384 contraction kernel for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction is
+// bound by operand delivery into LDS, not by the MFMA pipe (ablation of its 16-deep predecessor, ms per launch
+// of the bench shape: full 0.60, no MFMAs 0.43, no DMA 0.37).  The design goal is therefore
+// the fewest operand bytes per CU, i.e. the largest output tile the register file can hold, and request shapes
+// the memory system likes:
 //   * a 256 x 384 output tile per workgroup (8 waves as 4 x 2, wave tile 64 x 192 = 2 x 6 MFMA tiles, 192
-//     accumulator registers = 75 % of the CU's register file) -> 40 KB of operands per 16-deep slice;
-//     v1 (128 x 192 tiles, two workgroups per CU) moves twice that per flop;
+//     accumulator registers = 75 % of the CU's register file); the 128 x 192 kernels above (two workgroups
+//     per CU) move twice the bytes per flop;
 //   * K split over blockIdx.y (two partial maps, summed by the scan kernels) so that 32 768 rows still
 //     give one workgroup per CU;
-//   * operands by direct global->LDS loads (no staging registers, no ds_write) through a 3-stage ring of
-//     BK = 16 slices with ONE barrier per slice; the steering table is stored tiled [plane][slice][384][16]
-//     so that each of its DMA instructions is one contiguous KiB (out of a row-major table it is 32 pieces
-//     of 32 B: 0.26 ms instead of 0.16 ms per launch for B alone); A stays row-major because the tiled form
-//     costs its producer more than it saves here;
-//   * LDS rows are 32 B (two 16-B chunks); the physical chunk is the logical one XOR ((row >> 3) & 1) --
-//     applied on the per-lane SOURCE address of the LDS-DMA and on the ds_read_b128 address -- which makes
-//     every 16-lane read group hit 16 distinct 4-bank slots;
-//   * B fragments in three rolling register slots (see the loop).
+//   * operands by direct global->LDS loads (no staging registers, no ds_write) through a two-stage ring of
+//     32-deep K stages that uses the whole 160 KiB of LDS, ONE barrier per stage.  The stage depth is about
+//     the request shape: out of the row-major A a 16-deep stage gives every LDS-DMA instruction 32 pieces of
+//     32 B, a 32-deep stage 16 pieces of 64 B (0.49 -> 0.46 ms per launch).  The steering table is stored
+//     tiled per stage ([plane][stage][384][32]) so that each of its DMA instructions is one contiguous KiB (out
+//     of a row-major table: 0.26 instead of 0.16 ms per launch for B alone); A stays row-major because a tiled
+//     A costs its producer more than it saves here;
+//   * LDS rows are 64 B = four 16-B chunks; the physical chunk is the logical one XOR ((row >> 2) & 3) --
+//     applied on the per-lane SOURCE address of the LDS-DMA and on the ds_read_b128 address -- which makes the
+//     16 rows of a read group hit 16 distinct 4-bank slots;
+//   * B fragments in two rolling register slots (see the loop).
 // A variant that computed the steering operand into LDS with sincospif + rotations instead of loading it
 // passed every parity test and ran at the same speed (its VALU work took the place of the loads).
 // ---------------------------------------------------------------------------------------
-constexpr int V2_BM = 256, V2_BN = 384, V2_BK = 16, V2_ROWB = 32;
+constexpr int V2_BM = 256, V2_BN = 384;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int V3_BK = 32, V3_ROWB = 64;
 
 template <bool SPLIT>
 __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
 {
     constexpr int NP = SPLIT ? 2 : 1;
-    constexpr int NSTAGE = 3;
-    constexpr int A_BYTES = V2_BM * V2_ROWB, B_BYTES = V2_BN * V2_ROWB;      // per plane
-    constexpr int STAGE = NP * (A_BYTES + B_BYTES);
+    constexpr int A_BYTES = V2_BM * V3_ROWB, B_BYTES = V2_BN * V3_ROWB;      // per plane: 16 KiB, 24 KiB
+    constexpr int STAGE = NP * (A_BYTES + B_BYTES);                         // 80 KiB (SPLIT)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int row0 = blockIdx.x * V2_BM;
     const unsigned char *A = reinterpret_cast<const unsigned char *>(p.A);
-    const unsigned char *B = reinterpret_cast<const unsigned char *>(p.Bt);   // tiled table [plane][slice][384][16]
+    const unsigned char *B = reinterpret_cast<const unsigned char *>(p.Bt);  // [plane][stage][384][32]
 
-    // K slices of this workgroup
-    const int nslices = p.Kp / V2_BK;
-    const int per = (nslices + gridDim.y - 1) / gridDim.y;
-    const int s_beg = blockIdx.y * per, s_end = min(s_beg + per, nslices);
+    const int nst_all = p.Kp / V3_BK;
+    const int per = (nst_all + gridDim.y - 1) / gridDim.y;
+    const int s_beg = blockIdx.y * per, s_end = min(s_beg + per, nst_all);
     const int ns = s_end - s_beg;
 
-    // Operand movement: every wave loads.  One LDS-DMA instruction moves 32 rows x 32 B (lane = row pair x
-    // 16-B chunk); per slice and plane wave w moves A row block w (of 8) and B row block w (of 12), waves
-    // 0..3 also B row block w + 8.  The A workspace is allocated in multiples of 256 rows, so no row clamp.
-    const int lr = (wave & 3) * 32 + (lane >> 1);
-    const int lc = (lane & 1) ^ ((lane >> 4) & 1);             // logical chunk stored at this lane's physical position
-    const int hi = wave >> 2;                                  // which 128-row half of the A / B region this wave fills
-    const unsigned char *a_lane = A + ((long long)(row0 + lr + 128 * hi) * p.a_row_elems + lc * 8) * 2;
-    const unsigned char *b_lane = B + (lr + 128 * hi) * V2_ROWB + lc * 16;
-    const long long a_pl = (long long)p.Kp * 2, b_pl = (long long)nslices * B_BYTES;
-    const int dst_lane_blk = (wave & 3) * 1024 + hi * 4096;
+    // one LDS-DMA instruction = 16 rows x 64 B: lane -> (row lane >> 2, physical chunk lane & 3)
+    const int lrow = lane >> 2, pch = lane & 3;
+    // A: 16 instructions per plane and stage, wave w takes row blocks w and w + 8 (16 rows each)
+    // B: 24 instructions per plane and stage, wave w takes row blocks w, w + 8, w + 16
+    // (the swizzle term (row >> 2) & 3 only depends on lrow: row blocks start at multiples of 16 rows, so one
+    // per-lane pointer per operand plus uniform block offsets is enough)
+    const int r0 = wave * 16 + lrow;
+    const int lch = pch ^ ((r0 >> 2) & 3);
+    const unsigned char *a_lane = A + ((long long)(row0 + r0) * p.a_row_elems + lch * 8) * 2;
+    const unsigned char *b_lane = B + r0 * V3_ROWB + lch * 16;
+    const long long a_blk = (long long)128 * p.a_row_elems * 2;                  // 8 row blocks of 16 rows further
+    const int dst0 = wave * 1024;
+    const long long a_pl = (long long)p.Kp * 2, b_pl = (long long)nst_all * B_BYTES;
 
     f32x16 acc[2][6];
 #pragma unroll
@@ -269,86 +274,82 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto issue = [&](int s, int buf) {
-        const long long koff_a = (long long)(s_beg + s) * V2_BK * 2;
+        const long long koff_a = (long long)(s_beg + s) * V3_BK * 2;
         const long long koff_b = (long long)(s_beg + s) * B_BYTES;
-        unsigned char *sb = smem_g + buf * STAGE + dst_lane_blk;
+        unsigned char *sb = smem_g + buf * STAGE;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + koff_a),
-                                             (lds_void_t *)(sb + pl * A_BYTES), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + koff_b),
-                                             (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES), 16, 0, 0);
-            if (wave < 4)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + 256 * V2_ROWB + koff_b),
-                                                 (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + 8192), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + pl * a_pl + i * a_blk + koff_a),
+                                                 (lds_void_t *)(sb + pl * A_BYTES + dst0 + i * 8192), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + pl * b_pl + i * (128 * V3_ROWB) + koff_b),
+                                                 (lds_void_t *)(sb + NP * A_BYTES + pl * B_BYTES + dst0 + i * 8192), 16, 0, 0);
         }
     };
 
-    // fragment byte offsets inside a plane (slice-independent); row blocks are 32 rows = 1 KiB apart
+    // fragment addresses: lane (row l & 31, k half l >> 5); k-step kk of the stage is logical chunk 2 kk + (l >> 5);
+    // row blocks are 32 rows = 2 KiB apart, and the swizzle term (row >> 2) & 3 is the same for rows 32 apart
     const int ra = wm * 64 + (lane & 31), rb = wn * 192 + (lane & 31);
-    const int a_off0 = ra * V2_ROWB + (((lane >> 5) ^ ((ra >> 3) & 1)) << 4);
-    const int b_off0 = rb * V2_ROWB + (((lane >> 5) ^ ((rb >> 3) & 1)) << 4);
+    // (k-step 1 is logical chunk 2 + (l >> 5): its address is that of k-step 0 with byte-offset bit 5 flipped)
+    const int a_off0 = ra * V3_ROWB + ((((lane >> 5)) ^ ((ra >> 2) & 3)) << 4);
+    const int b_off0 = rb * V3_ROWB + ((((lane >> 5)) ^ ((rb >> 2) & 3)) << 4);
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t *)smem_g);
 
-#pragma unroll
-    for (int q = 0; q < NSTAGE - 1; ++q)
-        if (q < ns) issue(q, q);
+    if (ns > 0) issue(0, 0);
     for (int s = 0; s < ns; ++s) {
-        // slice s has landed once at most the loads of the NSTAGE-2 = 1 younger slice in flight are outstanding
-        // (a wave issues 2 * NP or 3 * NP loads per slice: waiting for the smaller count is safe)
-        if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage s is the only one in flight
         __builtin_amdgcn_s_barrier();
-        if (s + NSTAGE - 1 < ns) issue(s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);   // that buffer was last read in slice s-1
-        // Rolling B fragments: three register slots.  All of A and column blocks 0..2 are requested up front;
-        // as soon as the MFMAs of block j have issued, block j+3 is requested into the slot they read.  The
-        // LDS reads of a slice are thereby spread under the matrix work instead of read-then-compute phases
-        // in which all eight waves hit the LDS at once while the matrix cores idle.
-        // The reads and their waits are inline asm: the compiler waits for lgkmcnt(0) before every MFMA
-        // group (it does not count outstanding ds_read_b128), which would re-serialise the schedule.  LDS
-        // reads of one wave return in order, so "at most N younger reads outstanding" is exact; every wait
-        // lists the registers it releases as in/out operands so that nothing can read them earlier.
-        f16x8 af[NP][2], bs[3][NP];
-        const unsigned a_addr = lds0 + (s % NSTAGE) * STAGE + a_off0;
-        const unsigned b_addr = lds0 + (s % NSTAGE) * STAGE + NP * A_BYTES + b_off0;
+        if (s + 1 < ns) issue(s + 1, (s + 1) & 1);              // that buffer was last read in stage s-1
 #define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            LDS_RD(af[pl][0], a_addr, pl * A_BYTES);
-            LDS_RD(af[pl][1], a_addr, pl * A_BYTES + 32 * V2_ROWB);
-        }
+        for (int kk = 0; kk < 2; ++kk) {
+            // Rolling B fragments: two register slots (a third would spill).  A and column blocks 0, 1 are requested
+            // up front; as soon as the MFMAs of block j have issued, block j+2 is requested into the slot they read, so
+            // the LDS reads run under the matrix work.  The reads and their waits are inline asm: the compiler waits
+            // for lgkmcnt(0) before every MFMA group (it does not count outstanding ds_read_b128), which would
+            // serialise read and compute phases.  LDS reads of one wave return in order, so "at most N younger reads
+            // outstanding" is exact; every wait lists the registers it releases as in/out operands so that nothing
+            // can read them earlier.
+            f16x8 af[NP][2], bs[2][NP];
+            const unsigned a_addr = lds0 + (s & 1) * STAGE + (a_off0 ^ (kk << 5));
+            const unsigned b_addr = lds0 + (s & 1) * STAGE + NP * A_BYTES + (b_off0 ^ (kk << 5));
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j][pl], b_addr, pl * B_BYTES + j * 32 * V2_ROWB);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            // younger reads allowed in flight while block j computes: blocks j+1, j+2 (NP reads each)
-            constexpr int Y2 = 2 * NP, Y1 = NP;
-            if constexpr (SPLIT) {
-                if (j == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]) : "n"(Y2));
-                else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y2));
-                else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]) : "n"(Y1));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]), "+v"(bs[j % 3][1]));
-                // small terms first so they are not absorbed by the large partial sum
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][1], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][1], acc[1][j], 0, 0, 0);
-            } else {
-                if (j == 0) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bs[0][0]) : "n"(Y2));
-                else if (j < 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y2));
-                else if (j == 4) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 3][0]) : "n"(Y1));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 3][0]));
+            for (int pl = 0; pl < NP; ++pl) {
+                LDS_RD(af[pl][0], a_addr, pl * A_BYTES);
+                LDS_RD(af[pl][1], a_addr, pl * A_BYTES + 32 * V3_ROWB);
             }
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 3][0], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 3][0], acc[1][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j + 3 < 6) {
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j % 3][pl], b_addr, pl * B_BYTES + (j + 3) * 32 * V2_ROWB);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j][pl], b_addr, pl * B_BYTES + j * 32 * V3_ROWB);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                constexpr int Y1 = NP;                 // younger reads allowed in flight: block j+1
+                if constexpr (SPLIT) {
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]) : "n"(Y1));
+                    else if (j < 5) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bs[j % 2][0]), "+v"(bs[j % 2][1]) : "n"(Y1));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 2][0]), "+v"(bs[j % 2][1]));
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bs[j % 2][0], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bs[j % 2][0], acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 2][1], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 2][1], acc[1][j], 0, 0, 0);
+                } else {
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bs[0][0]) : "n"(Y1));
+                    else if (j < 5) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bs[j % 2][0]) : "n"(Y1));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 2][0]));
+                }
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bs[j % 2][0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bs[j % 2][0], acc[1][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 2 < 6) {
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) LDS_RD(bs[j % 2][pl], b_addr, pl * B_BYTES + (j + 2) * 32 * V3_ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
 #undef LDS_RD
     }

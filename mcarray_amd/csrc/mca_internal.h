@@ -63,7 +63,7 @@ struct GemmArgs {
     int chunk_frames, total_frames, frame0;
     int Kp, Dp, a_row_elems;
     long long c_plane_elems;  // elements between the partial maps of a split-K launch
-    const void *Bt;          // fp16 steering table tiled for the 256 x 384 kernel: [plane][Kp/16][Dp][16] (a K slice of all columns is contiguous)
+    const void *Bt;          // fp16 steering table tiled for the 256 x 384 kernel: [plane][Kp/32][Dp][32] (a K stage of all columns is contiguous)
 };
 
 struct ScanPickArgs {
