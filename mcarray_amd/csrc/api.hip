@@ -712,7 +712,7 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
     if (smem3 > 64 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
-    hipLaunchKernelGGL(k_scan_pick, g3, dim3(nthr), smem3, st, pa);
+    hipLaunchKernelGGL(k_scan_pick, g3, dim3(std::max(nthr, 512)), smem3, st, pa);   // 8 waves: the per-frame pick is one wave per frame
     if (gate) {
         DoaFillArgs fa{};
         fa.voiced = c->d_voiced; fa.n_frames = n_frames; fa.S = c->S;
