@@ -569,16 +569,25 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
                 const int k = tid;   // bins 0..511
                 if (one_source) {
                     // one source, <= 8 channels: this thread's bin never changes, so its phasors stay in registers
-                    // until the source moves (8 LDS reads per frame instead of 24)
+                    // until the source moves (8 LDS reads per frame instead of 24).  M == 8 gets a branch-free copy:
+                    // with per-channel guards every LDS read sits behind a scalar branch and its latency is exposed.
                     if (!same) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
                             if (c < M) phc[c] = cmul(steer[c * 49 + 32 + (k >> 5)], steer[c * 49 + (k & 31)]);
                     }
                     float2 acc = make_float2(0.f, 0.f);
+                    if (M == 8) {
+                        float2 x[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (c < M) acc = cmac(acc, xs[c * FFT_SCRATCH + k], phc[c]);
+                        for (int c = 0; c < 8; ++c) x[c] = xs[c * FFT_SCRATCH + k];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc = cmac(acc, x[c], phc[c]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (c < M) acc = cmac(acc, xs[c * FFT_SCRATCH + k], phc[c]);
+                    }
                     ys[j * FFT_SCRATCH + k] = make_float2(acc.x * inv, acc.y * inv);             // divC :70
                 } else
                 for (int s = 0; s < S; ++s) {
