@@ -215,7 +215,7 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
     a.tail_in = c->d_tail[c->tail_cur]; a.tail_out = c->d_tail[c->tail_cur ^ 1];
     a.out = out_pcm; a.decisions = decisions;
     const size_t smem = (size_t)MK_NB * 2 * FFT_SCRATCH * sizeof(float2) + (size_t)MK_NB * 520 * sizeof(float4) +
-                        TW_WORDS * sizeof(float2) + (size_t)MK_NB * 48 * 8 * sizeof(float);
+                        TW_WORDS * sizeof(float2) + (size_t)MK_NB * 48 * 8 * sizeof(float) + 520 * (sizeof(float2) + sizeof(int));
     if (smem > 64 * 1024)
         MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);

@@ -69,6 +69,8 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
     float2 *tab = reinterpret_cast<float2 *>(binq + MK_NB * 520);          // [TW_WORDS]
     float *sums = reinterpret_cast<float *>(tab + TW_WORDS);               // [MK_NB][48][6]
     float *gains = sums + MK_NB * 48 * 6;                                  // [MK_NB][48][2]
+    float2 *wq = reinterpret_cast<float2 *>(gains + MK_NB * 48 * 2);       // [520] (H_kb[k], H_{kb+1}[k]): the two bands covering bin k
+    int *kbs = reinterpret_cast<int *>(wq + 520);                          // [520] first band covering bin k (-1: none)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.y;
     const MaskParams &mp = *p.mp;
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
     const bool passthrough = mp.method == 5;               // NOTHING :130-134
 
     fft_table_init(tab, p.window, tid, 512);
+    for (int k = tid; k < FFT_K; k += 512) { wq[k] = make_float2(mp.kw0[k], mp.kw1[k]); kbs[k] = mp.kb[k]; }
     __syncthreads();
     FftTw tw{tab};
 
@@ -113,18 +116,26 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
             binq[j * 520 + k] = make_float4(L.x * L.x + L.y * L.y, R.x * R.x + R.y * R.y, L.x * R.x + L.y * R.y, mr * mr + mi * mi);
         }
         __syncthreads();
-        // (3) band sums over the band's support, weight H_b[k]^2
-        {
-            const int j = tid >> 6, b = tid & 63;
-            if (j < nb && b < 45) {
-                float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
-                for (int k = mp.lo[b]; k <= mp.hi[b]; ++k) {
-                    const float h = mp.kb[k] == b ? mp.kw0[k] : mp.kw1[k];
-                    const float w = h * h;
-                    const float4 q = binq[j * 520 + k];
-                    a0 += w * q.x; a1 += w * q.y; a2 += w * q.z;
-                    if (k < FFT_H) { a3 += w * q.w; a4 += w * q.x; a5 += w * q.y; }
-                }
+        // (3) band sums over the band's support, weight H_b[k]^2: 8 lanes per (frame, band) pair, bins strided over
+        // the lanes (the widest mel band has ~100 bins), 3-level shuffle reduction.  One thread per pair walking
+        // its whole support serially took 27 % of the kernel.
+        for (int q = tid >> 3; q < nb * 45; q += 64) {
+            const int j = q / 45, b = q - j * 45;
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+            for (int k = mp.lo[b] + (tid & 7); k <= mp.hi[b]; k += 8) {
+                const float2 hw = wq[k];
+                const float h = kbs[k] == b ? hw.x : hw.y;
+                const float w = h * h;
+                const float4 v = binq[j * 520 + k];
+                a0 += w * v.x; a1 += w * v.y; a2 += w * v.z;
+                if (k < FFT_H) { a3 += w * v.w; a4 += w * v.x; a5 += w * v.y; }
+            }
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {
+                a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
+                a3 += __shfl_xor(a3, off); a4 += __shfl_xor(a4, off); a5 += __shfl_xor(a5, off);
+            }
+            if ((tid & 7) == 0) {
                 float *o = sums + (j * 48 + b) * 6;
                 o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
             }
@@ -149,12 +160,13 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
                 const int jc = e / FFT_K, k = e - jc * FFT_K, j = jc >> 1, ch = jc & 1;
                 float m = 1.f;
                 if (!passthrough) {
-                    const int b0 = mp.kb[k];
+                    const int b0 = kbs[k];
                     m = 0.f;
                     if (b0 >= 0) {
                         const float g0 = k < FFT_H ? gains[(j * 48 + b0) * 2 + ch] : 1.f;
                         const float g1 = (k < FFT_H && b0 + 1 < 45) ? gains[(j * 48 + b0 + 1) * 2 + ch] : 1.f;
-                        m = g0 * mp.kw0[k] + g1 * mp.kw1[k];
+                        const float2 hw = wq[k];
+                        m = g0 * hw.x + g1 * hw.y;
                     }
                 }
                 float2 x = spec[jc * FFT_SCRATCH + k];
