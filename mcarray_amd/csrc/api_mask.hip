@@ -214,8 +214,9 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
     a.Q_in = c->d_Q[c->q_cur]; a.Q_out = c->d_Q[c->q_cur ^ 1]; a.noise = c->d_noise;
     a.tail_in = c->d_tail[c->tail_cur]; a.tail_out = c->d_tail[c->tail_cur ^ 1];
     a.out = out_pcm; a.decisions = decisions;
-    const size_t smem = (size_t)MK_NB * 2 * FFT_SCRATCH * sizeof(float2) + (size_t)MK_NB * 520 * sizeof(float4) +
-                        TW_WORDS * sizeof(float2) + (size_t)MK_NB * 48 * 8 * sizeof(float) + 520 * (sizeof(float2) + sizeof(int));
+    // 79 KiB: two workgroups per CU
+    const size_t smem = (size_t)MK_NB * 2 * FFT_SCRATCH * sizeof(float2) + (size_t)MK_NB * 3 * 520 * sizeof(float) +
+                        TW_WIN * sizeof(float2) + (size_t)MK_NB * 48 * 8 * sizeof(float) + 520 * sizeof(float2) + 528;
     if (smem > 64 * 1024)
         MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);

@@ -123,7 +123,8 @@ struct FftTw {
     __device__ __forceinline__ float2 win(int r, int lane) const { return tab[TW_WIN + r * 64 + lane]; }
 };
 
-// fill the table (all threads of the block; caller must __syncthreads() afterwards)
+// fill the table (all threads of the block; caller must __syncthreads() afterwards).  window == nullptr: twiddles
+// only (TW_WIN words; the caller keeps its window samples in registers).
 __device__ __forceinline__ void fft_table_init(float2 *tab, const float *window, int tid, int nthreads)
 {
     for (int e = tid; e < TW_WIN; e += nthreads) {
@@ -133,10 +134,11 @@ __device__ __forceinline__ void fft_table_init(float2 *tab, const float *window,
         else { const int i = (e - TW_TS) >> 6, l = (e - TW_TS) & 63; v = twiddle(l + 64 * i, 1024, false); }
         tab[e] = v;
     }
-    for (int e = tid; e < 512; e += nthreads) {   // half the window: carries the 1/2 of rfft1024's split step (exact in fp32)
-        const float2 w = reinterpret_cast<const float2 *>(window)[e];
-        tab[TW_WIN + e] = make_float2(0.5f * w.x, 0.5f * w.y);
-    }
+    if (window)
+        for (int e = tid; e < 512; e += nthreads) {   // half the window: carries the 1/2 of rfft1024's split step (exact in fp32)
+            const float2 w = reinterpret_cast<const float2 *>(window)[e];
+            tab[TW_WIN + e] = make_float2(0.5f * w.x, 0.5f * w.y);
+        }
 }
 
 // wave-level ordering of LDS traffic: LDS instructions of one wave execute in order, so only

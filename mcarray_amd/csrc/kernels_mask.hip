@@ -65,12 +65,12 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *spec = reinterpret_cast<float2 *>(smem_raw);                  // [MK_NB][2][FFT_SCRATCH]
-    float4 *binq = reinterpret_cast<float4 *>(spec + MK_NB * 2 * FFT_SCRATCH);   // [MK_NB][520]
-    float2 *tab = reinterpret_cast<float2 *>(binq + MK_NB * 520);          // [TW_WORDS]
-    float *sums = reinterpret_cast<float *>(tab + TW_WORDS);               // [MK_NB][48][6]
+    float *binq = reinterpret_cast<float *>(spec + MK_NB * 2 * FFT_SCRATCH);     // [MK_NB][3][520]: |L|^2, |R|^2, Re(conj(L) R)
+    float2 *tab = reinterpret_cast<float2 *>(binq + MK_NB * 3 * 520);      // [TW_WIN] twiddles (the window stays in registers)
+    float *sums = reinterpret_cast<float *>(tab + TW_WIN);                 // [MK_NB][48][6]
     float *gains = sums + MK_NB * 48 * 6;                                  // [MK_NB][48][2]
     float2 *wq = reinterpret_cast<float2 *>(gains + MK_NB * 48 * 2);       // [520] (H_kb[k], H_{kb+1}[k]): the two bands covering bin k
-    int *kbs = reinterpret_cast<int *>(wq + 520);                          // [520] first band covering bin k (-1: none)
+    signed char *kbs = reinterpret_cast<signed char *>(wq + 520);          // [520] first band covering bin k (-1: none)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.y;
     const MaskParams &mp = *p.mp;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
     const int tbeg = t0 > 0 ? max(0, tfull - MK_WARM) : 0; // first frame of the Q warm-up
     const bool passthrough = mp.method == 5;               // NOTHING :130-134
 
-    fft_table_init(tab, p.window, tid, 512);
-    for (int k = tid; k < FFT_K; k += 512) { wq[k] = make_float2(mp.kw0[k], mp.kw1[k]); kbs[k] = mp.kb[k]; }
+    fft_table_init(tab, nullptr, tid, 512);
+    for (int k = tid; k < FFT_K; k += 512) { wq[k] = make_float2(mp.kw0[k], mp.kw1[k]); kbs[k] = (signed char)mp.kb[k]; }
     __syncthreads();
     FftTw tw{tab};
 
@@ -93,6 +93,12 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
     if (t0 == 0) { carry[0] = p.tail_in[(s * 2 + 0) * FFT_H + tid]; carry[1] = p.tail_in[(s * 2 + 1) * FFT_H + tid]; }
     const int jw = wave >> 1, cw = wave & 1;
     const float *base = p.pcm + (long long)s * p.stream_stride + (long long)cw * p.ch_stride;
+    float2 wreg[8];                                        // this lane's window samples, halved (the 1/2 of the split step)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float2 w = reinterpret_cast<const float2 *>(p.window)[lane + 64 * r];
+        wreg[r] = make_float2(0.5f * w.x, 0.5f * w.y);
+    }
 
     for (int tb = tbeg; tb < t1; tb += MK_NB) {
         const int nb = min(MK_NB, t1 - tb);
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
             float2 v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float2 x = src[lane + 64 * r], w = tw.win(r, lane);
+                const float2 x = src[lane + 64 * r], w = wreg[r];
                 v[r] = make_float2(x.x * w.x, x.y * w.y);
             }
             rfft1024(v, spec + (jw * 2 + cw) * FFT_SCRATCH, lane, tw);
@@ -112,8 +118,9 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
         for (int e = tid; e < nb * FFT_K; e += 512) {
             const int j = e / FFT_K, k = e - j * FFT_K;
             const float2 L = spec[(j * 2) * FFT_SCRATCH + k], R = spec[(j * 2 + 1) * FFT_SCRATCH + k];
-            const float mr = 0.5f * L.x + 0.5f * R.x, mi = 0.5f * L.y + 0.5f * R.y;   // divC(2) + add :510-512
-            binq[j * 520 + k] = make_float4(L.x * L.x + L.y * L.y, R.x * R.x + R.y * R.y, L.x * R.x + L.y * R.y, mr * mr + mi * mi);
+            // |L/2 + R/2|^2 (divC(2) + add :510-512) = (|L|^2 + |R|^2 + 2 Re(conj(L) R)) / 4: formed from the band sums
+            float *bq = binq + j * 3 * 520 + k;
+            bq[0] = L.x * L.x + L.y * L.y; bq[520] = R.x * R.x + R.y * R.y; bq[1040] = L.x * R.x + L.y * R.y;
         }
         __syncthreads();
         // (3) band sums over the band's support, weight H_b[k]^2: 8 lanes per (frame, band) pair, bins strided over
@@ -121,14 +128,15 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
         // its whole support serially took 27 % of the kernel.
         for (int q = tid >> 3; q < nb * 45; q += 64) {
             const int j = q / 45, b = q - j * 45;
-            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;           // a3: Re(conj(L) R) over the first N/2 bins
             for (int k = mp.lo[b] + (tid & 7); k <= mp.hi[b]; k += 8) {
                 const float2 hw = wq[k];
                 const float h = kbs[k] == b ? hw.x : hw.y;
                 const float w = h * h;
-                const float4 v = binq[j * 520 + k];
-                a0 += w * v.x; a1 += w * v.y; a2 += w * v.z;
-                if (k < FFT_H) { a3 += w * v.w; a4 += w * v.x; a5 += w * v.y; }
+                const float *bq = binq + j * 3 * 520 + k;
+                const float ll = bq[0], rr = bq[520], lr = bq[1040];
+                a0 += w * ll; a1 += w * rr; a2 += w * lr;
+                if (k < FFT_H) { a3 += w * lr; a4 += w * ll; a5 += w * rr; }
             }
 #pragma unroll
             for (int off = 4; off > 0; off >>= 1) {
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
             }
             if ((tid & 7) == 0) {
                 float *o = sums + (j * 48 + b) * 6;
-                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
+                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = 0.25f * (a4 + a5 + 2.f * a3); o[4] = a4; o[5] = a5;
             }
         }
         __syncthreads();
