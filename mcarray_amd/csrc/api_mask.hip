@@ -209,7 +209,11 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
     MaskArgs a{};
     a.pcm = pcm; a.stream_stride = stream_stride; a.ch_stride = ch_stride; a.n_frames = n_frames;
     // NOISY takes its noise estimate from the stream's very first frame (:193-197): that one call runs as a single chunk
-    a.ft = (c->cfg.method == MCA_HIP_MASK_NOISY && c->frames_done == 0) ? n_frames : 64;
+    // otherwise runs of up to 256 frames (every run re-analyses 9 frames for the Q warm-up and the overlap-add carry),
+    // shorter ones for small batches so that two workgroups per CU exist
+    int ft = 256;
+    while (ft > 16 && (long long)n_streams * ((n_frames + ft - 1) / ft) < 512) ft >>= 1;
+    a.ft = (c->cfg.method == MCA_HIP_MASK_NOISY && c->frames_done == 0) ? n_frames : ft;
     a.frames_done = c->frames_done; a.window = c->d_window; a.mp = c->d_mp;
     a.Q_in = c->d_Q[c->q_cur]; a.Q_out = c->d_Q[c->q_cur ^ 1]; a.noise = c->d_noise;
     a.tail_in = c->d_tail[c->tail_cur]; a.tail_out = c->d_tail[c->tail_cur ^ 1];
