@@ -830,7 +830,11 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
     Gcc2ScanArgs ga{};
-    ga.C = c->d_C; ga.c_planes = c->c_planes; ga.c_plane_stride = c->c_plane; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D; ga.chunk = 32;
+    ga.C = c->d_C; ga.c_planes = c->c_planes; ga.c_plane_stride = c->c_plane; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D;
+    // frames per chunk: every chunk re-reads 160 warm-up frames (recursion + DOA smoothing), so long chunks are cheaper;
+    // shorter ones for small batches so that a few hundred workgroups exist
+    ga.chunk = 128;
+    while (ga.chunk > 32 && (long long)n_arrays * ((n_frames + ga.chunk - 1) / ga.chunk) < 512) ga.chunk >>= 1;
     ga.frames_done = c->gcc2_frames_done;
     ga.mu = 0.8f; ga.one_minus_mu = 1 - 0.8f;                      // _maxCorrMemoryFactor (BinauralLocalisation.h:198)
     ga.doa_mem = 0.6f; ga.one_minus_doa_mem = 1 - 0.6f;            // _maxDoaMemoryFactor (:199)
@@ -839,12 +843,12 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     ga.doa_in = c->d_doa[c->doa_cur]; ga.doa_out = c->d_doa[c->doa_cur ^ 1];
     ga.grid = c->d_grid; ga.argmax = argmax; ga.doa_rad = doa_rad; ga.prob = prob; ga.corr = corr;
     const int nslot = GCC2_DOAWARM + ga.chunk;
-    const size_t smem = (size_t)nslot * (c->Dp + 8) * sizeof(float) + (size_t)nslot * 3 * sizeof(float);
+    const size_t smem = (size_t)nslot * ((c->D + 3) / 4 * 4 + 4) * sizeof(float) + (size_t)nslot * 3 * sizeof(float);
     if (smem > 64 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcc2_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 g((n_frames + ga.chunk - 1) / ga.chunk, n_arrays);
     time_begin(c, MCA_HIP_K_GCC2_SCAN, st);
-    hipLaunchKernelGGL(k_gcc2_scan, g, dim3(round_up(c->D, 64)), smem, st, ga);
+    hipLaunchKernelGGL(k_gcc2_scan, g, dim3(std::max(256, round_up(c->D, 64))), smem, st, ga);   // >= 4 waves: the per-frame argmax / min / sum is one wave per frame
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
     c->e_cur ^= 1; c->doa_cur ^= 1;

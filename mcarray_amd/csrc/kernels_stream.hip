@@ -653,7 +653,7 @@ template __global__ void k_beamform_ola<2, 2>(BeamformArgs);
 __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int D = p.D, Dl = p.Dp + 8;
+    const int D = p.D, Dl = (D + 3) / 4 * 4 + 4;                        // LDS row stride (the rows are only read along d)
     float *sC = reinterpret_cast<float *>(smem_raw);                    // [GCC2_DOAWARM + chunk][Dl]
     const int nslot = GCC2_DOAWARM + p.chunk;
     int *sIdx = reinterpret_cast<int *>(sC + nslot * Dl);               // [nslot]
@@ -667,13 +667,20 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     if (d < D) {
         float c = warm_start == 0 ? p.corr_in[(long long)a * D + d] : 0.f;
-        for (int t = warm_start; t < t_end; ++t) {
-            const bool first = (p.frames_done + t) == 0;                // _corrMemoryFactor = 0 on the first frame
-            const long long o = (long long)t * p.Dp + d;
-            const float r = csum(C, o, p.c_planes, p.c_plane_stride);
-            c = first ? r : (p.one_minus_mu * r + p.mu * c);            // :445-447
-            if (t >= keep_start) sC[(t - keep_start) * Dl + d] = c;
-            if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + t) * D + d] = c;
+        for (int t0 = warm_start; t0 < t_end; t0 += 8) {                  // 8 independent loads in flight, then the serial recursion
+            float r8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r8[i] = csum(C, (long long)min(t0 + i, t_end - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = t0 + i;
+                if (t < t_end) {
+                    const bool first = (p.frames_done + t) == 0;            // _corrMemoryFactor = 0 on the first frame
+                    c = first ? r8[i] : (p.one_minus_mu * r8[i] + p.mu * c);   // :445-447
+                    if (t >= keep_start) sC[(t - keep_start) * Dl + d] = c;
+                    if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + t) * D + d] = c;
+                }
+            }
         }
         if (t_end == p.n_frames) p.corr_out[(long long)a * D + d] = c;  // _prevCorrelationsReal :448
     }
