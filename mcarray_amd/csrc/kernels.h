@@ -5,6 +5,7 @@
 namespace mca {
 
 template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat(StftPhatArgs p);
+template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat_few(StftPhatArgs p);
 __global__ void k_sum_planes(float *C, long long n4, int planes, long long stride);
 __global__ void k_scan_partial(ScanPickArgs p);
 __global__ void k_scan_carry(ScanPickArgs p);

@@ -165,15 +165,93 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
 
 #define INST_STFT(MT, ULA, T) template __global__ void k_stft_phat<MT, ULA, T>(StftPhatArgs);
 INST_STFT(0, false, float) INST_STFT(0, true, float)
-INST_STFT(2, false, float)
 INST_STFT(4, false, float) INST_STFT(4, true, float)
 INST_STFT(8, false, float) INST_STFT(8, true, float)
 INST_STFT(16, true, float)
 INST_STFT(0, false, _Float16) INST_STFT(0, true, _Float16)
-INST_STFT(2, false, _Float16)
 INST_STFT(4, false, _Float16) INST_STFT(4, true, _Float16)
 INST_STFT(8, false, _Float16) INST_STFT(8, true, _Float16)
 INST_STFT(16, true, _Float16)
+
+// --------------------------------------------------------------------------------------
+// k_stft_phat_few: the same stage for few microphones (instantiated for 2; with 4 it measured no faster than
+// k_stft_phat).  With one wave per channel only 2 of the 8 waves of k_stft_phat would transform; here a pass takes FP = 8 / MT consecutive frames at once (wave w -> frame slot
+// w / MT, channel w % MT), then the 512 threads run the pair stage of each of those frames.  Frames handled by one
+// wave are FP apart, so both halves of a frame are loaded (no shared half frame); the next pass is prefetched.
+// --------------------------------------------------------------------------------------
+template <int MT, bool ULA, typename OutT>
+__global__ __launch_bounds__(512) void k_stft_phat_few(StftPhatArgs p)
+{
+    constexpr int FP = 8 / MT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *smem = reinterpret_cast<float2 *>(smem_raw);                // [8][FFT_SCRATCH]: wave w's spectrum = (slot, channel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2 *tab = smem + 8 * FFT_SCRATCH;                                 // [TW_WORDS]
+    float2 *nyq = tab + TW_WORDS;                                         // [fpb][MT] whitened Nyquist bins
+    float *spow = reinterpret_cast<float *>(nyq + p.fpb * MT);            // [fpb]
+    const int a = blockIdx.y;
+    const int f_begin = blockIdx.x * p.fpb;
+    const int f_end = min(f_begin + p.fpb, p.n_frames);
+    const int slot = wave / MT, c = wave % MT;
+
+    fft_table_init(tab, p.window, tid, 512);
+    if (tid < p.fpb) spow[tid] = 0.f;
+    __syncthreads();
+    FftTw tw{tab};
+
+    const float *base = p.pcm + (long long)a * p.array_stride + (long long)c * p.mic_stride;
+    float2 nxt[8];
+    if (f_begin + slot < f_end) {
+        const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(p.frame0 + f_begin + slot) * FFT_H);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) nxt[r] = src[lane + 64 * r];
+    }
+    for (int f = f_begin; f < f_end; f += FP) {
+        if (f + slot < f_end) {
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const float2 w = tw.win(r, lane); v[r] = make_float2(nxt[r].x * w.x, nxt[r].y * w.y); }
+            if (f + FP + slot < f_end) {
+                const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(p.frame0 + f + FP + slot) * FFT_H);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) nxt[r] = src[lane + 64 * r];
+            }
+            rfft1024(v, smem + wave * FFT_SCRATCH, lane, tw);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < FP; ++sl) {
+            const int fr = f + sl;
+            if (fr < f_end) {
+                const float2 *x = smem + sl * MT * FFT_SCRATCH;
+                OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + fr) * (long long)p.a_row_elems;
+                if (tid < MT) nyq[(fr - f_begin) * MT + tid] = whiten(x[tid * FFT_SCRATCH + FFT_H]);
+                if (p.power) {   // FFTPower [INFERRED, SURVEY A.8], as in k_stft_phat
+                    float acc = 0.f;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) { const float2 z = x[m * FFT_SCRATCH + tid]; acc += z.x * z.x + z.y * z.y; }
+                    acc *= tid == 0 ? 1.f : 2.f;
+                    if (tid < MT) { const float2 z = x[tid * FFT_SCRATCH + FFT_H]; acc += z.x * z.x + z.y * z.y; }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+                    if (lane == 0) atomicAdd(&spow[fr - f_begin], acc);
+                }
+                pair_stage<MT, ULA, true, OutT>(x + tid, FFT_SCRATCH, MT, arow, p, tid);
+            }
+        }
+        __syncthreads();
+    }
+    if (p.power && tid < f_end - f_begin)
+        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = spow[tid] / ((float)FFT_N * (float)FFT_N) / (float)MT;
+    if (tid < f_end - f_begin) {
+        OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
+        pair_stage<MT, ULA, false, OutT>(nyq + tid * MT, 1, MT, arow, p, FFT_H);
+    }
+}
+
+#define INST_FEW(MT, ULA, T) template __global__ void k_stft_phat_few<MT, ULA, T>(StftPhatArgs);
+INST_FEW(2, false, float)
+INST_FEW(2, false, _Float16)
 
 // --------------------------------------------------------------------------------------
 // k_gate -- the power gate of BeamformingSeparationAndLocalisation::processFrameLocalisation
