@@ -253,7 +253,7 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *c, const float *pcm, long long array_s
     ma.use_floor = c->cfg.use_power_floor; ma.margin_db = 3.0f;                 // _noiseMarginDB (.h:47)
     ma.grid = c->d_grid; ma.gate = c->d_gate; ma.cur = c->d_cur;
     ma.doa_rad = doa_rad; ma.prob = prob; ma.power = power; ma.voiced = voiced;
-    hipLaunchKernelGGL(k_mb_summary, dim3(n_arrays), dim3(64), 0, st, ma);
+    hipLaunchKernelGGL(k_mb_summary, dim3(n_arrays), dim3(256), 0, st, ma);
     BHIP_TRY(c, hipGetLastError());
     c->corr_cur ^= 1;
     return MCA_HIP_OK;

@@ -132,41 +132,73 @@ __global__ __launch_bounds__(1024) void k_mb_scan(MbScanArgs p)
     }
 }
 
-// grid (arrays), 64 threads; thread 0 walks the frames in order (the gate's floor estimation and the
-// hold-over of _currentDOA on gated-out frames are sequential by nature and a few flops per frame)
-__global__ __launch_bounds__(64) void k_mb_summary(MbSummaryArgs p)
+// grid (arrays), 256 threads.  Only the floor estimation over the first 3 s is sequential (thread 0, <= 141
+// frames); after it every frame decides for itself, and "a gated-out frame keeps the previous _currentDOA"
+// (_doaMemoryFactorSilence = 1, :254) is an inclusive prefix max of the last fired frame over per-thread segments.
+__global__ __launch_bounds__(256) void k_mb_summary(MbSummaryArgs p)
 {
-    if (threadIdx.x != 0) return;
-    const int a = blockIdx.x;
+    __shared__ int sLast[256];
+    __shared__ int s_first_free;
+    __shared__ double s_floor;
+    const int a = blockIdx.x, tid = threadIdx.x, F = p.n_frames;
+    const long long base = (long long)a * F;
     double *g = p.gate + (long long)a * 4;
-    double acc = g[0], consumed = g[1], floor_db = g[2];
-    bool est = g[3] != 0.0;
-    float cur = p.cur[a * 2], pr = p.cur[a * 2 + 1];
-    const double per_frame = (double)(2 * p.K - 2);
-    for (int t = 0; t < p.n_frames; ++t) {
-        const long long row = (long long)a * p.n_frames + t;
-        double power, thr;
-        if (!est) {                                                                       // setPowerFloor :125-143
-            acc += (double)p.p_half[row] * per_frame;
+    const float cur_in = p.cur[a * 2];
+    if (tid == 0) {
+        double acc = g[0], consumed = g[1], floor_db = g[2];
+        bool est = g[3] != 0.0;
+        const double per_frame = (double)(2 * p.K - 2);
+        int t = 0;
+        for (; t < F && !est; ++t) {                                                      // setPowerFloor :125-143
+            acc += (double)p.p_half[base + t] * per_frame;
             consumed += per_frame;
             if (consumed >= (double)p.needed_samples) {
                 est = true;
                 floor_db = 10.0 * log10(acc / consumed) + (double)p.margin_db;
                 acc = floor_db;
             }
-            power = acc; thr = acc;                                                       // returns _powerFloor itself
-        } else {
-            power = (double)p.p_full[row]; thr = floor_db;                                // :221 (linear vs the dB floor)
+            // power == _powerFloor here (the function returns it), so only an ungated module fires (:225)
+            if (p.voiced) p.voiced[base + t] = p.use_floor ? 0 : 1;
+            if (p.power) p.power[base + t] = (float)acc;
         }
-        const bool fire = power > thr || !p.use_floor;                                    // :225
-        if (fire) { cur = p.grid[p.hist_idx[row]]; pr = p.hist_prob[row]; }               // :237-239, _doaMemoryFactor = 0
-        else pr = -100000.f;                                                              // :254-255, _doaMemoryFactorSilence = 1
-        p.doa_rad[row] = cur; p.prob[row] = pr;
-        if (p.voiced) p.voiced[row] = fire ? 1 : 0;
-        if (p.power) p.power[row] = (float)power;
+        g[0] = acc; g[1] = consumed; g[2] = floor_db; g[3] = est ? 1.0 : 0.0;
+        s_first_free = t; s_floor = floor_db;
     }
-    g[0] = acc; g[1] = consumed; g[2] = floor_db; g[3] = est ? 1.0 : 0.0;
-    p.cur[a * 2] = cur; p.cur[a * 2 + 1] = pr;
+    __syncthreads();
+    const int first_free = s_first_free;
+    const double floor_db = s_floor;
+    const int per = (F + 255) / 256;
+    const int t0 = tid * per, t1 = min(t0 + per, F);
+    // does frame t fire the callback?  During the estimation the function returns _powerFloor itself, so
+    // `power > _powerFloor` is false (:216,:225); afterwards the LINEAR frame power meets the dB floor (:221)
+    auto fires = [&](int t) -> bool {
+        if (!p.use_floor) return true;
+        return t >= first_free && (double)p.p_full[base + t] > floor_db;
+    };
+    int last = -1;
+    for (int t = t0; t < t1; ++t) {
+        const bool fire = fires(t);
+        if (t >= first_free) {
+            if (p.voiced) p.voiced[base + t] = fire ? 1 : 0;
+            if (p.power) p.power[base + t] = p.p_full[base + t];
+        }
+        p.prob[base + t] = fire ? p.hist_prob[base + t] : -100000.f;                      // :233 / :255
+        if (fire) last = t;
+    }
+    sLast[tid] = last;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int other = tid >= off ? sLast[tid - off] : -1;
+        __syncthreads();
+        sLast[tid] = max(sLast[tid], other);
+        __syncthreads();
+    }
+    int run = tid > 0 ? sLast[tid - 1] : -1;                    // last fired frame before this thread's segment
+    for (int t = t0; t < t1; ++t) {
+        if (fires(t)) run = t;
+        p.doa_rad[base + t] = run >= 0 ? p.grid[p.hist_idx[base + run]] : cur_in;        // :237-239, _doaMemoryFactor = 0
+    }
+    if (F - 1 >= t0 && F - 1 < t1) { p.cur[a * 2] = p.doa_rad[base + F - 1]; p.cur[a * 2 + 1] = p.prob[base + F - 1]; }
 }
 
 }  // namespace mca
