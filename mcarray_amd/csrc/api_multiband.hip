@@ -235,7 +235,9 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *c, const float *pcm, long long array_s
     hipLaunchKernelGGL(k_mb_analyse, dim3(n_frames, n_arrays), dim3(256), smem1, st, aa);
 
     MbScanArgs sa{};
-    sa.raw = c->d_raw; sa.band_energy = c->d_be; sa.n_frames = n_frames; sa.nbins = c->nb; sa.D = c->D; sa.chunk = 16;
+    sa.raw = c->d_raw; sa.band_energy = c->d_be; sa.n_frames = n_frames; sa.nbins = c->nb; sa.D = c->D;
+    // frames per chunk: every chunk re-reads 24 warm-up frames; its smoothed correlations stay in LDS (chunk x nbins x D floats)
+    sa.chunk = (size_t)32 * (c->nb * c->D + c->D + c->nb) * 4 <= 80 * 1024 ? 32 : 16;
     const float mem = 0.4f;                                                     // _corrMemoryFactor (MultibandBinarualLocalisation.h:46)
     sa.mem = mem; sa.one_minus_mem = 1 - mem;
     sa.corr_in = c->d_corr[c->corr_cur]; sa.corr_out = c->d_corr[c->corr_cur ^ 1];
