@@ -229,10 +229,20 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *c, const float *pcm, long long array_s
     aa.N = c->N; aa.logH = c->logH; aa.nbins = c->nb; aa.D = c->D;
     aa.window = c->d_window; aa.tw = c->d_tw; aa.coef = c->d_coef; aa.lo = c->d_lo; aa.hi = c->d_hi; aa.T = c->d_T;
     aa.raw = c->d_raw; aa.band_energy = c->d_be; aa.p_full = c->d_pf; aa.p_half = c->d_ph;
-    const size_t smem1 = (size_t)2 * (c->H + 1) * 8 + (size_t)c->K * 8 + (size_t)c->K * 4 + 8 * 4;
-    if (smem1 > 64 * 1024)
-        BHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mb_analyse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
-    hipLaunchKernelGGL(k_mb_analyse, dim3(n_frames, n_arrays), dim3(256), smem1, st, aa);
+    static const bool no_tuned = std::getenv("MCA_HIP_MB_GENERIC") != nullptr;     // A/B switch for measurements
+    if (c->N == FFT_N && !no_tuned) {
+        // 1024-sample frames: wave-level FFT, 4 frames x 2 channels per pass
+        int fpb = 16;
+        while (fpb > 4 && (long long)n_arrays * ((n_frames + fpb - 1) / fpb) < 512) fpb >>= 1;
+        const size_t smem1 = (size_t)8 * FFT_SCRATCH * 8 + (size_t)4 * 520 * (8 + 4) + (size_t)TW_WORDS * 8 + 16 * 4;
+        BHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mb_analyse_1024), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+        hipLaunchKernelGGL(k_mb_analyse_1024, dim3((n_frames + fpb - 1) / fpb, n_arrays), dim3(512), smem1, st, aa, fpb);
+    } else {
+        const size_t smem1 = (size_t)2 * (c->H + 1) * 8 + (size_t)c->K * 8 + (size_t)c->K * 4 + 8 * 4;
+        if (smem1 > 64 * 1024)
+            BHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mb_analyse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+        hipLaunchKernelGGL(k_mb_analyse, dim3(n_frames, n_arrays), dim3(256), smem1, st, aa);
+    }
 
     MbScanArgs sa{};
     sa.raw = c->d_raw; sa.band_energy = c->d_be; sa.n_frames = n_frames; sa.nbins = c->nb; sa.D = c->D;

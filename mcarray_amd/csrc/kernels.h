@@ -34,6 +34,7 @@ __global__ void k_gcc2_scan(Gcc2ScanArgs p);
 __global__ void k_mask_stream(MaskArgs p);
 __global__ void k_mask_frame(MaskFrameArgs p);
 __global__ void k_mb_analyse(MbAnalyseArgs p);
+__global__ void k_mb_analyse_1024(MbAnalyseArgs p, int fpb);
 __global__ void k_mb_scan(MbScanArgs p);
 __global__ void k_mb_summary(MbSummaryArgs p);
 

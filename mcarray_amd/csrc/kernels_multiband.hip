@@ -77,6 +77,90 @@ __global__ __launch_bounds__(256) void k_mb_analyse(MbAnalyseArgs p)
     }
 }
 
+// The same stage for N = 1024 (44.1 / 48 kHz) with the wave-level FFT of fft512.h: grid (frames / fpb, arrays),
+// 512 threads; a pass takes 4 frames x 2 channels (wave w -> frame slot w >> 1, channel w & 1), then the 512 threads
+// work on the 4 spectra pairs.  LDS: spec [8][FFT_SCRATCH] float2, G [4][520] float2, pw [4][520] float, table, red.
+__global__ __launch_bounds__(512) void k_mb_analyse_1024(MbAnalyseArgs p, int fpb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int K = FFT_K, Kh = FFT_K / 2;
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);
+    float2 *G = spec + 8 * FFT_SCRATCH;                         // [4][520]
+    float *pw = reinterpret_cast<float *>(G + 4 * 520);         // [4][520]
+    float2 *tab = reinterpret_cast<float2 *>(pw + 4 * 520);     // [TW_WORDS]
+    float *red = reinterpret_cast<float *>(tab + TW_WORDS);     // [4][2][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.y;
+    const int f_begin = blockIdx.x * fpb, f_end = min(f_begin + fpb, p.n_frames);
+    const int slot = wave >> 1, ch = wave & 1;
+    const float *base = p.pcm + (long long)a * p.array_stride + (long long)ch * p.ch_stride;
+    const int BD = p.nbins * p.D;
+
+    fft_table_init(tab, p.window, tid, 512);
+    __syncthreads();
+    FftTw tw{tab};
+    for (int f = f_begin; f < f_end; f += 4) {
+        const int nb = min(4, f_end - f);
+        if (slot < nb) {
+            const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(f + slot) * FFT_H);
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const float2 x = src[lane + 64 * r], w = tw.win(r, lane); v[r] = make_float2(x.x * w.x, x.y * w.y); }
+            rfft1024(v, spec + wave * FFT_SCRATCH, lane, tw);
+        }
+        __syncthreads();
+        // per-bin power and PHAT cross-spectrum of the nb frames: wave pair (2j, 2j+1) -> frame j, 128 threads x 4 bins (+ Nyquist)
+        {
+            const int j = tid >> 7, t = tid & 127;
+            float full = 0.f, half = 0.f;
+            if (j < nb) {
+                const float2 *L = spec + (2 * j) * FFT_SCRATCH, *R = L + FFT_SCRATCH;
+                for (int k = t; k < K; k += 128) {
+                    const float2 l = L[k], r = R[k];
+                    const float pk = l.x * l.x + l.y * l.y + r.x * r.x + r.y * r.y;
+                    pw[j * 520 + k] = pk;
+                    full += (k == 0 || k == K - 1) ? pk : 2.f * pk;
+                    if (k < Kh) half += (k == 0 || k == Kh - 1) ? pk : 2.f * pk;
+                    G[j * 520 + k] = whiten_g(cmulc(l, r));
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { full += __shfl_down(full, off); half += __shfl_down(half, off); }
+            if (lane == 0) { red[wave] = full; red[8 + wave] = half; }          // waves 2j, 2j+1 belong to frame j
+        }
+        __syncthreads();
+        if (tid < nb) {
+            const long long row = (long long)a * p.n_frames + f + tid;
+            const float n2 = (float)FFT_N * (float)FFT_N, h2 = (float)(K - 2) * (float)(K - 2);
+            p.p_full[row] = (red[2 * tid] + red[2 * tid + 1]) / n2 * 0.5f;      // mean over the 2 channels
+            p.p_half[row] = (red[8 + 2 * tid] + red[8 + 2 * tid + 1]) / h2 * 0.5f;
+        }
+        // band energies: 8 lanes per (frame, band)
+        for (int q = tid >> 3; q < nb * p.nbins; q += 64) {
+            const int j = q / p.nbins, b = q - j * p.nbins;
+            float s = 0.f;
+            for (int k = p.lo[b] + (tid & 7); k <= p.hi[b]; k += 8) {
+                const float h = p.coef[(long long)b * K + k];
+                const float w = (k == 0 || k == K - 1) ? 1.f : 2.f;
+                s += w * h * h * pw[j * 520 + k];
+            }
+            s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+            if ((tid & 7) == 0) p.band_energy[((long long)a * p.n_frames + f + j) * p.nbins + b] = s / ((float)FFT_N * (float)FFT_N) * 0.5f;
+        }
+        // band correlations at the steering delays
+        for (int e = tid; e < nb * BD; e += 512) {
+            const int j = e / BD, r = e - j * BD, b = r / p.D, d = r - b * p.D;
+            float s = 0.f;
+            for (int k = p.lo[b]; k <= p.hi[b]; ++k) {
+                const float2 g = G[j * 520 + k], t = p.T[(long long)k * p.D + d];
+                s += g.x * t.x - g.y * t.y;
+            }
+            p.raw[((long long)a * p.n_frames + f + j) * BD + r] = s;
+        }
+        __syncthreads();
+    }
+}
+
 // grid (chunks, arrays), blockDim = roundup(nbins * D, 64).  LDS: sC [chunk][BD] float, sE [chunk][D] float, sIdx [chunk][nbins] int
 __global__ __launch_bounds__(1024) void k_mb_scan(MbScanArgs p)
 {
