@@ -229,7 +229,7 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
         // 128 x 192 tiles: small batches (a single stream) would leave most CUs idle and walk the whole K range
         // in a handful of workgroups (0.29 ms however few frames); split K until ~512 workgroups exist, keeping
         // at least 8 K steps per workgroup
-        const long long wgs = (rows + 127) / 128 * (c->Dp / 192);
+        const long long wgs = (rows + 127) / 128 * (c->Dp == 64 ? 1 : c->Dp / 192);
         const int nk = c->Kp / (c->prec == MCA_HIP_SRP_FP32 ? 16 : 32);
         long long ks = 512 / (wgs > 0 ? wgs : 1);
         if (ks > nk / 8) ks = nk / 8;
@@ -399,7 +399,9 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     c->D = (int)(std::round(M_PI / (double)c->step) + 1);                   // :40
     if (c->D < 3 || c->D > 512) { free_ctx(c); return fail(nullptr, MCA_HIP_ERR_UNSUPPORTED, "number of steering angles must be in [3,512]"); }
     c->P = c->M * (c->M - 1) / 2;
-    c->Dp = round_up(c->D, 192);
+    // column padding of the correlation map = tile width of the contraction kernels: 192, or 64 for the fp16 kernels on
+    // grids of up to 64 angles (the reference's own 37, the 2-microphone module's 61)
+    c->Dp = (c->D <= 64 && c->prec != MCA_HIP_SRP_FP32) ? 64 : round_up(c->D, 192);
     c->H = c->N / 2;
     // stream API: the tuned 1024-sample kernels, or the any-power-of-two kernels (kernels_generic.hip)
     // whose channel spectra of one frame must fit the 160 KiB LDS of a CU
@@ -669,16 +671,18 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             else V2_LAUNCH((k_srp_gemm_f16_v2<false>));
 #undef V2_LAUNCH
         } else {
-            dim3 g2((ga.rows + 127) / 128, c->Dp / 192, ksplit);
+            dim3 g2((ga.rows + 127) / 128, c->Dp == 64 ? 1 : c->Dp / 192, ksplit);
             if (c->prec == MCA_HIP_SRP_FP32) hipLaunchKernelGGL(k_srp_gemm_f32, g2, dim3(256), 0, st, ga);
-            else if (c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL(k_srp_gemm_f16<true>, g2, dim3(256), 0, st, ga);
-            else hipLaunchKernelGGL(k_srp_gemm_f16<false>, g2, dim3(256), 0, st, ga);
+            else if (c->Dp == 64 && c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL((k_srp_gemm_f16<true, 64>), g2, dim3(256), 0, st, ga);
+            else if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_f16<false, 64>), g2, dim3(256), 0, st, ga);
+            else if (c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL((k_srp_gemm_f16<true, 192>), g2, dim3(256), 0, st, ga);
+            else hipLaunchKernelGGL((k_srp_gemm_f16<false, 192>), g2, dim3(256), 0, st, ga);
         }
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
     }
     if (c->c_planes > 2) {      // deep split-K of a small batch: fold the partial maps once, the scans read one map
-        const long long n4 = c->c_plane / 4;       // Dp is a multiple of 192
+        const long long n4 = c->c_plane / 4;       // Dp is a multiple of 64
         time_begin(c, MCA_HIP_K_FOLD, st);
         hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, c->d_C, n4, c->c_planes, c->c_plane);
         time_end(c, st);

@@ -17,7 +17,7 @@ template <typename OutT> __global__ void k_stft_phat_gen(StftPhatArgs p);
 __global__ void k_beamform_gen(BeamformArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);
-template <bool SPLIT> __global__ void k_srp_gemm_f16(GemmArgs p);
+template <bool SPLIT, int BN> __global__ void k_srp_gemm_f16(GemmArgs p);
 template <bool SPLIT> __global__ void k_srp_gemm_f16_v2(GemmArgs p);
 
 template <typename T> struct C2;

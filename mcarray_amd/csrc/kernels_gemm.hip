@@ -107,44 +107,50 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f32(GemmArgs p)
 // ---------------------------------------------------------------------------------------
 // fp16 operands, fp32 accumulate: v_mfma_f32_32x32x16_f16.  A: [rows][planes*Kp] halves
 // (k contiguous, lo plane after hi plane), B: [planes][Dp][Kp] halves (k contiguous).
-// Block tile 128 x 192, 4 waves as 2 x 2, BK = 32 halves.  Fragments: lane l holds
+// Block tile 128 x BN (192 or 64), BK = 32 halves.  Fragments: lane l holds
 // A[row l&31][k = 8 (l>>5) + 0..7] (one 16-byte LDS read).  LDS rows are 64 B + 16 B pad
 // (stride 80 B): ds_read_b128 of 16-lane groups then covers all 64 banks without conflict
 // (rows r..r+15 at stride 20 dwords hit distinct 4-bank slots).
 // SPLIT = false: C += Ahi Bhi.   SPLIT = true: C += Ahi Bhi + Alo Bhi + Ahi Blo  (~fp32 accuracy).
 // ---------------------------------------------------------------------------------------
-constexpr int G16_BM = 128, G16_BN = 192, G16_BK = 32, G16_LD = 40;   // LD in halves (80 B)
+constexpr int G16_BM = 128, G16_BK = 32, G16_LD = 40;   // LD in halves (80 B)
 
-template <bool SPLIT>
+// BN = 192: 4 waves as 2 x 2, wave tile 64 x 96.  BN = 64 (grids of up to 64 angles: the reference's own 37 and
+// the 2-microphone 61): 4 waves as 4 x 1, wave tile 32 x 64 -- a third of the B traffic, LDS and MFMA work of a
+// 192-wide tile whose columns would mostly be padding.
+template <bool SPLIT, int BN>
 __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
 {
     constexpr int NP = SPLIT ? 2 : 1;
+    constexpr int WN = BN == 192 ? 2 : 1, WM = 4 / WN;            // waves across columns / rows
+    constexpr int NI = G16_BM / WM / 32, NJ = BN / WN / 32;       // 32 x 32 MFMA tiles per wave
+    constexpr int NBL = BN * 4 / 256;                             // 16-byte B chunks per thread and plane
     __shared__ __attribute__((aligned(16))) _Float16 As[NP][G16_BM][G16_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[NP][G16_BN][G16_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[NP][BN][G16_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int row0 = blockIdx.x * G16_BM, col0 = blockIdx.y * G16_BN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int row0 = blockIdx.x * G16_BM, col0 = blockIdx.y * BN;
     const _Float16 *A = reinterpret_cast<const _Float16 *>(p.A);
     const _Float16 *B = reinterpret_cast<const _Float16 *>(p.B);
 
-    f32x16 acc[2][3];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // global loads: 16 B = 8 halves per thread; a BK=32 row is 64 B = 4 chunks.
-    // A tile: 128 rows x 4 chunks = 512 chunks -> 2 per thread; B tile: 192 x 4 = 768 -> 3 per thread.
+    // A tile: 128 rows x 4 chunks = 512 chunks -> 2 per thread; B tile: BN x 4 chunks -> NBL per thread.
     const int lr = tid >> 2, lc = tid & 3;
-    f16x8 ra[NP][2], rb[NP][3];
+    f16x8 ra[NP][2], rb[NP][NBL];
     const int ar0 = min(row0 + lr, p.rows - 1), ar1 = min(row0 + lr + 64, p.rows - 1);
 #define G16_GLOAD(k0)                                                                                                          \
     _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                                                        \
         ra[pl][0] = *reinterpret_cast<const f16x8 *>(A + (long long)ar0 * p.a_row_elems + pl * p.Kp + (k0) + lc * 8);          \
         ra[pl][1] = *reinterpret_cast<const f16x8 *>(A + (long long)ar1 * p.a_row_elems + pl * p.Kp + (k0) + lc * 8);          \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NBL; ++i)                                                                        \
             rb[pl][i] = *reinterpret_cast<const f16x8 *>(B + ((long long)pl * p.Dp + col0 + lr + 64 * i) * p.Kp + (k0) + lc * 8); \
     }
     const int nk_all = p.Kp / G16_BK, per = (nk_all + gridDim.z - 1) / gridDim.z;   // split-K over blockIdx.z
@@ -156,25 +162,25 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
             *reinterpret_cast<f16x8 *>(&As[pl][lr][lc * 8]) = ra[pl][0];
             *reinterpret_cast<f16x8 *>(&As[pl][lr + 64][lc * 8]) = ra[pl][1];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) *reinterpret_cast<f16x8 *>(&Bs[pl][lr + 64 * i][lc * 8]) = rb[pl][i];
+            for (int i = 0; i < NBL; ++i) *reinterpret_cast<f16x8 *>(&Bs[pl][lr + 64 * i][lc * 8]) = rb[pl][i];
         }
         __syncthreads();
         if (kt + 1 < nk) { G16_GLOAD((kt + 1) * G16_BK) }
 #pragma unroll
         for (int kk = 0; kk < G16_BK; kk += 16) {
             const int ko = kk + 8 * (lane >> 5);
-            f16x8 af[NP][2], bf[NP][3];
+            f16x8 af[NP][NI], bf[NP][NJ];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[pl][i] = *reinterpret_cast<const f16x8 *>(&As[pl][wm * 64 + i * 32 + (lane & 31)][ko]);
+                for (int i = 0; i < NI; ++i) af[pl][i] = *reinterpret_cast<const f16x8 *>(&As[pl][wm * (32 * NI) + i * 32 + (lane & 31)][ko]);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) bf[pl][j] = *reinterpret_cast<const f16x8 *>(&Bs[pl][wn * 96 + j * 32 + (lane & 31)][ko]);
+                for (int j = 0; j < NJ; ++j) bf[pl][j] = *reinterpret_cast<const f16x8 *>(&Bs[pl][wn * (32 * NJ) + j * 32 + (lane & 31)][ko]);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     if constexpr (SPLIT) {
                         // small terms first so they are not absorbed by the large partial sum
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
@@ -185,22 +191,25 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
         }
         __syncthreads();
     }
+#undef G16_GLOAD
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int frow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int frow = row0 + wm * (32 * NI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (frow < p.rows) {
                 const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
-                float *crow = p.C + (long long)blockIdx.z * p.c_plane_elems + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * 96 + (lane & 31);
+                float *crow = p.C + (long long)blockIdx.z * p.c_plane_elems + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * (32 * NJ) + (lane & 31);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) crow[j * 32] = acc[i][j][r];
+                for (int j = 0; j < NJ; ++j) crow[j * 32] = acc[i][j][r];
             }
         }
 }
 
-template __global__ void k_srp_gemm_f16<false>(GemmArgs);
-template __global__ void k_srp_gemm_f16<true>(GemmArgs);
+template __global__ void k_srp_gemm_f16<false, 192>(GemmArgs);
+template __global__ void k_srp_gemm_f16<true, 192>(GemmArgs);
+template __global__ void k_srp_gemm_f16<false, 64>(GemmArgs);
+template __global__ void k_srp_gemm_f16<true, 64>(GemmArgs);
 
 // ---------------------------------------------------------------------------------------
 // The 256 x 384 contraction kernel for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction is
