@@ -252,6 +252,48 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *ctx, const float *pcm_dev, long long a
 int mca_hip_mb_frames_host(mca_hip_mb_ctx *ctx, const float *pcm, int n_arrays, int n_frames, float *doa_rad, float *prob,
                            unsigned char *voiced, float *power, int *band_idx, float *energy_in_doa, float *band_corr);
 
+/* ---- MVDR-style beamformer with a per-bin spatial covariance (BASELINE.json configs[3]) ---------
+ * [BUILD-DEFINES -- NO REFERENCE COUNTERPART]: the reference's only beamformer is the delay-and-sum of
+ * mca::Beamformer::processFrame (src/mcarray/Beamformer.cpp:51-71); this module keeps its interface shape
+ * (frames in, one output channel, a look direction in radians) and its steering convention (Beamformer.cpp:59:
+ * x coordinate only, cos(DOA + pi/2)), and replaces the uniform weights 1/M by the minimum-variance
+ * distortionless-response weights of SURVEY A.9.  Per stream and bin k:
+ *     Phi_t = alpha Phi_{t-1} + (1 - alpha) x x^H,   PhiL = Phi_t + loading tr(Phi_t)/M I,
+ *     w = PhiL^-1 d / (d^H PhiL^-1 d),  d_m = exp(+j 2 pi k fs x_m sin(DOA) / (N c)),   Y[k] = w^H x.
+ * A bin whose covariance trace is <= 1e-30 (digital silence so far) uses w = d/M, i.e. the reference's
+ * delay-and-sum.  With alpha = 0 ... 1 and loading > 0 the response towards DOA is exactly 1 (w^H d = 1). */
+typedef struct mca_hip_mvdr_ctx mca_hip_mvdr_ctx;
+typedef struct {
+    int struct_size;
+    int device;
+    int sample_rate;
+    int fft_size;            /* N, power of two 64..8192 with n_mics spectra of N/2+1 bins within the 160 KiB LDS */
+    int n_mics;              /* M, 2..16 */
+    const double *mic_xyz;   /* [M][3] metres */
+    double alpha;            /* covariance memory, SURVEY A.9: 0.95 */
+    double loading;          /* diagonal loading relative to tr(Phi)/M, SURVEY A.9: 1e-3 */
+    int max_streams;         /* independent streams whose covariance / overlap-add state the context holds */
+} mca_hip_mvdr_config;
+int  mca_hip_mvdr_create(const mca_hip_mvdr_config *cfg, mca_hip_mvdr_ctx **out);
+void mca_hip_mvdr_destroy(mca_hip_mvdr_ctx *ctx);
+const char *mca_hip_mvdr_last_error(const mca_hip_mvdr_ctx *ctx);
+int  mca_hip_mvdr_reset(mca_hip_mvdr_ctx *ctx, void *stream);      /* Phi = 0, overlap-add tails = 0 */
+/* STFT analysis + the recursion above + inverse FFT + overlap-add for n_frames consecutive frames of n_streams
+ * independent M-microphone streams (PCM layout as in mca_hip_process_frames_dev).
+ *   doa_rad_dev  [streams][F] float   look direction per frame (e.g. the doa_rad output of mca_hip_localise_frames_dev)
+ *   out_pcm_dev  [streams][F*hop] float (may be NULL)
+ *   out_spec_dev [streams][F][N/2+1] interleaved re,im float: the beamformed spectra Y (may be NULL) */
+int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *ctx, const float *pcm_dev, long long stream_stride, long long mic_stride,
+                            int n_streams, int n_frames, const float *doa_rad_dev, float *out_pcm_dev,
+                            float *out_spec_dev, void *stream);
+int mca_hip_mvdr_frames_host(mca_hip_mvdr_ctx *ctx, const float *pcm, int n_streams, int n_frames, const float *doa_rad,
+                             float *out_pcm, float *out_spec);
+/* copy of the covariance of one stream: out[N/2+1][M][M] interleaved re,im double (full Hermitian matrices) */
+int mca_hip_mvdr_get_covariance(mca_hip_mvdr_ctx *ctx, int stream_index, double *out);
+/* per-kernel timing as mca_hip_set_timing / mca_hip_get_timing: kernel_id 0 = analysis, 1 = solve, 2 = synthesis */
+int mca_hip_mvdr_set_timing(mca_hip_mvdr_ctx *ctx, int enable);
+int mca_hip_mvdr_get_timing(mca_hip_mvdr_ctx *ctx, int kernel_id, int *launches, double *total_ms);
+
 /* ---- measurement ------------------------------------------------------------ */
 typedef enum {
     MCA_HIP_K_STFT_PHAT = 0,   /* STFT + PHAT whitening + pair-group sums */

@@ -62,6 +62,20 @@ class MbConfig(C.Structure):
     ]
 
 
+class MvdrConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int),
+        ("device", C.c_int),
+        ("sample_rate", C.c_int),
+        ("fft_size", C.c_int),
+        ("n_mics", C.c_int),
+        ("mic_xyz", c_dp),
+        ("alpha", C.c_double),
+        ("loading", C.c_double),
+        ("max_streams", C.c_int),
+    ]
+
+
 # every symbol include/mcarray_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mca_hip_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
@@ -117,6 +131,16 @@ SYMBOLS = [
       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mca_hip_mb_frames_host", C.c_int,
      [C.c_void_p, c_fp, C.c_int, C.c_int, c_fp, c_fp, C.c_void_p, c_fp, c_ip, c_fp, c_fp]),
+    ("mca_hip_mvdr_create", C.c_int, [C.POINTER(MvdrConfig), C.POINTER(C.c_void_p)]),
+    ("mca_hip_mvdr_destroy", None, [C.c_void_p]),
+    ("mca_hip_mvdr_last_error", C.c_char_p, [C.c_void_p]),
+    ("mca_hip_mvdr_reset", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mca_hip_mvdr_frames_dev", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mca_hip_mvdr_frames_host", C.c_int, [C.c_void_p, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp]),
+    ("mca_hip_mvdr_get_covariance", C.c_int, [C.c_void_p, C.c_int, c_dp]),
+    ("mca_hip_mvdr_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("mca_hip_mvdr_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
     ("mca_hip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("mca_hip_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
     ("mca_hip_reset_timing", C.c_int, [C.c_void_p]),

@@ -399,6 +399,89 @@ class MultibandBinarualLocalisation:
         return dict(doa=doa, prob=prob, voiced=voiced, power=power, band_idx=bi, energy_in_doa=eid, band_corr=bc)
 
 
+class MvdrBeamformer:
+    """Frequency-domain beamformer with a per-bin spatial covariance (BASELINE.json configs[3]; SURVEY A.9).
+    No reference counterpart: the interface follows mca::Beamformer (Beamformer.h:39,49: frames in, one channel out,
+    a look direction in radians) with the delay-and-sum weights replaced by MVDR weights."""
+
+    K_ANALYSE, K_SOLVE, K_SYNTH = 0, 1, 2
+
+    def __init__(self, sample_rate, mic_positions, fft_size=1024, alpha=0.95, loading=1e-3, max_streams=1, device=0):
+        self._lib = _lib.load()
+        xyz = _xyz(mic_positions)
+        cfg = _lib.MvdrConfig()
+        cfg.struct_size = C.sizeof(_lib.MvdrConfig)
+        cfg.device = device
+        cfg.sample_rate = sample_rate
+        cfg.fft_size = fft_size
+        cfg.n_mics = len(xyz)
+        cfg.mic_xyz = xyz.ctypes.data_as(_lib.c_dp)
+        cfg.alpha = alpha
+        cfg.loading = loading
+        cfg.max_streams = max_streams
+        h = C.c_void_p()
+        rc = self._lib.mca_hip_mvdr_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise MCArrayHipError("mca_hip_mvdr_create failed (%d): %s" % (rc, self._lib.mca_hip_mvdr_last_error(None).decode()))
+        self.h = h
+        self.M, self.N, self.hop, self.K = len(xyz), fft_size, fft_size // 2, fft_size // 2 + 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.mca_hip_mvdr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MCArrayHipError("libmcarray_hip error %d: %s" % (rc, self._lib.mca_hip_mvdr_last_error(self.h).decode()))
+
+    def reset(self):
+        self._check(self._lib.mca_hip_mvdr_reset(self.h, None))
+
+    def process(self, pcm, doa_rad, want_audio=True, want_spec=False):
+        """pcm float32 [streams][M][(F+1)*hop], doa_rad [streams][F] (or a scalar) ->
+        dict(out [streams][F*hop], spec complex64 [streams][F][K])"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if pcm.ndim == 2:
+            pcm = pcm[None]
+        A, M, L = pcm.shape
+        F = L // self.hop - 1
+        if M != self.M or F < 1 or (F + 1) * self.hop != L:
+            raise MCArrayHipError("pcm must be [streams][M][(F+1)*hop]")
+        doa = np.ascontiguousarray(np.broadcast_to(np.asarray(doa_rad, dtype=np.float32), (A, F)))
+        out = np.empty((A, F * self.hop), dtype=np.float32) if want_audio else None
+        spec = np.empty((A, F, self.K), dtype=np.complex64) if want_spec else None
+        fp = _lib.c_fp
+        self._check(self._lib.mca_hip_mvdr_frames_host(
+            self.h, pcm.ctypes.data_as(fp), A, F, doa.ctypes.data_as(fp), out.ctypes.data_as(fp) if want_audio else None,
+            spec.ctypes.data_as(fp) if want_spec else None))
+        return dict(out=out, spec=spec)
+
+    def process_dev(self, pcm, n_frames, doa_rad, out_pcm=None, out_spec=None, stream=None):
+        """device tensors (torch, contiguous): pcm [streams][M][>= (F+1)*hop] float32, doa_rad [streams][F] float32,
+        out_pcm [streams][F*hop], out_spec [streams][F][K][2]; asynchronous on `stream` (a raw hipStream_t or None)."""
+        A = pcm.shape[0]
+        self._check(self._lib.mca_hip_mvdr_frames_dev(
+            self.h, pcm.data_ptr(), pcm.stride(0), pcm.stride(1), A, n_frames, doa_rad.data_ptr(),
+            out_pcm.data_ptr() if out_pcm is not None else None, out_spec.data_ptr() if out_spec is not None else None, stream))
+
+    def covariance(self, stream_index=0):
+        out = np.empty((self.K, self.M, self.M, 2))
+        self._check(self._lib.mca_hip_mvdr_get_covariance(self.h, stream_index, out.ctypes.data_as(_lib.c_dp)))
+        return out[..., 0] + 1j * out[..., 1]
+
+    def set_timing(self, enable):
+        self._check(self._lib.mca_hip_mvdr_set_timing(self.h, int(enable)))
+
+    def get_timing(self, kernel_id):
+        n, ms = C.c_int(0), C.c_double(0)
+        self._check(self._lib.mca_hip_mvdr_get_timing(self.h, kernel_id, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
 FACTOR, RELATIVE, FULL, NOISY, NOTHING = 0, 1, 3, 4, 5      # BinauralMasking::MaskingMethod (ArrayModules.h:81)
 BOTH, SPATIAL, TEMPORAL = 0, 1, 2                           # BinauralMasking::MaskingAlg (ArrayModules.h:89)
 

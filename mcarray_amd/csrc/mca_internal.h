@@ -195,4 +195,36 @@ struct MbSummaryArgs {
     float *doa_rad, *prob, *power; unsigned char *voiced;   // [arrays][n_frames]
 };
 
+// ---- MVDR-style beamformer with a per-bin spatial covariance (BASELINE configs[3]) ----
+struct MvdrAnalyseArgs {
+    const float *pcm;
+    long long stream_stride, mic_stride;
+    int n_frames, N, logH, M;
+    const float *window;
+    const float2 *tw;         // [N/2]
+    const float *doa_rad;     // [streams][n_frames]
+    float2 *X;                // [streams][n_frames][K][M] one-sided spectra, microphone fastest
+    double *cdoa;             // [streams][n_frames] cos(DOA + pi/2) (Beamformer.cpp:59), evaluated in double
+};
+
+struct MvdrSolveArgs {
+    const float2 *X;          // [streams][n_frames][K][M]
+    const double *cdoa;       // [streams][n_frames]
+    const double *mic_x;      // [M] x coordinates (Beamformer.cpp:59 uses x only)
+    double unit;              // fs / N / 346.1
+    int n_frames, K, M;
+    float alpha, one_minus_alpha, loading_over_m;
+    float2 *phi;              // [streams][K][M(M+1)/2] lower triangle of the covariance, row-major
+    float *trace;             // [streams][K] tr(Phi), carried as its own recursion
+    float2 *Y;                // [streams][n_frames][K] beamformed spectrum
+};
+
+struct MvdrSynthArgs {
+    const float2 *Y;          // [streams][n_frames][K]
+    int n_frames, N, logH, ft;
+    const float2 *tw;
+    const float *tail_in; float *tail_out;   // [streams][N/2] overlap-add carry
+    float *out;               // [streams][n_frames * N/2]
+};
+
 }  // namespace mca

@@ -1082,3 +1082,134 @@ int mca_or_multiband_process(mca_or_multiband *m, const double *left, const doub
     free(E);
     return fired;
 }
+
+/* ======================================================================= */
+/* MVDR-style frequency-domain beamformer with a per-bin spatial covariance  */
+/* (BASELINE.json configs[3]).  [BUILD-DEFINES -- NO REFERENCE COUNTERPART]: */
+/* the reference has delay-and-sum only (Beamformer.cpp:51-71); the spec is  */
+/* SURVEY A.9.  Steering vector and sign conventions follow Beamformer.cpp:59 */
+/* so that w = d/M is exactly the reference's delay-and-sum.                  */
+/* ======================================================================= */
+
+struct mca_or_mvdr {
+    int fs, N, K, M;
+    double alpha, loading;
+    double *x;          /* [M] microphone x coordinates (Beamformer.cpp:59 uses x only) */
+    double *Phi;        /* [K][M][M] complex, row-major, re/im interleaved */
+};
+
+mca_or_mvdr *mca_or_mvdr_create(int fs, int N, const double *xyz, int M, double alpha, double loading)
+{
+    mca_or_mvdr *v = (mca_or_mvdr *)calloc(1, sizeof(*v));
+    v->fs = fs; v->N = N; v->K = N / 2 + 1; v->M = M; v->alpha = alpha; v->loading = loading;
+    v->x = (double *)malloc(sizeof(double) * (size_t)M);
+    for (int m = 0; m < M; ++m) v->x[m] = xyz[3 * m];
+    v->Phi = (double *)calloc((size_t)v->K * M * M * 2, sizeof(double));
+    return v;
+}
+
+void mca_or_mvdr_destroy(mca_or_mvdr *v)
+{
+    if (!v) return;
+    free(v->x); free(v->Phi); free(v);
+}
+
+void mca_or_mvdr_reset(mca_or_mvdr *v) { memset(v->Phi, 0, sizeof(double) * (size_t)v->K * v->M * v->M * 2); }
+
+const double *mca_or_mvdr_covariance(const mca_or_mvdr *v) { return v->Phi; }
+
+/* One frame.  frames[M] -> ccs double[N+2]; out ccs double[N+2]; DOA radians.
+ * Per bin k:  Phi <- alpha Phi + (1-alpha) x x^H ;  PhiL = Phi + loading tr(Phi)/M I ;
+ *             w = PhiL^-1 d / (d^H PhiL^-1 d) ;  Y[k] = w^H x
+ * with d_m = exp(-j k s_m), s_m = 2 pi fs/N/c x_m cos(DOA + pi/2) (the conjugate of the phasor Beamformer.cpp:59-64
+ * multiplies X_m by), i.e. d_m = exp(+j 2 pi k fs x_m sin(DOA) / (N c)).  Evaluated through the Cholesky factor
+ * PhiL = L L^H:  u = L^-1 d, v = L^-1 x, Y = (u^H v) / (u^H u).  A bin whose covariance trace is <= 1e-30 (digital
+ * silence so far) falls back to w = d/M, the reference's delay-and-sum. */
+void mca_or_mvdr_process_frame(mca_or_mvdr *v, const double *const *frames, double *out, double DOA)
+{
+    const int M = v->M, K = v->K;
+    double Lr[16 * 16], Li[16 * 16], dr[16], di[16], xr[16], xi[16], ur[16], ui[16], vr[16], vi[16];
+    const double cd = cos(DOA + M_PI / 2);
+    for (int k = 0; k < K; ++k) {
+        double *P = v->Phi + (size_t)k * M * M * 2;
+        for (int m = 0; m < M; ++m) {
+            xr[m] = frames[m][2 * k]; xi[m] = frames[m][2 * k + 1];
+            const double slope = 2 * M_PI * v->fs / v->N / mca_or_speed_of_sound() * v->x[m] * cd;   /* Beamformer.cpp:59 */
+            const double ph = slope * (double)k;
+            dr[m] = cos(ph); di[m] = -sin(ph);
+        }
+        double tr = 0;
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < M; ++j) {
+                /* x_i conj(x_j) */
+                const double pr = xr[i] * xr[j] + xi[i] * xi[j], pi = xi[i] * xr[j] - xr[i] * xi[j];
+                double *e = P + ((size_t)i * M + j) * 2;
+                e[0] = v->alpha * e[0] + (1 - v->alpha) * pr;
+                e[1] = v->alpha * e[1] + (1 - v->alpha) * pi;
+                if (i == j) tr += e[0];
+            }
+        double yr, yi;
+        if (!(tr > 1e-30)) {
+            yr = yi = 0;
+            for (int m = 0; m < M; ++m) { yr += dr[m] * xr[m] + di[m] * xi[m]; yi += dr[m] * xi[m] - di[m] * xr[m]; }
+            yr /= M; yi /= M;
+        } else {
+            const double delta = v->loading * tr / M;
+            /* Cholesky-Banachiewicz, lower triangle */
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double sr = P[((size_t)i * M + j) * 2] + (i == j ? delta : 0.0), si = (i == j) ? 0.0 : P[((size_t)i * M + j) * 2 + 1];
+                    for (int m = 0; m < j; ++m) {
+                        /* L[i][m] conj(L[j][m]) */
+                        sr -= Lr[i * 16 + m] * Lr[j * 16 + m] + Li[i * 16 + m] * Li[j * 16 + m];
+                        si -= Li[i * 16 + m] * Lr[j * 16 + m] - Lr[i * 16 + m] * Li[j * 16 + m];
+                    }
+                    if (i == j) { Lr[i * 16 + j] = sqrt(sr); Li[i * 16 + j] = 0; }
+                    else { Lr[i * 16 + j] = sr / Lr[j * 16 + j]; Li[i * 16 + j] = si / Lr[j * 16 + j]; }
+                }
+            /* forward substitutions u = L^-1 d, v = L^-1 x */
+            for (int i = 0; i < M; ++i) {
+                double ar = dr[i], ai = di[i], br = xr[i], bi = xi[i];
+                for (int m = 0; m < i; ++m) {
+                    ar -= Lr[i * 16 + m] * ur[m] - Li[i * 16 + m] * ui[m]; ai -= Lr[i * 16 + m] * ui[m] + Li[i * 16 + m] * ur[m];
+                    br -= Lr[i * 16 + m] * vr[m] - Li[i * 16 + m] * vi[m]; bi -= Lr[i * 16 + m] * vi[m] + Li[i * 16 + m] * vr[m];
+                }
+                ur[i] = ar / Lr[i * 16 + i]; ui[i] = ai / Lr[i * 16 + i];
+                vr[i] = br / Lr[i * 16 + i]; vi[i] = bi / Lr[i * 16 + i];
+            }
+            double nr = 0, ni = 0, den = 0;
+            for (int m = 0; m < M; ++m) {
+                nr += ur[m] * vr[m] + ui[m] * vi[m]; ni += ur[m] * vi[m] - ui[m] * vr[m];   /* conj(u) v */
+                den += ur[m] * ur[m] + ui[m] * ui[m];
+            }
+            yr = nr / den; yi = ni / den;
+        }
+        out[2 * k] = yr; out[2 * k + 1] = yi;
+    }
+}
+
+/* whole stream through the [BUILD-DEFINES] STFT engine: pcm M channels at pcm + c*stride,
+ * (F+1)*hop samples; doa_rad[F] look direction per frame; out_pcm[F*hop]; out_spec (may be NULL) [F][N+2]. */
+void mca_or_mvdr_stream(mca_or_mvdr *v, const double *pcm, long stride, int F, const double *doa_rad,
+                        double *out_pcm, double *out_spec)
+{
+    const int N = v->N, hop = N / 2, ccs = N + 2, M = v->M;
+    double *win = (double *)malloc(sizeof(double) * (size_t)N);
+    mca_or_hann_periodic(win, N);
+    double **fr = (double **)malloc(sizeof(double *) * (size_t)M);
+    for (int c = 0; c < M; ++c) fr[c] = (double *)malloc(sizeof(double) * (size_t)ccs);
+    double *Y = (double *)malloc(sizeof(double) * (size_t)ccs);
+    double *y = (double *)malloc(sizeof(double) * (size_t)N);
+    double *tail = (double *)calloc((size_t)hop, sizeof(double));
+    for (int t = 0; t < F; ++t) {
+        for (int c = 0; c < M; ++c) mca_or_stft_frame(pcm + (size_t)c * stride + (size_t)t * hop, win, N, fr[c]);
+        mca_or_mvdr_process_frame(v, (const double *const *)fr, Y, doa_rad[t]);
+        if (out_spec) memcpy(out_spec + (size_t)t * ccs, Y, sizeof(double) * (size_t)ccs);
+        if (out_pcm) {
+            mca_or_irfft_ccs(Y, N, y);
+            for (int n = 0; n < hop; ++n) { out_pcm[(size_t)t * hop + n] = tail[n] + y[n]; tail[n] = y[n + hop]; }
+        }
+    }
+    for (int c = 0; c < M; ++c) free(fr[c]);
+    free(fr); free(win); free(Y); free(y); free(tail);
+}

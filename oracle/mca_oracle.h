@@ -183,6 +183,21 @@ int  mca_or_multiband_process(mca_or_multiband *m, const double *left, const dou
                               int *band_idx, double *band_energy, double *band_corr /* nbins*D */,
                               double *energy_in_doa, double *doa_rad, double *prob, double *power);
 
+/* ---- MVDR-style beamformer with a per-bin spatial covariance (BASELINE.json configs[3]) --------------
+ * [BUILD-DEFINES -- NO REFERENCE COUNTERPART]: the reference has delay-and-sum only (Beamformer.cpp:51-71);
+ * the spec is SURVEY A.9 ("parity unpinned" against the reference by construction).  Conventions follow
+ * Beamformer.cpp:59 so that w = d/M reproduces the reference's delay-and-sum exactly:
+ *   Phi_t[k] = alpha Phi_{t-1}[k] + (1-alpha) x x^H,  PhiL = Phi + loading tr(Phi)/M I,
+ *   d_m = exp(+j 2 pi k fs x_m sin(DOA)/(N c)),  w = PhiL^-1 d / (d^H PhiL^-1 d),  Y[k] = w^H x.         */
+typedef struct mca_or_mvdr mca_or_mvdr;
+mca_or_mvdr *mca_or_mvdr_create(int fs, int N, const double *xyz, int M, double alpha, double loading);
+void mca_or_mvdr_destroy(mca_or_mvdr *v);
+void mca_or_mvdr_reset(mca_or_mvdr *v);
+const double *mca_or_mvdr_covariance(const mca_or_mvdr *v);      /* [K][M][M] complex */
+void mca_or_mvdr_process_frame(mca_or_mvdr *v, const double *const *frames, double *out, double DOA);
+void mca_or_mvdr_stream(mca_or_mvdr *v, const double *pcm, long stride, int F, const double *doa_rad,
+                        double *out_pcm, double *out_spec);
+
 #ifdef __cplusplus
 }
 #endif

@@ -362,3 +362,41 @@ def multiband_stream(fs, N, xs, pcm, nbins=15, use_power_floor=True):
             pr = -100000.0
         out["doa"][t], out["prob"][t], out["power"][t], out["energy_in_doa"][t] = cur, pr, power, E
     return out
+
+
+# ---- MVDR-style beamformer with a per-bin spatial covariance (no reference counterpart) ----
+def mvdr_stream(fs, N, xs, pcm, doa_rad, alpha=0.95, loading=1e-3):
+    """Independent of the C oracle: full-matrix numpy.linalg.solve instead of the Cholesky / forward-substitution form.
+    pcm [M][(F+1)*hop]; doa_rad [F].  Returns dict(out [F*hop], spec [F][K] complex, phi [K][M][M])."""
+    x = np.asarray(xs, dtype=np.float64)
+    if x.ndim == 2:
+        x = x[:, 0]
+    M = len(x)
+    hop, K = N // 2, N // 2 + 1
+    X = stft_frames(pcm, N)                                   # complex [F][M][K]
+    F = X.shape[0]
+    doa = np.broadcast_to(np.asarray(doa_rad, dtype=np.float64), (F,))
+    Phi = np.zeros((K, M, M), dtype=np.complex128)
+    k = np.arange(K, dtype=np.float64)
+    spec = np.zeros((F, K), dtype=np.complex128)
+    out = np.zeros(F * hop)
+    tail = np.zeros(hop)
+    eye = np.eye(M)
+    for t in range(F):
+        Xc = X[t].T                                                   # [K][M]
+        slope = 2 * np.pi * fs / N / C_SOUND * x * np.cos(doa[t] + np.pi / 2)   # Beamformer.cpp:59
+        d = np.exp(-1j * k[:, None] * slope[None, :])                 # [K][M]: conj of the phasor X_m is multiplied by
+        Phi = alpha * Phi + (1 - alpha) * Xc[:, :, None] * np.conj(Xc[:, None, :])
+        tr = np.real(np.trace(Phi, axis1=1, axis2=2))
+        for kk in range(K):
+            if not tr[kk] > 1e-30:
+                spec[t, kk] = np.vdot(d[kk], Xc[kk]) / M
+                continue
+            PL = Phi[kk] + loading * tr[kk] / M * eye
+            g = np.linalg.solve(PL, d[kk])
+            w = g / np.vdot(d[kk], g)
+            spec[t, kk] = np.vdot(w, Xc[kk])
+        y = irfft_ccs(spec[t], N)
+        out[t * hop:(t + 1) * hop] = tail + y[:hop]
+        tail = y[hop:]
+    return dict(out=out, spec=spec, phi=Phi)

@@ -115,6 +115,14 @@ def lib():
         L.mca_or_masking_process.argtypes = [C.c_void_p, c_dp, c_dp, c_ip]
         L.mca_or_masking_stream.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int, c_dp, c_dp]
         L.mca_or_mel_filterbank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, c_dp, c_dp]
+        L.mca_or_mvdr_create.restype = C.c_void_p
+        L.mca_or_mvdr_create.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_double, C.c_double]
+        L.mca_or_mvdr_destroy.argtypes = [C.c_void_p]
+        L.mca_or_mvdr_reset.argtypes = [C.c_void_p]
+        L.mca_or_mvdr_covariance.restype = c_dp
+        L.mca_or_mvdr_covariance.argtypes = [C.c_void_p]
+        L.mca_or_mvdr_process_frame.argtypes = [C.c_void_p, C.POINTER(c_dp), c_dp, C.c_double]
+        L.mca_or_mvdr_stream.argtypes = [C.c_void_p, c_dp, C.c_long, C.c_int, c_dp, c_dp, c_dp]
         _LIB = L
     return _LIB
 
@@ -398,6 +406,48 @@ class Multiband:
                                            C.byref(doa), C.byref(prob), C.byref(power))
         return dict(fired=bool(v), band_idx=bi, band_energy=be, band_corr=bc, energy_in_doa=eid, doa=doa.value,
                     prob=prob.value, power=power.value)
+
+
+class MVDR:
+    """MVDR-style beamformer with a per-bin spatial covariance, SURVEY A.9 [BUILD-DEFINES, no reference counterpart]."""
+
+    def __init__(self, fs, N, xyz, alpha=0.95, loading=1e-3):
+        self.xyz = _xyz(xyz)
+        self.M = len(self.xyz)
+        assert self.M <= 16
+        self.N, self.K = N, N // 2 + 1
+        self.h = lib().mca_or_mvdr_create(fs, N, _dp(self.xyz), self.M, alpha, loading)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mca_or_mvdr_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        lib().mca_or_mvdr_reset(self.h)
+
+    def covariance(self):
+        p = lib().mca_or_mvdr_covariance(self.h)
+        a = np.ctypeslib.as_array(p, shape=(self.K, self.M, self.M, 2)).copy()
+        return a[..., 0] + 1j * a[..., 1]
+
+    def process_frame(self, frames, doa):
+        """frames [M][N+2] CCS -> out [N+2] CCS"""
+        rows = [np.ascontiguousarray(f, dtype=np.float64) for f in frames]
+        out = np.zeros(self.N + 2)
+        lib().mca_or_mvdr_process_frame(self.h, _ptr_array(rows), _dp(out), float(doa))
+        return out
+
+    def stream(self, pcm, doa_rad, want_spec=False):
+        """pcm [M][(F+1)*hop] double, doa_rad [F] -> dict(out [F*hop], spec [F][N+2] or None)"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float64)
+        hop = self.N // 2
+        F = pcm.shape[1] // hop - 1
+        doa = np.ascontiguousarray(np.broadcast_to(np.asarray(doa_rad, dtype=np.float64), (F,)))
+        out = np.zeros(F * hop)
+        spec = np.zeros((F, self.N + 2)) if want_spec else None
+        lib().mca_or_mvdr_stream(self.h, _dp(pcm), pcm.shape[1], F, _dp(doa), _dp(out), _dp(spec) if want_spec else None)
+        return dict(out=out, spec=spec)
 
 
 FACTOR, RELATIVE, FULL, NOISY, NOTHING = 0, 1, 3, 4, 5

@@ -93,6 +93,17 @@ def multiband_case(name, fs, N, d, nbins, theta_deg, F, seed):
     print(name, "doa", np.rad2deg(r["doa"]))
 
 
+def mvdr_case(name, xs, fs, N, F, seed, look_deg, interferer_deg):
+    n = (F + 1) * N // 2
+    pcm = (synth.noise_source_stream(xs, np.deg2rad(look_deg), fs, n, seed)
+           + synth.noise_source_stream(xs, np.deg2rad(interferer_deg), fs, n, seed + 100, snr_db=60)).astype(np.float32)
+    doa = (np.deg2rad(look_deg) + 0.002 * np.arange(F)).astype(np.float32)      # a slowly moving look direction
+    r = tw.mvdr_stream(fs, N, xs, pcm.astype(np.float64), doa.astype(np.float64))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), xs=np.asarray(xs), fs=fs, N=N, pcm=pcm, doa=doa,
+                        out=r["out"].astype(np.float32), spec=r["spec"].astype(np.complex64), phi_last=r["phi"][::64].astype(np.complex64))
+    print(name, "out rms", float(np.sqrt(np.mean(r["out"] ** 2))))
+
+
 if __name__ == "__main__":
     ssl_case("ssl_reemc_d37", synth.REEM_C, 48000, 1024, 5.0, 20.0, 8, 11)
     ssl_case("ssl_ula8_d361", synth.ULA8, 48000, 1024, 0.5, -33.0, 6, 12)
@@ -103,3 +114,5 @@ if __name__ == "__main__":
     masking_case("mask_noisy_spatial", 16000, 1024, 0.086, 500.0, 5000.0, 4, 1, 7, 24, delay=1, nlev=0.003)
     freqgcc_case("freqgcc_16k_d61", 16000, 1024, 0.086, 3.0, 30.0, 6, 31)
     multiband_case("multiband_48k_b15", 48000, 1024, 0.086, 15, -35.0, 8, 41)
+    mvdr_case("mvdr_ula16_48k", synth.ULA16, 48000, 1024, 6, 51, 25.0, -40.0)
+    mvdr_case("mvdr_reemc_16k", synth.REEM_C, 16000, 512, 10, 52, -15.0, 55.0)
