@@ -106,7 +106,8 @@ def test_multiband_oracle_vs_twin_gated():
 def test_all_golden_files_are_covered(golden_dir):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_dir, "*.npz")))
     assert names == sorted(["ssl_reemc_d37", "ssl_ula8_d361", "ssl_reemc_d37_s2", "mask_relative_both", "mask_full_both",
-                            "mask_factor_temporal", "mask_noisy_spatial", "freqgcc_16k_d61", "multiband_48k_b15"])
+                            "mask_factor_temporal", "mask_noisy_spatial", "freqgcc_16k_d61", "multiband_48k_b15",
+                            "mvdr_ula16_48k", "mvdr_reemc_16k"])   # the mvdr_* files are covered by tests/test_oracle_mvdr.py
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
