@@ -6,6 +6,7 @@
 #include "BinauralLocalisation.h"
 #include "FastBinauralMasking.h"
 #include "MultibandBinarualLocalisation.h"
+#include "MvdrBeamformer.h"
 #include "Beamformer.h"
 #include "BeamformingSeparationAndLocalistaion.h"
 #include "SoundLocalisationCallback.h"

@@ -225,13 +225,14 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     sa.alpha = (float)c->cfg.alpha; sa.one_minus_alpha = (float)(1.0 - c->cfg.alpha);
     sa.loading_over_m = (float)(c->cfg.loading / c->M);
     sa.phi = c->d_phi; sa.trace = c->d_trace; sa.Y = Y;
-    const int LP = c->M <= 4 ? 4 : c->M <= 8 ? 8 : 16;
-    const int per_block = 4 * (64 / LP);
-    const dim3 sgrid((c->K + per_block - 1) / per_block, n_streams);
+    sa.n_streams = n_streams;
+    const int Q = (c->M + 3) / 4;                                                     // row slots per lane
+    const dim3 sgrid((unsigned)(((long long)n_streams * c->K + 63) / 64));
     t_begin(c, 1, st);
-    if (LP == 4) hipLaunchKernelGGL(k_mvdr_solve<4>, sgrid, dim3(256), 0, st, sa);
-    else if (LP == 8) hipLaunchKernelGGL(k_mvdr_solve<8>, sgrid, dim3(256), 0, st, sa);
-    else hipLaunchKernelGGL(k_mvdr_solve<16>, sgrid, dim3(256), 0, st, sa);
+    if (Q == 1) hipLaunchKernelGGL(k_mvdr_solve<1>, sgrid, dim3(256), 0, st, sa);
+    else if (Q == 2) hipLaunchKernelGGL(k_mvdr_solve<2>, sgrid, dim3(256), 0, st, sa);
+    else if (Q == 3) hipLaunchKernelGGL(k_mvdr_solve<3>, sgrid, dim3(256), 0, st, sa);
+    else hipLaunchKernelGGL(k_mvdr_solve<4>, sgrid, dim3(256), 0, st, sa);
     t_end(c, st);
 
     if (out_pcm) {

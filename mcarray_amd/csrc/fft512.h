@@ -59,6 +59,20 @@ __device__ __forceinline__ float2 cmacc(float2 acc, float2 a, float2 b)  // acc 
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(u));   // (a.y b.y + u.lo, -a.x b.y + u.hi)
     return from_v2f(r);
 }
+__device__ __forceinline__ float2 cnmac(float2 acc, float2 a, float2 b)   // acc - a * b
+{
+    v2f av = to_v2f(a), bv = to_v2f(b), cv = to_v2f(acc), u, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(u) : "v"(av), "v"(bv), "v"(cv));   // (c.x - a.x b.x, c.y - a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(u));                  // (u.lo + a.y b.y, u.hi - a.y b.x)
+    return from_v2f(r);
+}
+__device__ __forceinline__ float2 cnmacc(float2 acc, float2 a, float2 b)  // acc - a * conj(b)
+{
+    v2f av = to_v2f(a), bv = to_v2f(b), cv = to_v2f(acc), u, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(u) : "v"(av), "v"(bv), "v"(cv));   // (c.x - a.x b.x, c.y - a.y b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(u));                  // (u.lo - a.y b.y, u.hi + a.x b.y)
+    return from_v2f(r);
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }

@@ -10,11 +10,11 @@
 // forward substitutions, no back substitution, and only cond(L) = sqrt(cond(PhiL)) enters the fp32 error.
 //
 //   k_mvdr_analyse   PCM -> windowed N-pt real FFT of the M channels -> X [stream][frame][bin][mic]
-//   k_mvdr_solve     the recursion + factorisation above; LP lanes per (stream, bin) problem, lane = matrix row
+//   k_mvdr_solve     the recursion + factorisation above; four lanes per (stream, bin) problem, rows dealt cyclically
 //   k_mvdr_synth     Y -> inverse FFT -> overlap-add
 //
 // The covariance (M(M+1)/2 complex per bin: 1.1 KB at M = 16, 0.56 MB per stream) never leaves the registers of
-// its LP lanes between frames of a call; HBM sees it once per call ("must stay in LDS/L2 ... or the
+// its four lanes between frames of a call; HBM sees it once per call ("must stay in LDS/L2 ... or the
 // path becomes state-traffic-bound").
 #include "fft_block.h"
 #include "mca_internal.h"
@@ -47,120 +47,161 @@ __global__ __launch_bounds__(1024) void k_mvdr_analyse(MvdrAnalyseArgs p)
 }
 
 // --------------------------------------------------------------------------------------
-// k_mvdr_solve<LP>: grid (ceil(K / (4 * 64/LP)), streams), 256 threads.  One (stream, bin) problem per group of LP
-// lanes (M <= LP), lane i = row i of the lower triangle.  Frames are walked in order inside the kernel.
+// k_mvdr_solve<Q>: grid (ceil(streams * K / 64)), 256 threads.  FOUR lanes per (stream, bin) problem: lane l of a quad
+// owns the rows l, l+4, l+8, ... of the lower triangles of Phi and L (Q = ceil(M/4) row slots, cyclic so that the
+// lanes stay balanced as the factorisation shrinks), all in registers.  Frames are walked in order inside the kernel.
 //
-// Step j of the factorisation (Cholesky-Banachiewicz by columns): lane j owns the finished row j of L; it computes the
-// pivot from its own registers, publishes row j, 1/L_jj, u_j and v_j in the group's LDS words, and every lane i > j
-// reads them (broadcast reads) to form L_ij and to take L_ij u_j / L_ij v_j off its residuals.  u^H v and u^H u are
-// accumulated by all lanes from the published values.  The groups of a wave run in lock step; the only
-// synchronisation is the wave-level LDS fence between the write and the reads of a step.
+// Factorisation by columns (Cholesky-Banachiewicz).  In step j the row j of L, the pivot and the residuals of the
+// two forward substitutions live in lane j%4; the other lanes of the quad get them with DPP quad-broadcast moves
+// (full-rate VALU, no LDS, no synchronisation), every lane then updates the rows it owns below j.  A problem costs
+// ~1/4 of the lane-instructions of a lane-per-row layout: the O(M^2) exchange is shared by up to four rows per lane
+// and no lane idles while the active part of the matrix shrinks.
 // --------------------------------------------------------------------------------------
-template <int LP>
-__global__ __launch_bounds__(256) void k_mvdr_solve(MvdrSolveArgs p)
+template <int B>
+__device__ __forceinline__ float quad_bcast1(float v)
 {
-    constexpr int GPW = 64 / LP;                 // problems per wave
-    constexpr int GS = 2 * LP + 4;               // float2 words per group: x[LP] | row[LP] | {1/L_jj, u_j, v_j, pad}
-    __shared__ __attribute__((aligned(16))) float2 sm[4 * GPW * GS];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane / LP, i = lane % LP;
-    const int M = p.M, K = p.K, F = p.n_frames, a = blockIdx.y;
-    const int k = (blockIdx.x * 4 + wave) * GPW + grp;
-    const bool kv = k < K;
-    const int kk = kv ? k : K - 1;               // surplus groups shadow the last bin and store nothing
-    const bool rv = i < M;
-    const int ii = rv ? i : 0;
-    float2 *g = sm + (wave * GPW + grp) * GS;
-    float2 *gx = g, *gr = g + LP, *ge = g + 2 * LP;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), B * 0x55, 0xf, 0xf, true));   // quad_perm:[B,B,B,B]
+}
+__device__ __forceinline__ float quad_bcast(float v, int b)
+{
+    switch (b) {
+    case 0: return quad_bcast1<0>(v);
+    case 1: return quad_bcast1<1>(v);
+    case 2: return quad_bcast1<2>(v);
+    default: return quad_bcast1<3>(v);
+    }
+}
+__device__ __forceinline__ float2 quad_bcast(float2 v, int b) { return make_float2(quad_bcast(v.x, b), quad_bcast(v.y, b)); }
+
+template <int Q>
+__global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
+{
+    constexpr int NE = 2 * Q * (Q + 1);          // row slot q holds 4 (q + 1) entries, starting at 2 q (q + 1)
+    const int tid = threadIdx.x, l = tid & 3;
+    const int M = p.M, K = p.K, F = p.n_frames;
+    const long long total = (long long)p.n_streams * K;
+    const long long pid = (long long)blockIdx.x * 64 + (tid >> 2);
+    const bool pv = pid < total;
+    const long long pc = pv ? pid : total - 1;   // surplus quads shadow the last problem and store nothing
+    const int a = (int)(pc / K), k = (int)(pc - (long long)a * K);
 
     const int tri = M * (M + 1) / 2;
-    float2 *st = p.phi + ((long long)a * K + kk) * tri + ii * (ii + 1) / 2;
-    float2 P[LP], Lr[LP];
+    float2 *st = p.phi + pc * tri;
+    float2 P[NE], L[NE];
+    double geo[Q];
 #pragma unroll
-    for (int m = 0; m < LP; ++m) P[m] = (rv && m <= i) ? st[m] : make_float2(0.f, 0.f);
-    float tr = p.trace[(long long)a * K + kk];
-    const double geo = p.unit * p.mic_x[ii];
+    for (int q = 0; q < Q; ++q) {
+        const int i = 4 * q + l;
+        geo[q] = p.unit * p.mic_x[i < M ? i : 0];
+#pragma unroll
+        for (int m = 0; m < 4 * (q + 1); ++m)
+            P[2 * q * (q + 1) + m] = (i < M && m <= i) ? st[i * (i + 1) / 2 + m] : make_float2(0.f, 0.f);
+    }
+    float tr = p.trace[pc];
     const double *cd = p.cdoa + (long long)a * F;
     const long long fstride = (long long)K * M;
-    const float2 *X = p.X + (long long)a * F * fstride + (long long)kk * M + ii;
+    const float2 *X = p.X + (long long)a * F * fstride + (long long)k * M + l;
     const float al = p.alpha, oma = p.one_minus_alpha;
-    float2 *yo = p.Y + (long long)a * F * K + kk;
+    float2 *yo = p.Y + (long long)a * F * K + k;
 
-    float2 xn = rv ? X[0] : make_float2(0.f, 0.f);
-    for (int t = 0; t < F; ++t) {
-        const float2 x = xn;
-        if (t + 1 < F && rv) xn = X[(long long)(t + 1) * fstride];
-        // steering d_i = exp(-j k s_i), s_i = 2 pi fs/N/c x_i cos(DOA + pi/2); the phase is reduced in double
-        double turns = (double)kk * (geo * cd[t]);
-        turns -= rint(turns);
-        float sn, cs;
-        sincospif(2.0f * (float)turns, &sn, &cs);
-        const float2 d = make_float2(cs, -sn);
-
-        gx[i] = x;
-        wave_lds_fence();
-        // Phi <- alpha Phi + (1 - alpha) x x^H (row i), tr <- alpha tr + (1 - alpha) |x|^2
-        float e = 0.f;
-        const float2 xs = make_float2(oma * x.x, oma * x.y);
+    float2 xn[Q];
 #pragma unroll
-        for (int m = 0; m < LP; ++m)
-            if (m < M) {
-                const float2 xm = gx[m];
-                e = fmaf(xm.x, xm.x, fmaf(xm.y, xm.y, e));
-                P[m] = cmacc(make_float2(al * P[m].x, al * P[m].y), xs, xm);
-            }
+    for (int q = 0; q < Q; ++q) xn[q] = 4 * q + l < M ? X[4 * q] : make_float2(0.f, 0.f);
+    for (int t = 0; t < F; ++t) {
+        float2 x[Q], d[Q], rd[Q], rx[Q];
+        float dsum[Q];
+        const double cdt = cd[t];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            x[q] = xn[q];
+            if (t + 1 < F && 4 * q + l < M) xn[q] = X[(long long)(t + 1) * fstride + 4 * q];
+            // steering d_i = exp(-j k s_i), s_i = 2 pi fs/N/c x_i cos(DOA + pi/2); the phase is reduced in double
+            double turns = (double)k * (geo[q] * cdt);
+            turns -= rint(turns);
+            float sn, cs;
+            sincospif(2.0f * (float)turns, &sn, &cs);
+            d[q] = 4 * q + l < M ? make_float2(cs, -sn) : make_float2(0.f, 0.f);
+        }
+        // Phi <- alpha Phi + (1 - alpha) x x^H (the rows of this lane), tr <- alpha tr + (1 - alpha) |x|^2
+        float e = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float2 xs = make_float2(oma * x[q].x, oma * x[q].y);
+#pragma unroll
+            for (int m = 0; m < 4 * (q + 1); ++m)
+                if (m < M) {
+                    const float2 xm = quad_bcast(x[m >> 2], m & 3);
+                    float2 &e_ = P[2 * q * (q + 1) + m];
+                    e_ = cmacc(make_float2(al * e_.x, al * e_.y), xs, xm);
+                    if (q == Q - 1) e = fmaf(xm.x, xm.x, fmaf(xm.y, xm.y, e));
+                }
+        }
         tr = fmaf(al, tr, oma * e);
         const float delta = p.loading_over_m * tr;
 
-        float2 rd = d, rx = x, num = make_float2(0.f, 0.f);
+        float2 num = make_float2(0.f, 0.f);
         float den = 0.f;
 #pragma unroll
-        for (int j = 0; j < LP; ++j)
+        for (int q = 0; q < Q; ++q) { rd[q] = d[q]; rx[q] = x[q]; dsum[q] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4 * Q; ++j)
             if (j < M) {
-                if (i == j) {
-                    float s = P[j].x + delta;
-#pragma unroll
-                    for (int m = 0; m < j; ++m) s -= Lr[m].x * Lr[m].x + Lr[m].y * Lr[m].y;
-                    const float inv = rsqrtf(s);
-#pragma unroll
-                    for (int m = 0; m < j; ++m) gr[m] = Lr[m];
-                    ge[0] = make_float2(inv, 0.f);
-                    ge[1] = make_float2(rd.x * inv, rd.y * inv);
-                    ge[2] = make_float2(rx.x * inv, rx.y * inv);
-                }
-                wave_lds_fence();
-                const float inv = ge[0].x;
-                const float2 uj = ge[1], vj = ge[2];
-                float2 s = P[j];
-#pragma unroll
-                for (int m = 0; m < j; ++m) s = cmacc(s, make_float2(-Lr[m].x, -Lr[m].y), gr[m]);
-                const float2 l = make_float2(s.x * inv, s.y * inv);
-                Lr[j] = l;
-                rd = cmac(rd, make_float2(-l.x, -l.y), uj);
-                rx = cmac(rx, make_float2(-l.x, -l.y), vj);
+                const int jq = j >> 2, jl = j & 3, jo = 2 * jq * (jq + 1);
+                // pivot and the two substitution values of row j, from its owner
+                const float inv = __builtin_amdgcn_rsqf(quad_bcast(P[jo + j].x + delta - dsum[jq], jl));
+                float2 uj = quad_bcast(rd[jq], jl), vj = quad_bcast(rx[jq], jl);
+                uj = make_float2(uj.x * inv, uj.y * inv);
+                vj = make_float2(vj.x * inv, vj.y * inv);
                 num = cmacc(num, vj, uj);                               // conj(u_j) v_j
                 den = fmaf(uj.x, uj.x, fmaf(uj.y, uj.y, den));
+                // L_ij = (Phi_ij - sum_{m<j} L_im conj(L_jm)) / L_jj for the rows below j (rows <= j compute dead values)
+                float2 s[Q];
+#pragma unroll
+                for (int q = jq; q < Q; ++q) s[q] = P[2 * q * (q + 1) + j];
+#pragma unroll
+                for (int m = 0; m < j; ++m) {
+                    const float2 r = quad_bcast(L[jo + m], jl);
+#pragma unroll
+                    for (int q = jq; q < Q; ++q) s[q] = cnmacc(s[q], L[2 * q * (q + 1) + m], r);
+                }
+#pragma unroll
+                for (int q = jq; q < Q; ++q) {
+                    const float2 lq = make_float2(s[q].x * inv, s[q].y * inv);
+                    L[2 * q * (q + 1) + j] = lq;
+                    dsum[q] = fmaf(lq.x, lq.x, fmaf(lq.y, lq.y, dsum[q]));
+                    rd[q] = cnmac(rd[q], lq, uj);
+                    rx[q] = cnmac(rx[q], lq, vj);
+                }
             }
-        float2 y = make_float2(num.x / den, num.y / den);
+        const float rden = __builtin_amdgcn_rcpf(den);
+        float2 y = make_float2(num.x * rden, num.y * rden);
         if (!(tr > 1e-30f)) {
             // digital silence so far: w = d/M, the reference's delay-and-sum (Beamformer.cpp:51-71)
-            float2 q = rv ? cmulc(x, d) : make_float2(0.f, 0.f);       // conj(d_i) x_i
+            float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int off = LP / 2; off > 0; off >>= 1) { q.x += __shfl_xor(q.x, off, LP); q.y += __shfl_xor(q.y, off, LP); }
-            y = make_float2(q.x / (float)M, q.y / (float)M);
+            for (int q = 0; q < Q; ++q) acc = cmacc(acc, x[q], d[q]);   // conj(d_i) x_i
+            acc.x += __shfl_xor(acc.x, 1, 4); acc.y += __shfl_xor(acc.y, 1, 4);
+            acc.x += __shfl_xor(acc.x, 2, 4); acc.y += __shfl_xor(acc.y, 2, 4);
+            y = make_float2(acc.x / (float)M, acc.y / (float)M);
         }
-        if (i == 0 && kv) yo[(long long)t * K] = y;
-        wave_lds_fence();                                               // gx is rewritten by the next frame
+        if (l == 0 && pv) yo[(long long)t * K] = y;
     }
-    if (kv && rv) {
+    if (pv) {
 #pragma unroll
-        for (int m = 0; m < LP; ++m) if (m <= i) st[m] = P[m];
-        if (i == 0) p.trace[(long long)a * K + kk] = tr;
+        for (int q = 0; q < Q; ++q) {
+            const int i = 4 * q + l;
+#pragma unroll
+            for (int m = 0; m < 4 * (q + 1); ++m)
+                if (i < M && m <= i) st[i * (i + 1) / 2 + m] = P[2 * q * (q + 1) + m];
+        }
+        if (l == 0) p.trace[pc] = tr;
     }
 }
 
+template __global__ void k_mvdr_solve<1>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<2>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<3>(MvdrSolveArgs);
 template __global__ void k_mvdr_solve<4>(MvdrSolveArgs);
-template __global__ void k_mvdr_solve<8>(MvdrSolveArgs);
-template __global__ void k_mvdr_solve<16>(MvdrSolveArgs);
 
 // --------------------------------------------------------------------------------------
 // k_mvdr_synth: grid (runs of ft frames, streams), 256 threads, LDS = (H + 1) float2 + H floats.

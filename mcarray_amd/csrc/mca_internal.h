@@ -212,7 +212,7 @@ struct MvdrSolveArgs {
     const double *cdoa;       // [streams][n_frames]
     const double *mic_x;      // [M] x coordinates (Beamformer.cpp:59 uses x only)
     double unit;              // fs / N / 346.1
-    int n_frames, K, M;
+    int n_streams, n_frames, K, M;
     float alpha, one_minus_alpha, loading_over_m;
     float2 *phi;              // [streams][K][M(M+1)/2] lower triangle of the covariance, row-major
     float *trace;             // [streams][K] tr(Phi), carried as its own recursion
