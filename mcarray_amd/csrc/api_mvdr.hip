@@ -3,10 +3,12 @@
 // Host side only: owns the per-stream state (covariances, their traces, overlap-add tails) and the spectra
 // workspace, enqueues the three kernels of kernels_mvdr.hip.  No CPU fallback.
 #include "../../include/mcarray_hip.h"
+#include "fft512.h"
 #include "kernels.h"
 #include "stage.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -211,11 +213,21 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     aa.pcm = pcm; aa.stream_stride = stream_stride; aa.mic_stride = mic_stride; aa.n_frames = n_frames;
     aa.N = c->N; aa.logH = c->logH; aa.M = c->M; aa.window = c->d_window; aa.tw = c->d_tw; aa.doa_rad = doa_rad;
     aa.X = c->d_X; aa.cdoa = c->d_cdoa;
-    const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2);
-    if (smem1 > 64 * 1024)
-        VHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mvdr_analyse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+    static const bool no_tuned = std::getenv("MCA_HIP_MVDR_GENERIC") != nullptr;     // A/B switch for measurements
     t_begin(c, 0, st);
-    hipLaunchKernelGGL(k_mvdr_analyse, dim3(n_frames, n_streams), dim3(fft_threads(c->N, c->M)), smem1, st, aa);
+    if (c->N == FFT_N && !no_tuned) {
+        // 1024-sample frames: wave-level FFT, one wave per channel, eight channels per pass
+        int fpb = 8;
+        while (fpb > 1 && (long long)n_streams * ((n_frames + fpb - 1) / fpb) < 1024) fpb >>= 1;
+        const size_t smem1 = (size_t)(8 * 580 + TW_WORDS) * sizeof(float2);
+        VHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mvdr_analyse_1024), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+        hipLaunchKernelGGL(k_mvdr_analyse_1024, dim3((n_frames + fpb - 1) / fpb, n_streams), dim3(512), smem1, st, aa, fpb);
+    } else {
+        const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2);
+        if (smem1 > 64 * 1024)
+            VHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mvdr_analyse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+        hipLaunchKernelGGL(k_mvdr_analyse, dim3(n_frames, n_streams), dim3(fft_threads(c->N, c->M)), smem1, st, aa);
+    }
     t_end(c, st);
 
     MvdrSolveArgs sa{};

@@ -9,7 +9,7 @@
 // evaluated through the Cholesky factor PhiL = L L^H: u = L^-1 d, v = L^-1 x, Y = (u^H v) / (u^H u) -- two
 // forward substitutions, no back substitution, and only cond(L) = sqrt(cond(PhiL)) enters the fp32 error.
 //
-//   k_mvdr_analyse   PCM -> windowed N-pt real FFT of the M channels -> X [stream][frame][bin][mic]
+//   k_mvdr_analyse(_1024)   PCM -> windowed N-pt real FFT of the M channels -> X [stream][frame][bin][mic]
 //   k_mvdr_solve     the recursion + factorisation above; four lanes per (stream, bin) problem, rows dealt cyclically
 //   k_mvdr_synth     Y -> inverse FFT -> overlap-add
 //
@@ -43,6 +43,60 @@ __global__ __launch_bounds__(1024) void k_mvdr_analyse(MvdrAnalyseArgs p)
     for (int e = tid; e < K * M; e += NT) {
         const int k = e / M, m = e - k * M;
         xo[e] = xs[m * zs + k];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// k_mvdr_analyse_1024: the same for 1024-sample frames with the wave-level FFT of fft512.h (one wave per channel,
+// eight channels per pass).  grid (ceil(frames / fpb), streams), 512 threads,
+// LDS = 8 * MV_SP float2 (spectra of a pass) + TW_WORDS float2 (twiddles + half window).
+// After a pass the eight spectra go out transposed: 64-byte runs (8 microphones of one bin) per 8 lanes.
+// --------------------------------------------------------------------------------------
+constexpr int MV_SP = 580;      // float2 words per spectrum: 8 words of bank offset between the channels of a pass
+
+__global__ __launch_bounds__(512) void k_mvdr_analyse_1024(MvdrAnalyseArgs p, int fpb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int K = FFT_K;
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);        // [8][MV_SP]
+    float2 *tab = spec + 8 * MV_SP;                              // [TW_WORDS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.y, M = p.M;
+    const int f_begin = blockIdx.x * fpb, f_end = min(f_begin + fpb, p.n_frames);
+    const float *base = p.pcm + (long long)a * p.stream_stride;
+
+    fft_table_init(tab, p.window, tid, 512);
+    for (int f = f_begin + tid; f < f_end; f += 512) {
+        const long long o = (long long)a * p.n_frames + f;
+        p.cdoa[o] = cos((double)p.doa_rad[o] + 1.57079632679489661923);     // cos(DOA + M_PI/2), Beamformer.cpp:59
+    }
+    __syncthreads();
+    FftTw tw{tab};
+    for (int f = f_begin; f < f_end; ++f) {
+        float2 *xo = p.X + ((long long)a * p.n_frames + f) * (long long)K * M;
+        for (int c0 = 0; c0 < M; c0 += 8) {
+            const int nc = min(8, M - c0);
+            if (wave < nc) {
+                const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(c0 + wave) * p.mic_stride + (long long)f * FFT_H);
+                float2 v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const float2 x = src[lane + 64 * r], w = tw.win(r, lane); v[r] = make_float2(x.x * w.x, x.y * w.y); }
+                rfft1024(v, spec + wave * MV_SP, lane, tw);
+            }
+            __syncthreads();
+            if (nc == 8) {
+                for (int e = tid; e < K * 8; e += 512) {
+                    const int k = e >> 3, m = e & 7;
+                    xo[(long long)k * M + c0 + m] = spec[m * MV_SP + k];
+                }
+            } else {
+                for (int e = tid; e < K * nc; e += 512) {
+                    const int k = e / nc, m = e - k * nc;
+                    xo[(long long)k * M + c0 + m] = spec[m * MV_SP + k];
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
