@@ -163,6 +163,21 @@ int mca_hip_fft_log_power(mca_hip_ctx *ctx, const double *const *frames, int ccs
 /* copy of the current un-normalised _prevEnergyInDOA of array 0: out[D] */
 int mca_hip_get_energy(mca_hip_ctx *ctx, double *out);
 
+/* ---- real-time mode: the stream call as a HIP graph --------------------------------------------
+ * A caller that hands over a stream chunk by chunk (SourceSeparationAndLocalisation::process() on a live input,
+ * mcabeamf.cpp:112; BASELINE configs[1]) is bound by the launches of a call, not by its kernels: one frame is 18 KB.
+ * mca_hip_graph_create fixes the shape and the device buffers of a mca_hip_process_frames_dev call (out_pcm_dev NULL:
+ * of a mca_hip_localise_frames_dev call); mca_hip_graph_launch replays the kernels of that call as ONE graph launch on
+ * whatever the caller has put into pcm_dev since the last launch, continuing the context state exactly like the plain
+ * call (results are bit-identical).  The graphs (one per parity of the double-buffered state) are recorded on first
+ * use; recording executes nothing.  Plain stream calls and graph launches on the same context may be mixed. */
+typedef struct mca_hip_graph mca_hip_graph;
+int mca_hip_graph_create(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride, long long mic_stride,
+                         int n_arrays, int n_frames, int *doa_bin_dev, float *doa_rad_dev, float *prob_dev,
+                         float *energy_dev, float *out_pcm_dev, mca_hip_graph **out);
+int mca_hip_graph_launch(mca_hip_graph *g, void *stream);
+void mca_hip_graph_destroy(mca_hip_graph *g);
+
 /* ---- 2-microphone GCC-PHAT localisation (FreqGCCBinauralLocalisation) ----------------- */
 /* Deterministic part of FreqGCCBinauralLocalisation::processParametrisation
  * (BinauralLocalisation.cpp:406-567) for n_frames consecutive frames of n_arrays independent

@@ -148,6 +148,19 @@ class Context:
             self._check(self._lib.mca_hip_separate_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_rad),
                                                               ptr(out_pcm), stream))
 
+    # ---- real-time mode: the stream call as a HIP graph ----
+    def graph_create(self, pcm, n_frames, doa_bin, doa_rad, prob, energy=None, out_pcm=None):
+        """Fixes the shape and buffers (torch cuda tensors, as process_frames_dev) of a stream call; returns a StreamGraph
+        whose launch() replays the call's kernels as one HIP graph on the current contents of `pcm`."""
+        A, M, L = pcm.shape
+        if M != self.M or not pcm.is_contiguous():
+            raise MCArrayHipError("pcm must be a contiguous [A][M][L] tensor with M = the context's microphones")
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        h = C.c_void_p()
+        self._check(self._lib.mca_hip_graph_create(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_bin), ptr(doa_rad), ptr(prob),
+                                                   ptr(energy), ptr(out_pcm), C.byref(h)))
+        return StreamGraph(self, h, (pcm, doa_bin, doa_rad, prob, energy, out_pcm))
+
     # ---- 2-microphone GCC-PHAT path ----
     def gcc2_frames_host(self, pcm, want_corr=False):
         """pcm float32 [A][2][(F+1)*hop] -> dict(argmax [A][F], doa [A][F] (smoothed, rad), prob [A][F], corr [A][F][D])"""
@@ -217,6 +230,24 @@ class Context:
         ms = C.c_double(0)
         self._check(self._lib.mca_hip_get_timing(self.h, kernel_id, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+
+class StreamGraph:
+    """Handle of mca_hip_graph (include/mcarray_hip.h, real-time mode); keeps the buffers alive."""
+
+    def __init__(self, ctx, h, keep):
+        self.ctx, self.h, self._keep = ctx, h, keep
+
+    def launch(self, stream=None):
+        self.ctx._check(self.ctx._lib.mca_hip_graph_launch(self.h, stream))
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx._lib.mca_hip_graph_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 class SteeringBeamforming:

@@ -806,6 +806,89 @@ int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array
     return mca_hip_separate_frames_dev(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, stream);
 }
 
+// ---- real-time mode: the stream call as a HIP graph ------------------------------------------
+struct mca_hip_graph {
+    mca_hip_ctx *c = nullptr;
+    const float *pcm = nullptr; long long array_stride = 0, mic_stride = 0;
+    int n_arrays = 0, n_frames = 0;
+    int *doa_bin = nullptr; float *doa_rad = nullptr, *prob = nullptr, *energy = nullptr, *out_pcm = nullptr;
+    hipStream_t cap = nullptr;                 // recording stream
+    hipGraph_t graph[4] = {};                  // one per (e_cur, tail_cur): the state buffers a call reads / writes
+    hipGraphExec_t exec[4] = {};
+};
+
+int mca_hip_graph_create(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride, int n_arrays,
+                         int n_frames, int *doa_bin, float *doa_rad, float *prob, float *energy, float *out_pcm,
+                         mca_hip_graph **out)
+{
+    if (!out) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
+    if (rc) return rc;
+    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
+    if (out_pcm && !doa_rad) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev is NULL (the separation stage steers with it)");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if ((rc = mca_hip_reserve(c, n_arrays, n_frames))) return rc;      // recording must not allocate
+    mca_hip_graph *g = new mca_hip_graph();
+    g->c = c; g->pcm = pcm; g->array_stride = array_stride; g->mic_stride = mic_stride; g->n_arrays = n_arrays; g->n_frames = n_frames;
+    g->doa_bin = doa_bin; g->doa_rad = doa_rad; g->prob = prob; g->energy = energy; g->out_pcm = out_pcm;
+    if (hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking) != hipSuccess) { delete g; return fail(c, MCA_HIP_ERR_HIP, "hipStreamCreateWithFlags failed"); }
+    *out = g;
+    return MCA_HIP_OK;
+}
+
+static int graph_record(mca_hip_graph *g, int idx)
+{
+    mca_hip_ctx *c = g->c;
+    const int e_cur = c->e_cur, tail_cur = c->tail_cur;
+    const bool timing = c->timing;
+    c->timing = false;                          // event pairs belong to eager calls
+    HIP_TRY(c, hipStreamBeginCapture(g->cap, hipStreamCaptureModeRelaxed));
+    int rc = mca_hip_localise_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_bin, g->doa_rad,
+                                         g->prob, g->energy, g->cap);
+    if (!rc && g->out_pcm)
+        rc = mca_hip_separate_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_rad, g->out_pcm, g->cap);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(g->cap, &graph);
+    c->timing = timing;
+    c->e_cur = e_cur; c->tail_cur = tail_cur;   // nothing ran: the state has not moved
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(c, MCA_HIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    g->graph[idx] = graph;
+    HIP_TRY(c, hipGraphInstantiate(&g->exec[idx], graph, nullptr, nullptr, 0));
+    return MCA_HIP_OK;
+}
+
+int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
+{
+    if (!g) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    mca_hip_ctx *c = g->c;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int idx = c->e_cur | (c->tail_cur << 1);
+    if (!g->exec[idx]) {
+        const int rc = graph_record(g, idx);
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipGraphLaunch(g->exec[idx], (hipStream_t)stream));
+    c->e_cur ^= 1;                              // as the eager calls do
+    if (g->out_pcm) c->tail_cur ^= 1;
+    c->last_arrays = g->n_arrays; c->last_frames = g->n_frames;
+    return MCA_HIP_OK;
+}
+
+void mca_hip_graph_destroy(mca_hip_graph *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->c->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 4; ++i) {
+        if (g->exec[i]) (void)hipGraphExecDestroy(g->exec[i]);
+        if (g->graph[i]) (void)hipGraphDestroy(g->graph[i]);
+    }
+    if (g->cap) (void)hipStreamDestroy(g->cap);
+    delete g;
+}
+
 int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int n_frames, int *doa_bin,
                                 float *doa_rad, float *prob, float *energy, float *out_pcm)
 {
