@@ -21,8 +21,8 @@ public:
         : SoundLocalisationImpl(microphonePositions), _order(calculateOrderFromSampleRate(sampleRate, _frameRate))
     {
         if (microphonePositions.size() != 2) throw MCArrayException("FreqGCCBinauralLocalisation needs an ArrayDescription with 2 microphones");
-        if (usePowerFloor) throw MCArrayException("the stream path runs ungated: construct with usePowerFloor=false");
-        _ctx.reset(new detail::HipContext(sampleRate, microphonePositions, 1 << _order, doaStepDeg, 1, false));
+        _usePowerFloor = usePowerFloor;
+        _ctx.reset(new detail::HipContext(sampleRate, microphonePositions, 1 << _order, doaStepDeg, 1, usePowerFloor));
         _currentDOA.reset(new BaseType[1]);
         _prob.reset(new BaseType[1]);
         _currentDOA[0] = 0; _prob[0] = -1;                   // BinauralLocalisation.cpp:339-340
@@ -49,9 +49,13 @@ public:
         std::vector<int> idx(static_cast<size_t>(F));
         for (int c = 0; c < 2; ++c) std::copy(_pending[c].begin(), _pending[c].begin() + static_cast<long>(L), pcm.begin() + static_cast<long>(L) * c);
         _ctx->check(mca_hip_gcc2_frames_host(_ctx->get(), pcm.data(), 1, F, idx.data(), doa.data(), prob.data(), nullptr));
+        std::vector<unsigned char> voiced(static_cast<size_t>(F), 1);
+        std::vector<float> power(static_cast<size_t>(F), 0.f);
+        if (_usePowerFloor) _ctx->check(mca_hip_copy_gate(_ctx->get(), voiced.data(), power.data()));
         for (int t = 0; t < F; ++t) {
+            if (!voiced[static_cast<size_t>(t)]) continue;       // gated out: the block of BinauralLocalisation.cpp:434 is skipped, no setDOA
             _currentDOA[0] = doa[static_cast<size_t>(t)]; _prob[0] = prob[static_cast<size_t>(t)];
-            if (_ptrCallback) _ptrCallback->setDOA(toDegrees(_currentDOA, 1), _prob, 0.0, 1);
+            if (_ptrCallback) _ptrCallback->setDOA(toDegrees(_currentDOA, 1), _prob, static_cast<double>(power[static_cast<size_t>(t)]), 1);
         }
         for (int c = 0; c < 2; ++c) _pending[c].erase(_pending[c].begin(), _pending[c].begin() + static_cast<long>(F) * hop);
         _lastArgmax = idx;
@@ -62,6 +66,7 @@ public:
 private:
     static constexpr float _frameRate = 0.075f;      // BinauralLocalisation.h:196
     const int _order;
+    bool _usePowerFloor = true;
     std::shared_ptr<detail::HipContext> _ctx;
     std::vector<float> _pending[2];
     std::vector<int> _lastArgmax;

@@ -187,7 +187,10 @@ void mca_hip_graph_destroy(mca_hip_graph *g);
  * 0.8f afterwards (:445-448, :523), first-max argmax and the author's deterministic DOA smoothing
  * DOA = m DOA + (1-m) angle, m = 0 then 0.6f (the #else branch :502-504; the particle filter of
  * :456-473 is a stochastic DSPONE component and stays out of scope), and setProbability of the
- * previous DOA (:454, :569-631).  Runs ungated (usePowerFloor = false).
+ * previous DOA (:454, :569-631).  With use_power_floor = 1 the gate of :387-404 / :425-434 runs on the GPU (3 s of floor
+ * estimation, then a frame fires when its FFTLogPower exceeds the floor + 6 dB): the recursions only see the frames that
+ * fired, the others repeat the outputs of the last fired frame (argmax -1, DOA 0, prob -1 before the first), and
+ * mca_hip_copy_gate returns voiced[A][F] / power[A][F] of the call.
  *   argmax_dev [A][F] int32, doa_rad_dev [A][F] float (smoothed), prob_dev [A][F] float,
  *   corr_dev [A][F][D] float smoothed correlation (any but argmax_dev may be NULL). */
 int mca_hip_gcc2_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,

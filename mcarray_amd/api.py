@@ -179,7 +179,14 @@ class Context:
         self._check(self._lib.mca_hip_gcc2_frames_host(self.h, pcm.ctypes.data_as(fp), A, F, idx.ctypes.data_as(_lib.c_ip),
                                                        doa.ctypes.data_as(fp), prob.ctypes.data_as(fp),
                                                        corr.ctypes.data_as(fp) if want_corr else None))
-        return dict(argmax=idx, doa=doa, prob=prob, corr=corr)
+        res = dict(argmax=idx, doa=doa, prob=prob, corr=corr)
+        if self.use_power_floor:     # the gate of BinauralLocalisation.cpp:425-434: which frames fired, and the power handed to setDOA
+            voiced = np.empty((A, F), dtype=np.uint8)
+            power = np.empty((A, F), dtype=np.float32)
+            self._check(self._lib.mca_hip_copy_gate(self.h, voiced.ctypes.data_as(C.c_void_p), power.ctypes.data_as(fp)))
+            res["voiced"] = voiced
+            res["power"] = power
+        return res
 
     # ---- frame API ----
     def _rows(self, frames):
@@ -336,14 +343,25 @@ class FreqGCCBinauralLocalisation:
                  srp_precision=SRP_FP32, max_arrays=1, device=0):
         if fft_size is None:
             fft_size = 1 << calculate_order_from_sample_rate(sample_rate, self.FRAME_SECONDS)
-        if use_power_floor:
-            raise MCArrayHipError("the stream API runs ungated (usePowerFloor=false)")
-        self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, 1, False, srp_precision, max_arrays, device)
+        self.ctx = Context(sample_rate, mic_positions, fft_size, doa_step_deg, 1, use_power_floor, srp_precision, max_arrays, device)
         if self.ctx.M != 2:
             raise MCArrayHipError("FreqGCCBinauralLocalisation needs exactly 2 microphones")
+        self.callback = None
+
+    def set_callback(self, cb):
+        self.callback = cb
 
     def process(self, pcm, want_corr=False):
-        return self.ctx.gcc2_frames_host(pcm, want_corr)
+        """-> dict(argmax, doa, prob[, corr][, voiced, power]); the callback fires per frame of array 0 that passed the gate
+        as setDOA(degrees, prob, power, 1) (BinauralLocalisation.cpp:521)."""
+        r = self.ctx.gcc2_frames_host(pcm, want_corr)
+        if self.callback is not None:
+            for t in range(r["doa"].shape[1]):
+                if "voiced" in r and not r["voiced"][0, t]:
+                    continue
+                self.callback(np.array([np.rad2deg(float(r["doa"][0, t]))]), np.array([r["prob"][0, t]]),
+                              float(r["power"][0, t]) if "power" in r else 0.0, 1)
+        return r
 
 
 class MultibandBinarualLocalisation:

@@ -53,7 +53,9 @@ struct mca_hip_ctx {
     int last_arrays = 0, last_frames = 0;
     float *d_doa[2] = {nullptr, nullptr};   // 2-mic path: smoothed _currentDOA per array
     int doa_cur = 0;
-    long long gcc2_frames_done = 0;
+    long long gcc2_frames_done = 0;         // (kept in the state header for blob compatibility; the counters below are what runs)
+    long long *d_vdone[2] = {nullptr, nullptr};   // 2-mic path: frames that fired so far, per array (double-buffered with d_doa)
+    int *d_g2_vidx = nullptr, *d_g2_nv = nullptr; float *d_g2_rad = nullptr, *d_g2_prob = nullptr; size_t g2_rows = 0;   // gated 2-mic path
     // workspace
     void *d_A = nullptr; size_t a_bytes = 0;
     float *d_C = nullptr; size_t c_bytes = 0;
@@ -113,7 +115,7 @@ void free_ctx(mca_hip_ctx *c)
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt);
-    F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]);
+    F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
@@ -474,6 +476,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_gate_state, na * 4 * 8)) || (rc = zalloc((void **)&c->d_last_bin, na * MCA_MAX_SOURCES * 4)) ||
         (rc = zalloc((void **)&c->d_last_rad, na * MCA_MAX_SOURCES * 4)) || (rc = zalloc((void **)&c->d_last_prob, na * MCA_MAX_SOURCES * 4)) ||
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
+        (rc = zalloc((void **)&c->d_vdone[0], na * 8)) || (rc = zalloc((void **)&c->d_vdone[1], na * 8)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
@@ -520,6 +523,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
         HIP_TRY(c, hipMemsetAsync(c->d_tail[i], 0, na * c->S * c->H * 4, st));
         HIP_TRY(c, hipMemsetAsync(c->d_E64[i], 0, (size_t)c->D * 8, st));
         HIP_TRY(c, hipMemsetAsync(c->d_doa[i], 0, na * 4, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_vdone[i], 0, na * 8, st));
     }
     c->gcc2_frames_done = 0;
     return init_last_state(c, st);
@@ -550,7 +554,7 @@ std::vector<StatePart> state_parts(mca_hip_ctx *c)
     return {
         {c->d_E[c->e_cur], na * c->D * 4}, {c->d_tail[c->tail_cur], na * c->S * c->H * 4}, {c->d_gate_state, na * 4 * 8},
         {c->d_last_bin, na * MCA_MAX_SOURCES * 4}, {c->d_last_rad, na * MCA_MAX_SOURCES * 4}, {c->d_last_prob, na * MCA_MAX_SOURCES * 4},
-        {c->d_doa[c->doa_cur], na * 4}, {c->d_E64[c->e64_cur], (size_t)c->D * 8},
+        {c->d_doa[c->doa_cur], na * 4}, {c->d_E64[c->e64_cur], (size_t)c->D * 8}, {c->d_vdone[c->doa_cur], na * 8},
     };
 }
 
@@ -933,24 +937,59 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     // shorter ones for small batches so that a few hundred workgroups exist
     ga.chunk = 128;
     while (ga.chunk > 32 && (long long)n_arrays * ((n_frames + ga.chunk - 1) / ga.chunk) < 512) ga.chunk >>= 1;
-    ga.frames_done = c->gcc2_frames_done;
+    ga.vdone_in = c->d_vdone[c->doa_cur]; ga.vdone_out = c->d_vdone[c->doa_cur ^ 1];
     ga.mu = 0.8f; ga.one_minus_mu = 1 - 0.8f;                      // _maxCorrMemoryFactor (BinauralLocalisation.h:198)
     ga.doa_mem = 0.6f; ga.one_minus_doa_mem = 1 - 0.6f;            // _maxDoaMemoryFactor (:199)
     ga.step = c->step;
     ga.corr_in = c->d_E[c->e_cur]; ga.corr_out = c->d_E[c->e_cur ^ 1];
     ga.doa_in = c->d_doa[c->doa_cur]; ga.doa_out = c->d_doa[c->doa_cur ^ 1];
     ga.grid = c->d_grid; ga.argmax = argmax; ga.doa_rad = doa_rad; ga.prob = prob; ga.corr = corr;
+    const bool gate = c->cfg.use_power_floor != 0;
+    time_begin(c, MCA_HIP_K_GCC2_SCAN, st);
+    if (gate) {
+        // setPowerFloor + the gate of processParametrisation (BinauralLocalisation.cpp:387-404, :425-434): 3 s of floor
+        // estimation (power + 1e-10 per frame), then voiced = FFTLogPower > floor + 6 dB; the recursions below only see
+        // the frames that fired, gated-out frames repeat the previous outputs
+        const size_t rows = (size_t)n_arrays * n_frames;
+        if (rows > c->g2_rows) {
+            auto Fr = [](void *q) { if (q) (void)hipFree(q); };
+            Fr(c->d_g2_vidx); Fr(c->d_g2_nv); Fr(c->d_g2_rad); Fr(c->d_g2_prob);
+            c->d_g2_vidx = c->d_g2_nv = nullptr; c->d_g2_rad = c->d_g2_prob = nullptr; c->g2_rows = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_g2_vidx, rows * 4));
+            HIP_TRY(c, hipMalloc((void **)&c->d_g2_nv, (size_t)c->cfg.max_arrays * 4));
+            HIP_TRY(c, hipMalloc((void **)&c->d_g2_rad, rows * 4));
+            HIP_TRY(c, hipMalloc((void **)&c->d_g2_prob, rows * 4));
+            c->g2_rows = rows;
+        }
+        GateArgs gg{};
+        gg.power_lin = c->d_power; gg.n_frames = n_frames; gg.fft_n = c->N;
+        gg.needed_samples = (int)(3.0 * c->cfg.sample_rate);              // _durationToEstimatePowerFloor (SoundLocalisationImpl.h:77)
+        gg.margin_db = 6.f;                                                // _noiseMarginDB (BinauralLocalisation.h:197)
+        gg.eps = 1e-10;                                                    // BinauralLocalisation.cpp:391
+        gg.state = c->d_gate_state; gg.voiced = c->d_voiced; gg.power_out = c->d_power_out;
+        hipLaunchKernelGGL(k_gate, dim3(n_arrays), dim3(256), 0, st, gg);
+        hipLaunchKernelGGL(k_gcc2_compact, dim3(n_arrays), dim3(256), 0, st, c->d_voiced, n_frames, c->d_g2_vidx, c->d_g2_nv);
+        ga.vidx = c->d_g2_vidx; ga.nv = c->d_g2_nv;
+        if (!ga.doa_rad) ga.doa_rad = c->d_g2_rad;                         // the hold-over needs them whatever the caller asked for
+        if (!ga.prob) ga.prob = c->d_g2_prob;
+    }
     const int nslot = GCC2_DOAWARM + ga.chunk;
     const size_t smem = (size_t)nslot * ((c->D + 3) / 4 * 4 + 4) * sizeof(float) + (size_t)nslot * 3 * sizeof(float);
     if (smem > 64 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcc2_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 g((n_frames + ga.chunk - 1) / ga.chunk, n_arrays);
-    time_begin(c, MCA_HIP_K_GCC2_SCAN, st);
     hipLaunchKernelGGL(k_gcc2_scan, g, dim3(std::max(256, round_up(c->D, 64))), smem, st, ga);   // >= 4 waves: the per-frame argmax / min / sum is one wave per frame
+    if (gate) {
+        Gcc2FillArgs fa{};
+        fa.voiced = c->d_voiced; fa.n_frames = n_frames; fa.D = c->D;
+        fa.argmax = argmax; fa.doa_rad = ga.doa_rad; fa.prob = ga.prob; fa.corr = corr; fa.corr_state = ga.corr_in;
+        fa.last_idx = c->d_last_bin; fa.last_rad = c->d_last_rad; fa.last_prob = c->d_last_prob;
+        hipLaunchKernelGGL(k_gcc2_fill, dim3(n_arrays), dim3(1024), 0, st, fa);
+    }
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
     c->e_cur ^= 1; c->doa_cur ^= 1;
-    c->gcc2_frames_done += n_frames;
+    c->last_arrays = n_arrays; c->last_frames = n_frames;
     return MCA_HIP_OK;
 }
 

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gate(GateArgs p)
         bool est = st[3] != 0.0;
         int t = 0;
         for (; t < p.n_frames && !est; ++t) {
-            acc += (double)pl[t] * (double)p.fft_n;                      // _powerFloor += FFTPower * (fftCCSLength - 2) :58-59
+            acc += (double)pl[t] * (double)p.fft_n + p.eps;              // _powerFloor += FFTPower * (fftCCSLength - 2) :58-59
             consumed += (double)p.fft_n;                                 // :60
             double shown = acc;
             if (consumed >= (double)p.needed_samples) {                  // :62-67
@@ -739,7 +739,19 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
     float *sSum = sMin + nslot;                                         // [nslot]
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
     const int a = blockIdx.y;
-    const int t_start = blockIdx.x * p.chunk, t_end = min(t_start + p.chunk, p.n_frames);
+    // with the power gate the recursions only see the frames that passed it (:434): the scan runs over that list
+    const int nf = p.nv ? p.nv[a] : p.n_frames;
+    const long long done = p.vdone_in[a];
+    const int *vi = p.vidx ? p.vidx + (long long)a * p.n_frames : nullptr;
+    if (nf == 0) {                                                      // nothing fired: the state carries over unchanged
+        if (blockIdx.x == 0) {
+            if (d < D) p.corr_out[(long long)a * D + d] = p.corr_in[(long long)a * D + d];
+            if (d == 0) { p.doa_out[a] = p.doa_in[a]; p.vdone_out[a] = done; }
+        }
+        return;
+    }
+    const int t_start = blockIdx.x * p.chunk, t_end = min(t_start + p.chunk, nf);
+    if (t_start >= nf) return;
     const int keep_start = max(0, t_start - GCC2_DOAWARM);             // first frame whose corr is kept
     const int warm_start = max(0, keep_start - SCAN_WARM);
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
@@ -748,19 +760,22 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
         for (int t0 = warm_start; t0 < t_end; t0 += 8) {                  // 8 independent loads in flight, then the serial recursion
             float r8[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r8[i] = csum(C, (long long)min(t0 + i, t_end - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+            for (int i = 0; i < 8; ++i) {
+                const int j = min(t0 + i, t_end - 1);
+                r8[i] = csum(C, (long long)(vi ? vi[j] : j) * p.Dp + d, p.c_planes, p.c_plane_stride);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int t = t0 + i;
                 if (t < t_end) {
-                    const bool first = (p.frames_done + t) == 0;            // _corrMemoryFactor = 0 on the first frame
+                    const bool first = (done + t) == 0;                     // _corrMemoryFactor = 0 on the first frame
                     c = first ? r8[i] : (p.one_minus_mu * r8[i] + p.mu * c);   // :445-447
                     if (t >= keep_start) sC[(t - keep_start) * Dl + d] = c;
-                    if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + t) * D + d] = c;
+                    if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + (vi ? vi[t] : t)) * D + d] = c;
                 }
             }
         }
-        if (t_end == p.n_frames) p.corr_out[(long long)a * D + d] = c;  // _prevCorrelationsReal :448
+        if (t_end == nf) p.corr_out[(long long)a * D + d] = c;          // _prevCorrelationsReal :448
     }
     __syncthreads();
     for (int tl = wave; tl < t_end - keep_start; tl += nwaves) {
@@ -804,17 +819,85 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
                 } else pr = cr[idx];
                 float pb = sum > 0.f ? (pr - mn) / sum : 0.f;
                 pb = pb < 0.01f ? 0.f : pb;
-                if (p.prob) p.prob[(long long)a * p.n_frames + t] = pb;
+                if (p.prob) p.prob[(long long)a * p.n_frames + (vi ? vi[t] : t)] = pb;
             }
-            const bool first = (p.frames_done + t) == 0;
+            const bool first = (done + t) == 0;
             const float angle = p.grid[sIdx[tl]];                        // doaIdx2angle(idx) :503
             doa = first ? angle : (p.doa_mem * doa + p.one_minus_doa_mem * angle);   // :504
             if (t >= t_start) {
-                p.argmax[(long long)a * p.n_frames + t] = sIdx[tl];
-                if (p.doa_rad) p.doa_rad[(long long)a * p.n_frames + t] = doa;
+                const long long o = (long long)a * p.n_frames + (vi ? vi[t] : t);
+                p.argmax[o] = sIdx[tl];
+                if (p.doa_rad) p.doa_rad[o] = doa;
             }
         }
-        if (t_end == p.n_frames) p.doa_out[a] = doa;
+        if (t_end == nf) { p.doa_out[a] = doa; p.vdone_out[a] = done + nf; }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// k_gcc2_compact -- the frames of every array that passed the gate, in order (grid (arrays), 256 threads)
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gcc2_compact(const unsigned char *voiced, int n_frames, int *vidx, int *nv)
+{
+    __shared__ int s_w[4];
+    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned char *vc = voiced + (long long)a * n_frames;
+    int *out = vidx + (long long)a * n_frames;
+    int base = 0;
+    for (int t0 = 0; t0 < n_frames; t0 += 256) {
+        const int t = t0 + tid;
+        const bool v = t < n_frames && vc[t] != 0;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        if (v) out[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) nv[a] = base;
+}
+
+// --------------------------------------------------------------------------------------
+// k_gcc2_fill -- gated-out frames keep _currentDOA / _prob / the smoothed correlation of the last frame that fired
+// (BinauralLocalisation.cpp:434: the block is skipped).  grid (arrays), 1024 threads; prefix max as k_doa_fill.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_gcc2_fill(Gcc2FillArgs p)
+{
+    __shared__ int sLast[1024];
+    const int a = blockIdx.x, tid = threadIdx.x, F = p.n_frames, D = p.D;
+    const unsigned char *vc = p.voiced + (long long)a * F;
+    const int per = (F + 1023) / 1024;
+    const int t0 = tid * per, t1 = min(t0 + per, F);
+    int last = -1;
+    for (int t = t0; t < t1; ++t) if (vc[t]) last = t;
+    sLast[tid] = last;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int other = tid >= off ? sLast[tid - off] : -1;
+        __syncthreads();
+        sLast[tid] = max(sLast[tid], other);
+        __syncthreads();
+    }
+    int run = tid > 0 ? sLast[tid - 1] : -1;
+    const long long base = (long long)a * F;
+    for (int t = t0; t < t1; ++t) {
+        if (vc[t]) { run = t; continue; }
+        p.argmax[base + t] = run >= 0 ? p.argmax[base + run] : p.last_idx[a];
+        p.doa_rad[base + t] = run >= 0 ? p.doa_rad[base + run] : p.last_rad[a];
+        p.prob[base + t] = run >= 0 ? p.prob[base + run] : p.last_prob[a];
+        if (p.corr) {
+            const float *src = run >= 0 ? p.corr + (base + run) * D : p.corr_state + (long long)a * D;
+            float *dst = p.corr + (base + t) * D;
+            for (int d = 0; d < D; ++d) dst[d] = src[d];
+        }
+    }
+    __syncthreads();
+    if (F - 1 >= t0 && F - 1 < t1) {
+        p.last_idx[a] = p.argmax[base + F - 1];
+        p.last_rad[a] = p.doa_rad[base + F - 1];
+        p.last_prob[a] = p.prob[base + F - 1];
     }
 }
 

@@ -85,6 +85,7 @@ struct GateArgs {
     const float *power_lin;  // [arrays][n_frames] FFTPower of every frame
     int n_frames, fft_n, needed_samples;
     float margin_db;
+    double eps;              // added to every frame's power before it is accumulated (FreqGCC: 1e-10, BinauralLocalisation.cpp:391)
     // persistent gate state per array: {accumulated power (double), samples consumed (double), floor dB (double), estimated (double 0/1)}
     double *state;           // [arrays][4]
     unsigned char *voiced;   // [arrays][n_frames]
@@ -118,7 +119,9 @@ struct Gcc2ScanArgs {
     const float *C;          // [c_planes][arrays][n_frames][Dp] un-smoothed GCC-PHAT R_t[d] (split-K partial maps, summed here)
     int c_planes; long long c_plane_stride;
     int n_frames, Dp, D, chunk;
-    long long frames_done;   // frames this context has processed before this call (0 = stream start)
+    const long long *vdone_in; long long *vdone_out;   // [arrays] voiced frames processed before / after this call (0 = the stream's first)
+    const int *vidx;         // [arrays][n_frames] frames that passed the gate, in order (NULL: ungated, every frame)
+    const int *nv;           // [arrays] their number (NULL: n_frames)
     float mu, one_minus_mu;  // _maxCorrMemoryFactor 0.8f and 1 - 0.8f (float arithmetic)
     float doa_mem, one_minus_doa_mem;   // _maxDoaMemoryFactor 0.6f
     float step;              // _doaStep
@@ -126,6 +129,14 @@ struct Gcc2ScanArgs {
     const float *doa_in; float *doa_out;        // [arrays] _currentDOA
     const float *grid;       // [D]
     int *argmax; float *doa_rad; float *prob; float *corr;
+};
+
+struct Gcc2FillArgs {
+    const unsigned char *voiced;   // [arrays][n_frames]
+    int n_frames, D;
+    int *argmax; float *doa_rad, *prob, *corr;          // outputs of the scan (corr may be NULL); gated-out frames are filled here
+    const float *corr_state;       // [arrays][D] smoothed correlation at the start of the call
+    int *last_idx; float *last_rad, *last_prob;          // [arrays] values of the last frame, carried to the next call
 };
 
 struct MaskParams {

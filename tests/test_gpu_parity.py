@@ -318,6 +318,57 @@ def test_freqgcc_matches_golden_and_oracle(golden_dir):
     np.testing.assert_allclose(np.concatenate([ra["doa"], rb["doa"]], axis=1), r["doa"], atol=1e-5)
 
 
+def test_freqgcc_power_gate_matches_oracle():
+    """usePowerFloor = true (the reference's default, BinauralLocalisation.h:191): 3 s of floor estimation, then only frames
+    6 dB above the floor fire (BinauralLocalisation.cpp:387-404, :425-434); the recursions skip the others, whose outputs
+    repeat the last fired frame.  Two calls, a stream with loud bursts and quiet gaps, bursts that straddle the chunks."""
+    fs, N, F = 16000, 1024, 330
+    hop = N // 2
+    xs = synth.BINAURAL
+    A = 2
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-42.0 + 70 * a), fs, (F + 1) * hop, 8 + a) for a in range(A)])
+    env = np.full(F + 1, 0.01)
+    for (b0, b1) in [(70, 95), (120, 121), (140, 215), (260, 300)]:       # loud bursts (in hops)
+        env[b0:b1] = 1.0
+    pcm = (pcm * np.repeat(env, hop)[None, None, :]).astype(np.float32)
+    pcm[1] *= 0.5
+    loc = api.FreqGCCBinauralLocalisation(fs, xs, True, 3.0, max_arrays=A)
+    h = 150
+    ra = loc.process(pcm[:, :, :(h + 1) * hop], want_corr=True)
+    rb = loc.process(pcm[:, :, h * hop:], want_corr=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=1) for k in ("argmax", "doa", "prob", "corr", "voiced", "power")}
+    fired_total = 0
+    for a in range(A):
+        og = po.FreqGCC(fs, xs, N + 2, True, 3.0)
+        X = po.stft_frames(pcm[a].astype(np.float64), N)
+        prev_doa, last = 0.0, None
+        nbad = 0
+        for t in range(F):
+            voiced, corr, idx, doa, power = og.process(X[t, 0], X[t, 1])
+            assert bool(r["voiced"][a, t]) == voiced, (a, t)
+            assert abs(r["power"][a, t] - power) <= 1e-4 * abs(power) + 1e-6, (a, t)
+            if voiced:
+                fired_total += 1
+                if idx != r["argmax"][a, t]:
+                    assert abs(corr[idx] - corr[r["argmax"][a, t]]) < 1e-5 * np.abs(corr).max()   # numerical tie
+                    nbad += 1
+                assert np.abs(r["corr"][a, t] - corr).max() <= 2e-5 * np.abs(corr).max(), (a, t)
+                assert abs(r["doa"][a, t] - doa) <= 2e-5 + 0.06 * nbad, (a, t)
+                pr = og.set_probability(np.array([prev_doa]))[0]
+                assert abs(r["prob"][a, t] - pr) <= 2e-4, (a, t)
+                prev_doa = doa
+                last = t
+            elif last is None:
+                assert r["argmax"][a, t] == -1 and r["doa"][a, t] == 0 and r["prob"][a, t] == -1     # :339-340
+                assert np.all(r["corr"][a, t] == 0)
+            else:
+                for k in ("argmax", "doa", "prob"):
+                    assert r[k][a, t] == r[k][a, last], (a, t, k)
+                assert np.array_equal(r["corr"][a, t], r["corr"][a, last])
+        assert nbad <= 2
+    assert 150 < fired_total <= 2 * 148                        # the bursts after the 47 frames of floor estimation, both arrays
+
+
 def _mask_margins(m, X, t_count):
     """oracle decisions plus a flag per (frame, band): decision sits within 1e-4 (relative) of a threshold"""
     decs, near = [], []
