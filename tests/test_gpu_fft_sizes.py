@@ -120,6 +120,47 @@ def test_two_microphone_gcc_at_512():
     ctx.close()
 
 
+def test_freqgcc_reference_test_configuration_44k1():
+    """The configuration of the reference's own FreqGCC test (test/test_mcarray.cpp:276-301): 44.1 kHz, microphones 0.089 m
+    apart, usePowerFloor = true, sources at -60 ... 60 degrees, mean reported DOA within 35 degrees.  0.075 s at 44.1 kHz
+    gives 4096-sample frames (the any-length kernels); the recordings are not in the reference's tree, so the source is a
+    far-field broadband one after 3 s of quiet for the floor estimation.  One angle is also compared frame by frame
+    with the oracle."""
+    fs, tol = 44100, 35.0
+    xs = [0.0, 0.089]
+    loc = None
+    for doa_deg in (-60, -30, 0, 20, 60):
+        loc = api.FreqGCCBinauralLocalisation(fs, xs, True)             # grid 3 degrees, N from the sample rate
+        N = loc.ctx.N
+        assert N == 4096 and loc.ctx.D == 61
+        hop, F = N // 2, 70
+        pcm = synth.noise_source_stream(xs, np.deg2rad(float(doa_deg)), fs, (F + 1) * hop, 100 + doa_deg)
+        env = np.repeat(np.where(np.arange(F + 1) < 36, 0.01, 1.0), hop)
+        pcm = (pcm * env[None, :]).astype(np.float32)
+        got = []
+        loc.set_callback(lambda deg, prob, power, n: got.append(float(deg[0])))
+        r = loc.process(pcm, want_corr=True)
+        assert len(got) == int(r["voiced"].sum()) and len(got) >= 25
+        assert abs(np.mean(got) - doa_deg) <= tol, (doa_deg, np.mean(got))
+        assert abs(np.mean(got[5:]) - doa_deg) <= 8.0, (doa_deg, np.mean(got[5:]))     # what this build actually achieves
+        if doa_deg == 20:
+            og = po.FreqGCC(fs, xs, N + 2, True, 3.0)
+            X = po.stft_frames(pcm.astype(np.float64), N)
+            nbad = 0
+            for t in range(F):
+                voiced, corr, idx, doa, power = og.process(X[t, 0], X[t, 1])
+                assert bool(r["voiced"][0, t]) == voiced, t
+                if not voiced:
+                    continue
+                if idx != r["argmax"][0, t]:
+                    assert abs(corr[idx] - corr[r["argmax"][0, t]]) < 1e-5 * np.abs(corr).max()
+                    nbad += 1
+                assert np.abs(r["corr"][0, t] - corr).max() <= 2e-5 * np.abs(corr).max(), t
+                assert abs(r["doa"][0, t] - doa) <= 2e-5 + 0.06 * nbad, t
+            assert nbad <= 1
+        loc.ctx.close()
+
+
 def test_unsupported_stream_sizes_say_why():
     ctx = api.Context(48000, synth.ULA8, 1000, 5.0, 1)             # even but not a power of two: frame API only
     with pytest.raises(api.MCArrayHipError, match="power-of-two"):
