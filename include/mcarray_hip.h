@@ -210,7 +210,8 @@ typedef struct {
     int struct_size;
     int device;
     int sample_rate;
-    int fft_size;            /* N = 2^calculateOrderFromSampleRate(fs, 0.050); the stream API needs 1024 */
+    int fft_size;            /* N = 2^calculateOrderFromSampleRate(fs, 0.050): 1024 at 16 kHz (tuned kernel), 2048 at 44.1 / 48 kHz;
+                                the stream API takes powers of two up to 8192, the frame hook any even N */
     double micro_distance;
     float low_freq, high_freq;
     int method;              /* mca_hip_mask_method */

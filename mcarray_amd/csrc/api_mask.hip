@@ -7,6 +7,7 @@
 #include "stage.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,8 @@ struct mca_hip_mask_ctx {
     MaskParams hp{};
     MaskParams *d_mp = nullptr;
     float *d_window = nullptr;
+    float2 *d_tw = nullptr, *d_kw = nullptr; int *d_kb = nullptr;   // any-length stream kernel
+    int hop = 0, logH = 0;
     float *d_Q[2] = {nullptr, nullptr}, *d_noise = nullptr, *d_tail[2] = {nullptr, nullptr};
     int q_cur = 0, tail_cur = 0;
     long long frames_done = 0;
@@ -79,7 +82,7 @@ void free_mask(mca_hip_mask_ctx *c)
 {
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->d_mp); F(c->d_window); F(c->d_Q[0]); F(c->d_Q[1]); F(c->d_noise); F(c->d_tail[0]); F(c->d_tail[1]);
+    F(c->d_mp); F(c->d_window); F(c->d_tw); F(c->d_kw); F(c->d_kb); F(c->d_Q[0]); F(c->d_Q[1]); F(c->d_noise); F(c->d_tail[0]); F(c->d_tail[1]);
     F(c->d_H); F(c->d_thr); F(c->d_Q64); F(c->d_noise64); F(c->d_io); F(c->d_dec);
     c->stage.release();
     delete c;
@@ -109,7 +112,8 @@ int mca_hip_mask_create(const mca_hip_mask_config *cfg, mca_hip_mask_ctx **out)
     if (hipSetDevice(cfg->device) != hipSuccess) return mfail(nullptr, MCA_HIP_ERR_HIP, "hipSetDevice failed");
 
     mca_hip_mask_ctx *c = new mca_hip_mask_ctx();
-    c->cfg = *cfg; c->N = cfg->fft_size; c->K = c->N / 2 + 1;
+    c->cfg = *cfg; c->N = cfg->fft_size; c->K = c->N / 2 + 1; c->hop = c->N / 2;
+    while ((1 << c->logH) < c->hop) ++c->logH;
     mel_filterbank(c->N, 45, cfg->sample_rate, (double)cfg->low_freq, (double)cfg->high_freq, c->H, c->center);
     c->thr.resize(45);
     const double phi = 10 * M_PI / 180;                                           // FastBinauralMasking.h:113
@@ -120,37 +124,41 @@ int mca_hip_mask_create(const mca_hip_mask_config *cfg, mca_hip_mask_ctx **out)
     const float lam = 0.04f, rej = 0.999f, rho = 0.01f;                           // FastBinauralMasking.h:114,128,124
     MaskParams &hp = c->hp;
     hp.lambda = lam; hp.one_minus_lambda = 1 - lam; hp.reject = rej; hp.rho = rho; hp.method = cfg->method; hp.alg = cfg->algorithm;
-    bool compact_ok = c->N == FFT_N;
-    if (compact_ok) {
-        for (int b = 0; b < 45; ++b) { hp.thr[b] = (float)c->thr[b]; hp.lo[b] = 1; hp.hi[b] = 0; }
-        for (int k = 0; k < c->K; ++k) {
-            hp.kb[k] = -1; hp.kw0[k] = 0.f; hp.kw1[k] = 0.f;
-            int nfound = 0;
-            for (int b = 0; b < 45; ++b) {
-                const double h = c->H[(size_t)b * c->K + k];
-                if (h > 0) {
-                    if (nfound == 0) { hp.kb[k] = b; hp.kw0[k] = (float)h; }
-                    else if (nfound == 1 && b == hp.kb[k] + 1) hp.kw1[k] = (float)h;
-                    else compact_ok = false;
-                    ++nfound;
-                    if (hp.lo[b] > hp.hi[b]) hp.lo[b] = k;
-                    hp.hi[b] = k;
-                }
+    // every bin is covered by at most two adjacent triangles: (first band, its weight, the next band's weight) per bin
+    bool compact_ok = true;
+    std::vector<int> kb(c->K, -1);
+    std::vector<float2> kw(c->K, make_float2(0.f, 0.f));
+    for (int b = 0; b < 45; ++b) { hp.thr[b] = (float)c->thr[b]; hp.lo[b] = 1; hp.hi[b] = 0; }
+    for (int k = 0; k < c->K; ++k) {
+        int nfound = 0;
+        for (int b = 0; b < 45; ++b) {
+            const double h = c->H[(size_t)b * c->K + k];
+            if (h > 0) {
+                if (nfound == 0) { kb[k] = b; kw[k].x = (float)h; }
+                else if (nfound == 1 && b == kb[k] + 1) kw[k].y = (float)h;
+                else compact_ok = false;
+                ++nfound;
+                if (hp.lo[b] > hp.hi[b]) hp.lo[b] = k;
+                hp.hi[b] = k;
             }
         }
     }
-    if (c->N == FFT_N && !compact_ok) { free_mask(c); return mfail(nullptr, MCA_HIP_ERR_UNSUPPORTED, "a bin is covered by more than two adjacent bands"); }
-
+    if (!compact_ok) { free_mask(c); return mfail(nullptr, MCA_HIP_ERR_UNSUPPORTED, "a bin is covered by more than two adjacent bands"); }
+    if (c->N == FFT_N)
+        for (int k = 0; k < c->K; ++k) { hp.kb[k] = kb[k]; hp.kw0[k] = kw[k].x; hp.kw1[k] = kw[k].y; }
     const size_t ns = (size_t)cfg->max_streams;
-    std::vector<float> win(FFT_N);
-    for (int n = 0; n < FFT_N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / FFT_N));
+    std::vector<float> win(c->N);
+    for (int n = 0; n < c->N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / c->N));
+    std::vector<float2> tw(c->N / 2);
+    for (int i = 0; i < c->N / 2; ++i) tw[i] = make_float2((float)std::cos(2.0 * M_PI * i / c->N), (float)(-std::sin(2.0 * M_PI * i / c->N)));
 #define MUP(dst, src, bytes) do { MHIP_TRY(c, hipMalloc((void **)&(dst), (bytes))); MHIP_TRY(c, hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice)); } while (0)
 #define MZ(dst, bytes) do { MHIP_TRY(c, hipMalloc((void **)&(dst), (bytes))); MHIP_TRY(c, hipMemset((dst), 0, (bytes))); } while (0)
     auto body = [&]() -> int {
         MUP(c->d_mp, &c->hp, sizeof(MaskParams));
         MUP(c->d_window, win.data(), win.size() * 4);
+        MUP(c->d_tw, tw.data(), tw.size() * 8); MUP(c->d_kw, kw.data(), kw.size() * 8); MUP(c->d_kb, kb.data(), kb.size() * 4);
         MZ(c->d_Q[0], ns * 45 * 4); MZ(c->d_Q[1], ns * 45 * 4); MZ(c->d_noise, ns * 45 * 4);
-        MZ(c->d_tail[0], ns * 2 * FFT_H * 4); MZ(c->d_tail[1], ns * 2 * FFT_H * 4);
+        MZ(c->d_tail[0], ns * 2 * c->hop * 4); MZ(c->d_tail[1], ns * 2 * c->hop * 4);
         MUP(c->d_H, c->H.data(), c->H.size() * 8);
         MUP(c->d_thr, c->thr.data(), 45 * 8);
         MZ(c->d_Q64, 45 * 8); MZ(c->d_noise64, 45 * 8);
@@ -179,7 +187,7 @@ int mca_hip_mask_reset(mca_hip_mask_ctx *c)
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
     MHIP_TRY(c, hipSetDevice(c->cfg.device));
     const size_t ns = (size_t)c->cfg.max_streams;
-    for (int i = 0; i < 2; ++i) { MHIP_TRY(c, hipMemset(c->d_Q[i], 0, ns * 45 * 4)); MHIP_TRY(c, hipMemset(c->d_tail[i], 0, ns * 2 * FFT_H * 4)); }
+    for (int i = 0; i < 2; ++i) { MHIP_TRY(c, hipMemset(c->d_Q[i], 0, ns * 45 * 4)); MHIP_TRY(c, hipMemset(c->d_tail[i], 0, ns * 2 * c->hop * 4)); }
     MHIP_TRY(c, hipMemset(c->d_noise, 0, ns * 45 * 4));
     MHIP_TRY(c, hipMemset(c->d_Q64, 0, 45 * 8)); MHIP_TRY(c, hipMemset(c->d_noise64, 0, 45 * 8));
     c->frames_done = 0; c->first_call = 0;
@@ -198,11 +206,11 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
                             int n_streams, int n_frames, float *out_pcm, int *decisions, void *stream)
 {
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
-    if (c->N != FFT_N) return mfail(c, MCA_HIP_ERR_UNSUPPORTED, "the stream API needs fft_size == 1024 (the frame hook takes any size)");
+    if (c->N > 8192) return mfail(c, MCA_HIP_ERR_UNSUPPORTED, "the stream API takes frame lengths up to 8192 (the frame hook takes any size)");
     if (!pcm || !out_pcm) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev/out_pcm_dev is NULL");
     if (n_streams < 1 || n_streams > c->cfg.max_streams) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_streams outside [1, max_streams]");
     if (n_frames < 1) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_frames < 1");
-    const long long need = (long long)(n_frames + 1) * FFT_H;
+    const long long need = (long long)(n_frames + 1) * c->hop;
     if (ch_stride < need || (n_streams > 1 && stream_stride < ch_stride + need)) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "strides shorter than (n_frames+1)*hop samples");
     if ((ch_stride & 1) || (stream_stride & 1) || (reinterpret_cast<uintptr_t>(pcm) & 7)) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev must be 8-byte aligned with even strides");
     hipStream_t st = (hipStream_t)stream;
@@ -218,13 +226,25 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
     a.Q_in = c->d_Q[c->q_cur]; a.Q_out = c->d_Q[c->q_cur ^ 1]; a.noise = c->d_noise;
     a.tail_in = c->d_tail[c->tail_cur]; a.tail_out = c->d_tail[c->tail_cur ^ 1];
     a.out = out_pcm; a.decisions = decisions;
-    // 79 KiB: two workgroups per CU
-    const size_t smem = (size_t)MK_NB * 2 * FFT_SCRATCH * sizeof(float2) + (size_t)MK_NB * 3 * 520 * sizeof(float) +
-                        TW_WIN * sizeof(float2) + (size_t)MK_NB * 48 * 8 * sizeof(float) + 520 * sizeof(float2) + 528;
-    if (smem > 64 * 1024)
-        MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);
-    hipLaunchKernelGGL(k_mask_stream, g, dim3(512), smem, st, a);
+    static const bool no_tuned = std::getenv("MCA_HIP_MASK_GENERIC") != nullptr;      // A/B switch for measurements
+    if (c->N == FFT_N && !no_tuned) {
+        // 79 KiB: two workgroups per CU
+        const size_t smem = (size_t)MK_NB * 2 * FFT_SCRATCH * sizeof(float2) + (size_t)MK_NB * 3 * 520 * sizeof(float) +
+                            TW_WIN * sizeof(float2) + (size_t)MK_NB * 48 * 8 * sizeof(float) + 520 * sizeof(float2) + 528;
+        if (smem > 64 * 1024)
+            MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);
+        hipLaunchKernelGGL(k_mask_stream, g, dim3(512), smem, st, a);
+    } else {
+        // any other power of two: one frame at a time, block-cooperative FFT (runs re-analyse MK_WARM + 1 frames)
+        MaskGenArgs ga{};
+        ga.a = a; ga.N = c->N; ga.logH = c->logH; ga.tw = c->d_tw; ga.kw = c->d_kw; ga.kb = c->d_kb;
+        const size_t smem = (size_t)2 * (c->hop + 1) * sizeof(float2) + ((size_t)3 * c->K + 2 * c->hop + 48 * 8) * sizeof(float);
+        if (smem > 64 * 1024)
+            MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);
+        hipLaunchKernelGGL(k_mask_stream_gen, g, dim3(c->N >= 2048 ? 512 : 256), smem, st, ga);
+    }
     MHIP_TRY(c, hipGetLastError());
     c->q_cur ^= 1; c->tail_cur ^= 1;
     c->frames_done += n_frames;
@@ -236,8 +256,8 @@ int mca_hip_mask_frames_host(mca_hip_mask_ctx *c, const float *pcm, int n_stream
     if (!c || !pcm || !out_pcm) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_streams < 1 || n_frames < 1) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_streams/n_frames < 1");
     MHIP_TRY(c, hipSetDevice(c->cfg.device));
-    const long long cs = (long long)(n_frames + 1) * FFT_H, ss = 2 * cs;
-    const size_t n_out = (size_t)n_streams * 2 * n_frames * FFT_H, n_dec = decisions ? (size_t)n_streams * n_frames * 45 : 0;
+    const long long cs = (long long)(n_frames + 1) * c->hop, ss = 2 * cs;
+    const size_t n_out = (size_t)n_streams * 2 * n_frames * c->hop, n_dec = decisions ? (size_t)n_streams * n_frames * 45 : 0;
     float *d_pcm = (float *)c->stage.get(0, (size_t)ss * n_streams * 4), *d_out = (float *)c->stage.get(1, n_out * 4);
     int *d_dec = (int *)c->stage.get(2, n_dec * 4);
     if (!d_pcm || !d_out || (decisions && !d_dec)) return mfail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");

@@ -34,6 +34,7 @@ __global__ void k_gcc2_scan(Gcc2ScanArgs p);
 __global__ void k_gcc2_compact(const unsigned char *voiced, int n_frames, int *vidx, int *nv);
 __global__ void k_gcc2_fill(Gcc2FillArgs p);
 __global__ void k_mask_stream(MaskArgs p);
+__global__ void k_mask_stream_gen(MaskGenArgs p);
 __global__ void k_mask_frame(MaskFrameArgs p);
 __global__ void k_mb_analyse(MbAnalyseArgs p);
 __global__ void k_mb_analyse_1024(MbAnalyseArgs p, int fpb);

@@ -10,26 +10,26 @@
 //
 //   k_mask_stream   batched streams: STFT -> masking -> ISTFT -> overlap-add, fp32
 //   k_mask_frame    one frame of double CCS spectra in place (the DSPONE hook), double
-#include "fft512.h"
+#include "fft_block.h"
 #include "mca_internal.h"
 
 namespace mca {
 
 __device__ __forceinline__ void mask_decide(const MaskParams &mp, int b, float S_mix, float S_LL, float S_RR, float S_LR,
                                             float S_LL512, float S_RR512, float &Q, float noise_b, long long gframe,
-                                            int &dec, float &gL, float &gR)
+                                            int &dec, float &gL, float &gR, int H = FFT_H, int K = FFT_K)
 {
     // temportalMasking :477-493 ; getFramePower/getPower :496-538 (an RMS over the first N/2 bins)
-    const float P = sqrtf(S_mix / (float)FFT_H);
+    const float P = sqrtf(S_mix / (float)H);
     Q = Q * mp.lambda + mp.one_minus_lambda * P;
     bool temp = P < mp.reject * Q;
     bool spat = false;
     if (mp.alg == 0 || mp.alg == 1) {                       // BOTH or SPATIAL :159-166
-        const float num = S_LR / (float)FFT_K;             // normaliseFFTCorrelation :410-460
+        const float num = S_LR / (float)K;             // normaliseFFTCorrelation :410-460
         float nc;
         if (num == 0.f) nc = 0.f;
         else {
-            const float den = sqrtf((S_LL / (float)FFT_K) * (S_RR / (float)FFT_K));
+            const float den = sqrtf((S_LL / (float)K) * (S_RR / (float)K));
             nc = den == 0.f ? 1.f : num / den;
         }
         spat = nc < mp.thr[b];
@@ -42,14 +42,14 @@ __device__ __forceinline__ void mask_decide(const MaskParams &mp, int b, float S
         case 3: gL = gR = 1.f / 1000.f; break;              // FULL: zeroFrame :214-217
         case 0: gL = gR = 1.f / (dec == 2 ? 10.f : 3.f); break;   // FACTOR :289-292 with .h:116-117
         case 1: {                                           // RELATIVE: maskFrameByScaling :245-287
-            float fl = (S_LL / (float)FFT_K) * mp.rho, fr = (S_RR / (float)FFT_K) * mp.rho;
+            float fl = (S_LL / (float)K) * mp.rho, fr = (S_RR / (float)K) * mp.rho;
             if (Q < 1e-10f) { fl = mp.rho; fr = mp.rho; } else { fl /= Q; fr /= Q; }
             gL = sqrtf(fl); gR = sqrtf(fr);
             break;
         }
         case 4: {                                           // NOISY: noisyFrame :219-243 (inactive during the first two frames)
             if (gframe >= 2) {
-                const float pl = sqrtf(S_LL512 / (float)FFT_H), pr = sqrtf(S_RR512 / (float)FFT_H);
+                const float pl = sqrtf(S_LL512 / (float)H), pr = sqrtf(S_RR512 / (float)H);
                 gL = pl > 0.f ? noise_b / pl : 1.f;
                 gR = pr > 0.f ? noise_b / pr : 1.f;
             }
@@ -204,6 +204,139 @@ __global__ __launch_bounds__(512) void k_mask_stream(MaskArgs p)
         if (tid < 45) { p.Q_out[s * 45 + tid] = Q; }
     }
     if (tid < 45 && p.frames_done == 0 && tbeg == 0) p.noise[s * 45 + tid] = noise_b;   // only one block per stream has tbeg == 0
+}
+
+// ---------------------------------------------------------------------------------------
+// k_mask_stream_gen: the same module for any power-of-two frame length (the reference derives N from the sample rate:
+// 2^round(log2(0.050 fs)), FastBinauralMasking.h:112 -- 1024 at 16 kHz, 2048 at 44.1/48 kHz, 512 at 8 kHz).
+// grid (runs of ft frames, streams), 256 ... 1024 threads, one frame at a time with the block-cooperative FFT of
+// fft_block.h; LDS = 2 (H + 1) float2 + 3 K + 2 H + 48 * 8 floats.  A run starts MK_WARM + 1 frames early: the Q
+// recursion warms up (0.04^8) and the frame before the run rebuilds the overlap-add carry.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_mask_stream_gen(MaskGenArgs pg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const MaskArgs &p = pg.a;
+    const int logH = pg.logH, H = 1 << logH, K = H + 1, zs = H + 1;
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);                  // [2][H + 1]
+    float *binq = reinterpret_cast<float *>(spec + 2 * zs);               // [3][K]
+    float *carry = binq + 3 * K;                                          // [2][H]
+    float *sums = carry + 2 * H;                                          // [48][6]
+    float *gains = sums + 48 * 6;                                         // [48][2]
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int s = blockIdx.y;
+    const MaskParams &mp = *p.mp;
+    const int t0 = blockIdx.x * p.ft, t1 = min(t0 + p.ft, p.n_frames);
+    const int tfull = t0 > 0 ? t0 - 1 : 0;
+    const int tbeg = t0 > 0 ? max(0, tfull - MK_WARM) : 0;
+    const bool passthrough = mp.method == 5;                              // NOTHING :130-134
+
+    float Q = 0.f, noise_b = 0.f;
+    if (tid < 45) {
+        if (tbeg == 0) Q = p.Q_in[s * 45 + tid];
+        noise_b = p.noise[s * 45 + tid];
+    }
+    for (int e = tid; e < 2 * H; e += NT) carry[e] = t0 == 0 ? p.tail_in[(long long)s * 2 * H + e] : 0.f;
+    const float *base = p.pcm + (long long)s * p.stream_stride;
+    const float sc = 1.0f / (float)H;
+
+    for (int t = tbeg; t < t1; ++t) {
+        // (1) analysis of both channels
+        load_frames(spec, zs, 2, logH, base, p.ch_stride, (long long)t, p.window, tid, NT);
+        block_fft_dit(spec, zs, 2, logH, pg.tw, pg.N, tid, NT);
+        split_forward(spec, zs, 2, logH, pg.tw, tid, NT);
+        // (2) per-bin products
+        for (int k = tid; k < K; k += NT) {
+            const float2 L = spec[k], R = spec[zs + k];
+            binq[k] = L.x * L.x + L.y * L.y; binq[K + k] = R.x * R.x + R.y * R.y; binq[2 * K + k] = L.x * R.x + L.y * R.y;
+        }
+        __syncthreads();
+        // (3) band sums: 8 lanes per band
+        for (int b = tid >> 3; b < 45; b += NT >> 3) {
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+            for (int k = mp.lo[b] + (tid & 7); k <= mp.hi[b]; k += 8) {
+                const float2 hw = pg.kw[k];
+                const float h = pg.kb[k] == b ? hw.x : hw.y;
+                const float w = h * h;
+                const float ll = binq[k], rr = binq[K + k], lr = binq[2 * K + k];
+                a0 += w * ll; a1 += w * rr; a2 += w * lr;
+                if (k < H) { a3 += w * lr; a4 += w * ll; a5 += w * rr; }
+            }
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {
+                a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
+                a3 += __shfl_xor(a3, off); a4 += __shfl_xor(a4, off); a5 += __shfl_xor(a5, off);
+            }
+            if ((tid & 7) == 0) {
+                float *o = sums + b * 6;
+                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = 0.25f * (a4 + a5 + 2.f * a3); o[4] = a4; o[5] = a5;
+            }
+        }
+        __syncthreads();
+        // (4) decisions: thread = band
+        if (tid < 45) {
+            const float *o = sums + tid * 6;
+            int dec; float gL, gR;
+            const long long gframe = p.frames_done + t;
+            mask_decide(mp, tid, o[3], o[0], o[1], o[2], o[4], o[5], Q, noise_b, gframe, dec, gL, gR, H, K);
+            if (gframe == 0) noise_b = Q;                                   // noise <- Q after the first call :193-197
+            gains[tid * 2] = gL; gains[tid * 2 + 1] = gR;
+            if (p.decisions && t >= t0) p.decisions[((long long)s * p.n_frames + t) * 45 + tid] = dec;
+        }
+        __syncthreads();
+        if (t >= tfull) {
+            // (5) out[k] = X[k] * sum_b g_b H_b[k]  (Nyquist bin: gain 1)
+            for (int e = tid; e < 2 * K; e += NT) {
+                const int ch = e / K, k = e - ch * K;
+                float m = 1.f;
+                if (!passthrough) {
+                    const int b0 = pg.kb[k];
+                    m = 0.f;
+                    if (b0 >= 0) {
+                        const float g0 = k < H ? gains[b0 * 2 + ch] : 1.f;
+                        const float g1 = (k < H && b0 + 1 < 45) ? gains[(b0 + 1) * 2 + ch] : 1.f;
+                        const float2 hw = pg.kw[k];
+                        m = g0 * hw.x + g1 * hw.y;
+                    }
+                }
+                const float2 x = spec[ch * zs + k];
+                spec[ch * zs + k] = make_float2(x.x * m, x.y * m);
+            }
+            __syncthreads();
+            // (6) one-sided spectra -> packed Z (imaginary parts of DC and Nyquist ignored), inverse transform
+            for (int e = tid; e < 2 * (H / 2 + 1); e += NT) {
+                const int ch = e / (H / 2 + 1), k = e - ch * (H / 2 + 1);
+                float2 *yy = spec + ch * zs;
+                float2 xk = yy[k], xp = yy[H - k];
+                if (k == 0) { xk.y = 0.f; xp.y = 0.f; }
+                const float2 ev = make_float2(0.5f * (xk.x + xp.x), 0.5f * (xk.y - xp.y));
+                const float2 df = make_float2(0.5f * (xk.x - xp.x), 0.5f * (xk.y + xp.y));
+                const float2 od = cmulc(df, pg.tw[k]);
+                yy[k] = make_float2(ev.x - od.y, ev.y + od.x);
+                if (k != 0 && k != H - k) yy[H - k] = make_float2(ev.x + od.y, -ev.y + od.x);
+            }
+            __syncthreads();
+            block_ifft_dif(spec, zs, 2, logH, pg.tw, pg.N, tid, NT);
+            // (7) overlap-add
+            for (int e = tid; e < 2 * (H / 2); e += NT) {
+                const int ch = e / (H / 2), n = e - ch * (H / 2);
+                const float2 lo = spec[ch * zs + (int)(__brev((unsigned)n) >> (32 - logH))];
+                const float2 hi = spec[ch * zs + (int)(__brev((unsigned)(n + H / 2)) >> (32 - logH))];
+                float *cr = carry + ch * H + 2 * n;
+                if (t >= t0) {
+                    float *o = p.out + ((long long)s * 2 + ch) * (long long)p.n_frames * H + (long long)t * H + 2 * n;
+                    o[0] = cr[0] + lo.x * sc; o[1] = cr[1] + lo.y * sc;
+                }
+                cr[0] = hi.x * sc; cr[1] = hi.y * sc;
+            }
+        }
+        __syncthreads();
+    }
+    if (t1 == p.n_frames) {
+        for (int e = tid; e < 2 * H; e += NT) p.tail_out[(long long)s * 2 * H + e] = carry[e];
+        if (tid < 45) p.Q_out[s * 45 + tid] = Q;
+    }
+    if (tid < 45 && p.frames_done == 0 && tbeg == 0) p.noise[s * 45 + tid] = noise_b;
 }
 
 // ---------------------------------------------------------------------------------------

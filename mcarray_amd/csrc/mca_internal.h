@@ -160,6 +160,15 @@ struct MaskArgs {
     float *out; int *decisions;
 };
 
+// any-length variant: the per-bin band tables live in global memory (length K = N/2 + 1)
+struct MaskGenArgs {
+    MaskArgs a;
+    int N, logH;
+    const float2 *tw;         // [N/2]
+    const float2 *kw;         // [K] (H_kb[k], H_{kb+1}[k])
+    const int *kb;            // [K] first band covering bin k, -1 if none
+};
+
 struct MaskFrameArgs {
     const double *L, *R;      // [K] complex (CCS)
     double *outL, *outR;      // [K] complex, zeroed by the caller

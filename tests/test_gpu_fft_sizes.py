@@ -161,6 +161,41 @@ def test_freqgcc_reference_test_configuration_44k1():
         loc.ctx.close()
 
 
+@pytest.mark.parametrize("fs,N", [(48000, 2048), (44100, 2048), (8000, 512), (96000, 4096)])
+@pytest.mark.parametrize("method,alg", [(api.RELATIVE, api.BOTH), (api.FULL, api.BOTH), (api.FACTOR, api.TEMPORAL), (api.NOISY, api.SPATIAL)])
+def test_masking_stream_other_frame_lengths(fs, N, method, alg):
+    """FastBinauralMasking takes N = 2^round(log2(0.050 fs)) (FastBinauralMasking.h:112): 2048 at 44.1 / 48 kHz, 512 at 8 kHz.
+    Any-length stream kernel against the oracle; long enough to cross its runs (warm-up of the Q recursion, overlap-add
+    carry) and split over two calls.  Decisions exact except cells the oracle itself puts within 1e-4 of a threshold."""
+    assert N == 1 << api.calculate_order_from_sample_rate(fs, 0.050)
+    hop, F, d = N // 2, 70, 0.086
+    rng = np.random.default_rng(N + method)
+    n = (F + 1) * hop
+    src = rng.standard_normal(n) * 0.1
+    left = src + rng.standard_normal(n) * 0.003
+    right = np.roll(src, 1) * 0.9 + rng.standard_normal(n) * 0.003
+    env = np.repeat(rng.choice([1.0, 0.2, 0.05, 0.6], F + 1), hop)                    # level steps exercise the temporal mask
+    pcm = np.stack([left * env, right * env]).astype(np.float32)
+    flo, fhi = 300.0, min(5000.0, 0.45 * fs)
+    m = api.FastBinauralMasking(fs, d, flo, fhi, method, alg, fft_size=N)
+    h = 33
+    oa, da = m.process(pcm[:, :(h + 1) * hop])
+    ob, db = m.process(pcm[:, h * hop:])
+    out = np.concatenate([oa[0], ob[0]], axis=1)
+    dec = np.concatenate([da[0], db[0]], axis=0)
+    o = po.Masking(fs, N, d, flo, fhi, method, alg)
+    ol, orr = o.stream(pcm[0].astype(np.float64), pcm[1].astype(np.float64))
+    o2 = po.Masking(fs, N, d, flo, fhi, method, alg)
+    X = po.stft_frames(pcm.astype(np.float64), N)
+    odec = np.array([o2.process(X[t, 0], X[t, 1])[2] for t in range(F)])
+    ndiff = int((dec != odec).sum())
+    assert ndiff <= 2, "decisions differ in %d (frame, band) cells" % ndiff
+    ref = np.stack([ol, orr])
+    if ndiff == 0:
+        assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-7
+    m.close()
+
+
 def test_unsupported_stream_sizes_say_why():
     ctx = api.Context(48000, synth.ULA8, 1000, 5.0, 1)             # even but not a power of two: frame API only
     with pytest.raises(api.MCArrayHipError, match="power-of-two"):

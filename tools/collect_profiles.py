@@ -42,6 +42,14 @@ for prec in ("fp16x3", "fp16", "fp32"):
                                         "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"]["sum"] / v["FETCH_SIZE"]["dispatches"],
                                         "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"]["sum"] / v["WRITE_SIZE"]["dispatches"]}
         json.dump(out, open(os.path.join(P, "%s_pmc_traffic_%s.json" % (tag, prec)), "w"), indent=1)
+ks = os.path.join(G, "final", "kernel_stats_mvdr.csv")
+if os.path.exists(ks):
+    shutil.copy(ks, os.path.join(P, "%s_kernel_stats_mvdr.csv" % tag))
+log = os.path.join(G, "final", "bench_mvdr.log")
+if os.path.exists(log):
+    lines = [l for l in open(log) if l.startswith("{")]
+    if lines:
+        open(os.path.join(P, "%s_bench_mvdr.json" % tag), "w").write(lines[-1])
 sq = os.path.join(G, "pmc_sq", "sq_fp16x3.json")
 if os.path.exists(sq):
     raw = json.load(open(sq))
