@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #include "BeamformingSeparationAndLocalistaion.h"
@@ -87,7 +88,15 @@ public:
         const size_t FS = static_cast<size_t>(F) * static_cast<size_t>(_numOfSources);
         std::vector<int> bins(FS);
         std::vector<float> doa(FS), prob(FS), audio(FS * static_cast<size_t>(hop));
-        _stream->check(mca_hip_process_frames_host(_stream->get(), pcm.data(), 1, F, bins.data(), doa.data(), prob.data(), nullptr, audio.data()));
+        if (std::is_same<typename std::remove_cv<Tin>::type, short>::value) {
+            // 16-bit PCM (the process(std::vector<int16_t*>&, ...) overloads of the reference's callers, mcabeamf.cpp:112):
+            // the shorts go up as they are, half the PCIe bytes; the buffered floats hold them exactly
+            std::vector<short> pcm16(pcm.size());
+            for (size_t i = 0; i < pcm.size(); ++i) pcm16[i] = static_cast<short>(pcm[i]);
+            _stream->check(mca_hip_process_frames_host_i16(_stream->get(), pcm16.data(), 1, F, bins.data(), doa.data(), prob.data(), nullptr, audio.data()));
+        } else {
+            _stream->check(mca_hip_process_frames_host(_stream->get(), pcm.data(), 1, F, bins.data(), doa.data(), prob.data(), nullptr, audio.data()));
+        }
         std::vector<unsigned char> voiced(static_cast<size_t>(F), 1);
         std::vector<float> power(static_cast<size_t>(F), 0.f);
         if (_usePowerFloor) _stream->check(mca_hip_copy_gate(_stream->get(), voiced.data(), power.data()));

@@ -137,6 +137,13 @@ int mca_hip_process_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long
                                int *doa_bin_dev, float *doa_rad_dev, float *prob_dev,
                                float *energy_dev, float *out_pcm_dev, void *stream);
 
+/* The same for 16-bit PCM, the sample type of the reference's process(std::vector<int16_t*>&, ...) overloads and of the
+ * WAV / raw files its tools read (mcabeamf.cpp:112, test_mcarray.cpp:618).  pcm is [A][M][(F+1)*hop] int16; the samples
+ * are taken at face value (+-32768, like a cast to double: PHAT and the DOA do not depend on the scale, the audio out is
+ * in the same units).  Half the bytes cross PCIe; the conversion to fp32 runs on the GPU. */
+int mca_hip_process_frames_host_i16(mca_hip_ctx *ctx, const short *pcm, int n_arrays, int n_frames,
+                                    int *doa_bin, float *doa_rad, float *prob, float *energy, float *out_pcm);
+
 /* After a stream call on a context with use_power_floor = 1: copies, for the frames of that call,
  * voiced[A][F] (1 where processFrameLocalisation passed the gate and the callback fires,
  * BeamformingSeparationAndLocalisation.cpp:87-94) and power[A][F] (the value handed to setDOA).  Either may be NULL.

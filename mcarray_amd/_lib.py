@@ -131,6 +131,7 @@ SYMBOLS = [
       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mca_hip_mb_frames_host", C.c_int,
      [C.c_void_p, c_fp, C.c_int, C.c_int, c_fp, c_fp, C.c_void_p, c_fp, c_ip, c_fp, c_fp]),
+    ("mca_hip_process_frames_host_i16", C.c_int, [C.c_void_p, C.POINTER(C.c_short), C.c_int, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp]),
     ("mca_hip_graph_create", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
       C.POINTER(C.c_void_p)]),

@@ -102,7 +102,8 @@ class Context:
     # ---- stream API, host buffers ----
     def process_frames_host(self, pcm, want_energy=False, want_audio=True):
         """pcm float32 [A][M][(F+1)*hop] -> dict(bin [A][F][S], doa, prob, energy [A][F][D], out [A][S][F*hop])"""
-        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        i16 = isinstance(pcm, np.ndarray) and pcm.dtype == np.int16       # 16-bit PCM goes up as it is (half the PCIe bytes)
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16 if i16 else np.float32)
         if pcm.ndim == 2:
             pcm = pcm[None]
         A, M, L = pcm.shape
@@ -118,8 +119,9 @@ class Context:
         energy = np.empty((A, F, D), dtype=np.float32) if want_energy else None
         out = np.empty((A, S, F * self.hop), dtype=np.float32) if want_audio else None
         fp = _lib.c_fp
-        self._check(self._lib.mca_hip_process_frames_host(
-            self.h, pcm.ctypes.data_as(fp), A, F, bins.ctypes.data_as(_lib.c_ip), doa.ctypes.data_as(fp),
+        entry = self._lib.mca_hip_process_frames_host_i16 if i16 else self._lib.mca_hip_process_frames_host
+        self._check(entry(
+            self.h, pcm.ctypes.data_as(C.POINTER(C.c_short) if i16 else fp), A, F, bins.ctypes.data_as(_lib.c_ip), doa.ctypes.data_as(fp),
             prob.ctypes.data_as(fp), energy.ctypes.data_as(fp) if want_energy else None,
             out.ctypes.data_as(fp) if want_audio else None))
         res = dict(bin=bins, doa=doa, prob=prob, energy=energy, out=out)

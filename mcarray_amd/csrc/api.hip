@@ -921,6 +921,46 @@ int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, 
 }
 
 
+// 16-bit PCM: upload the shorts (half the PCIe bytes), widen on the GPU
+__global__ void k_i16_to_f32(const short *src, float *dst, long long n4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        const short4 v = reinterpret_cast<const short4 *>(src)[i];
+        reinterpret_cast<float4 *>(dst)[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+    }
+}
+
+int mca_hip_process_frames_host_i16(mca_hip_ctx *c, const short *pcm, int n_arrays, int n_frames, int *doa_bin,
+                                    float *doa_rad, float *prob, float *energy, float *out_pcm)
+{
+    if (!c || !pcm || !doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const long long ms = (long long)(n_frames + 1) * c->H, as = ms * c->M;
+    const size_t n_pcm = (size_t)as * n_arrays, n_fs = (size_t)n_arrays * n_frames * c->S;
+    const size_t n_en = energy ? (size_t)n_arrays * n_frames * c->D : 0, n_out = out_pcm ? (size_t)n_arrays * c->S * n_frames * c->H : 0;
+    float *d_pcm = (float *)c->stage.get(0, n_pcm * 4), *d_rad = (float *)c->stage.get(2, n_fs * 4), *d_prob = (float *)c->stage.get(3, n_fs * 4);
+    float *d_en = (float *)c->stage.get(4, n_en * 4), *d_out = (float *)c->stage.get(5, n_out * 4);
+    int *d_bin = (int *)c->stage.get(1, n_fs * 4);
+    short *d_i16 = (short *)c->stage.get(6, n_pcm * 2);
+    if (!d_pcm || !d_i16 || !d_bin || !d_rad || !d_prob || (energy && !d_en) || (out_pcm && !d_out))
+        return fail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
+    HIP_TRY(c, hipMemcpy(d_i16, pcm, n_pcm * 2, hipMemcpyHostToDevice));
+    const long long n4 = (long long)(n_pcm / 4);                    // (F+1)*hop is a multiple of 32
+    hipLaunchKernelGGL(k_i16_to_f32, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, nullptr, d_i16, d_pcm, n4);
+    int rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
+    if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
+    if (doa_rad) HIP_TRY(c, hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
+    if (prob) HIP_TRY(c, hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
+    if (energy) HIP_TRY(c, hipMemcpy(energy, d_en, n_en * 4, hipMemcpyDeviceToHost));
+    if (out_pcm) HIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
+    return MCA_HIP_OK;
+}
+
 int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
                             int n_arrays, int n_frames, int *argmax, float *doa_rad, float *prob, float *corr, void *stream)
 {
