@@ -64,6 +64,26 @@ def test_mvdr_stream_matches_oracle(xs, fs, N, F):
     assert np.abs(r2["out"][1, hop:] - o2["out"][hop:]).max() <= AUDIO_TOL * np.abs(o2["out"]).max()
 
 
+@pytest.mark.parametrize("M", [3, 6, 7, 9, 11, 13, 15])
+def test_mvdr_every_row_slot_count(M):
+    """The solve kernel deals the rows of the triangle cyclically over four lanes (1 ... 4 row slots per lane): channel counts
+    that leave the last slot partly empty, a bin count that is no multiple of the 16 problems of a wave, one frame per call."""
+    fs, N, F, A = 16000, 256, 9, 2
+    rng = np.random.default_rng(M)
+    xs = np.sort(rng.uniform(0.0, 0.04 * M, M))
+    pcm = np.stack([_scene(xs, fs, N, F, a) for a in range(A)])
+    doa = rng.uniform(-1.3, 1.3, (A, F)).astype(np.float32)
+    bf = api.MvdrBeamformer(fs, xs, N, max_streams=A)
+    hop = N // 2
+    specs = [bf.process(pcm[:, :, t * hop:(t + 2) * hop], doa[:, t:t + 1], want_spec=True)["spec"] for t in range(F)]
+    spec = np.concatenate(specs, axis=1)
+    for a in range(A):
+        og = po.MVDR(fs, N, xs)
+        sp = _ospec(og.stream(pcm[a].astype(np.float64), doa[a].astype(np.float64), want_spec=True))
+        assert np.abs(spec[a] - sp).max() <= SPEC_TOL * np.abs(sp).max(), (M, a)
+        assert np.abs(bf.covariance(a) - og.covariance()).max() <= COV_TOL * np.abs(og.covariance()).max()
+
+
 @pytest.mark.parametrize("name", ["mvdr_ula16_48k", "mvdr_reemc_16k"])
 def test_mvdr_matches_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
