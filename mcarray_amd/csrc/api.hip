@@ -760,7 +760,15 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     // frame (16 -> 64 frames: 0.344 -> 0.323 ms on the bench shape); smaller batches take shorter runs so that two
     // workgroups per CU exist (multiples of the 4-frame batch)
     ba.ft = 64;
-    while (ba.ft > BF_NB && (long long)n_arrays * ((n_frames + ba.ft - 1) / ba.ft) < 512) ba.ft >>= 1;
+    // (the any-length kernel walks its frames one at a time behind ~15 barriers each and is latency bound: it wants as
+    // many workgroups per CU as its LDS allows, up to the 8 that fill the wave slots with 256 threads)
+    long long want_wgs = 512;
+    if (c->generic) {
+        const size_t smem_g = (size_t)(c->M + c->S) * (c->H + 1) * sizeof(float2) + (size_t)c->S * c->H * sizeof(float);
+        const long long per_cu = std::max<long long>(1, std::min<long long>((160 * 1024) / (long long)smem_g, 2048 / gen_threads(c, true)));
+        want_wgs = 256 * per_cu;
+    }
+    while (ba.ft > BF_NB && (long long)n_arrays * ((n_frames + ba.ft - 1) / ba.ft) < want_wgs) ba.ft >>= 1;
     ba.window = c->d_window; ba.mic_x = c->d_micx; ba.doa_rad = doa_rad; ba.out = out_pcm;
     ba.tail_in = c->d_tail[c->tail_cur]; ba.tail_out = c->d_tail[c->tail_cur ^ 1];
     ba.N = c->N; ba.logH = c->logH; ba.tw = c->d_tw;

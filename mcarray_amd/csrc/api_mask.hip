@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include "stage.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -240,10 +241,17 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
         MaskGenArgs ga{};
         ga.a = a; ga.N = c->N; ga.logH = c->logH; ga.tw = c->d_tw; ga.kw = c->d_kw; ga.kb = c->d_kb;
         const size_t smem = (size_t)2 * (c->hop + 1) * sizeof(float2) + ((size_t)3 * c->K + 2 * c->hop + 48 * 8) * sizeof(float);
+        const int nthr = c->N >= 2048 ? 512 : 256;
+        if (!(c->cfg.method == MCA_HIP_MASK_NOISY && c->frames_done == 0)) {
+            // latency bound (one frame at a time behind ~20 barriers): as many workgroups per CU as LDS and wave slots allow
+            const long long per_cu = std::max<long long>(1, std::min<long long>((160 * 1024) / (long long)smem, 2048 / nthr));
+            ga.a.ft = 256;
+            while (ga.a.ft > 16 && (long long)n_streams * ((n_frames + ga.a.ft - 1) / ga.a.ft) < 256 * per_cu) ga.a.ft >>= 1;
+        }
         if (smem > 64 * 1024)
             MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);
-        hipLaunchKernelGGL(k_mask_stream_gen, g, dim3(c->N >= 2048 ? 512 : 256), smem, st, ga);
+        dim3 g((n_frames + ga.a.ft - 1) / ga.a.ft, n_streams);
+        hipLaunchKernelGGL(k_mask_stream_gen, g, dim3(nthr), smem, st, ga);
     }
     MHIP_TRY(c, hipGetLastError());
     c->q_cur ^= 1; c->tail_cur ^= 1;
