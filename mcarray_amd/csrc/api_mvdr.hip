@@ -26,7 +26,7 @@ struct mca_hip_mvdr_ctx {
     float *d_tail[2] = {nullptr, nullptr}; int tail_cur = 0;   // [max_streams][H]
     // workspace
     float2 *d_X = nullptr; size_t x_rows = 0;      // [rows][K][M]
-    float2 *d_Y = nullptr; double *d_cdoa = nullptr; size_t y_rows = 0;
+    float2 *d_Y = nullptr; float2 *d_T = nullptr; size_t y_rows = 0;   // d_T: factored steering phasors [rows][M][N/64 + 33]
     StagePool stage;
     bool timing = false;
     struct Ev { int id; hipEvent_t a, b; };
@@ -59,7 +59,7 @@ void free_mvdr(mca_hip_mvdr_ctx *c)
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_window); F(c->d_tw); F(c->d_micx); F(c->d_phi); F(c->d_trace); F(c->d_tail[0]); F(c->d_tail[1]);
-    F(c->d_X); F(c->d_Y); F(c->d_cdoa);
+    F(c->d_X); F(c->d_Y); F(c->d_T);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     c->stage.release();
     delete c;
@@ -84,9 +84,9 @@ int ensure_ws(mca_hip_mvdr_ctx *c, size_t rows)
         c->x_rows = rows;
     }
     if (rows > c->y_rows) {
-        F(c->d_Y); F(c->d_cdoa); c->d_Y = nullptr; c->d_cdoa = nullptr; c->y_rows = 0;
+        F(c->d_Y); F(c->d_T); c->d_Y = nullptr; c->d_T = nullptr; c->y_rows = 0;
         VHIP_TRY(c, hipMalloc((void **)&c->d_Y, rows * c->K * sizeof(float2)));
-        VHIP_TRY(c, hipMalloc((void **)&c->d_cdoa, rows * sizeof(double)));
+        VHIP_TRY(c, hipMalloc((void **)&c->d_T, rows * c->M * (c->N / 64 + 33) * sizeof(float2)));
         c->y_rows = rows;
     }
     return MCA_HIP_OK;
@@ -212,7 +212,8 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     MvdrAnalyseArgs aa{};
     aa.pcm = pcm; aa.stream_stride = stream_stride; aa.mic_stride = mic_stride; aa.n_frames = n_frames;
     aa.N = c->N; aa.logH = c->logH; aa.M = c->M; aa.window = c->d_window; aa.tw = c->d_tw; aa.doa_rad = doa_rad;
-    aa.X = c->d_X; aa.cdoa = c->d_cdoa;
+    aa.X = c->d_X; aa.T = c->d_T; aa.mic_x = c->d_micx;
+    aa.unit = (double)c->cfg.sample_rate / (double)c->N / 346.1;                      // Beamformer.cpp:59 without 2 pi
     static const bool no_tuned = std::getenv("MCA_HIP_MVDR_GENERIC") != nullptr;     // A/B switch for measurements
     t_begin(c, 0, st);
     if (c->N == FFT_N && !no_tuned) {
@@ -231,8 +232,7 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     t_end(c, st);
 
     MvdrSolveArgs sa{};
-    sa.X = c->d_X; sa.cdoa = c->d_cdoa; sa.mic_x = c->d_micx;
-    sa.unit = (double)c->cfg.sample_rate / (double)c->N / 346.1;                      // Beamformer.cpp:59 without 2 pi
+    sa.X = c->d_X; sa.T = c->d_T;
     sa.n_frames = n_frames; sa.K = c->K; sa.M = c->M;
     sa.alpha = (float)c->cfg.alpha; sa.one_minus_alpha = (float)(1.0 - c->cfg.alpha);
     sa.loading_over_m = (float)(c->cfg.loading / c->M);
@@ -241,10 +241,16 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     const int Q = (c->M + 3) / 4;                                                     // row slots per lane
     const dim3 sgrid((unsigned)(((long long)n_streams * c->K + 63) / 64));
     t_begin(c, 1, st);
-    if (Q == 1) hipLaunchKernelGGL(k_mvdr_solve<1>, sgrid, dim3(256), 0, st, sa);
-    else if (Q == 2) hipLaunchKernelGGL(k_mvdr_solve<2>, sgrid, dim3(256), 0, st, sa);
-    else if (Q == 3) hipLaunchKernelGGL(k_mvdr_solve<3>, sgrid, dim3(256), 0, st, sa);
-    else hipLaunchKernelGGL(k_mvdr_solve<4>, sgrid, dim3(256), 0, st, sa);
+#define SOLVE(QQ)                                                                                          \
+    do {                                                                                                   \
+        if (c->M == 4 * (QQ)) hipLaunchKernelGGL((k_mvdr_solve<QQ, true>), sgrid, dim3(256), 0, st, sa);   \
+        else hipLaunchKernelGGL((k_mvdr_solve<QQ, false>), sgrid, dim3(256), 0, st, sa);                   \
+    } while (0)
+    if (Q == 1) SOLVE(1);
+    else if (Q == 2) SOLVE(2);
+    else if (Q == 3) SOLVE(3);
+    else SOLVE(4);
+#undef SOLVE
     t_end(c, st);
 
     if (out_pcm) {

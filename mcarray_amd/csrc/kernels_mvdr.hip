@@ -24,6 +24,24 @@ namespace mca {
 // --------------------------------------------------------------------------------------
 // k_mvdr_analyse: grid (frames, streams), 256 ... 1024 threads, LDS = M * (H + 1) float2
 // --------------------------------------------------------------------------------------
+// factored steering phasors of frame f of stream a (see MvdrAnalyseArgs::T), by the threads tid, tid + nthr, ...
+__device__ __forceinline__ void mvdr_steering_tables(const MvdrAnalyseArgs &p, int a, int f, int tid, int nthr)
+{
+    const int nhi = (p.N >> 6) + 1, nph = nhi + 32;
+    const long long o = (long long)a * p.n_frames + f;
+    const double cd = cos((double)p.doa_rad[o] + 1.57079632679489661923);   // cos(DOA + M_PI/2), Beamformer.cpp:59
+    float2 *T = p.T + o * p.M * nph;
+    for (int e = tid; e < p.M * nph; e += nthr) {
+        const int m = e / nph, i = e - m * nph;
+        const int kk = i < nhi ? (i << 5) : i - nhi;
+        double turns = (double)kk * (p.unit * p.mic_x[m] * cd);
+        turns -= rint(turns);
+        float sn, cs;
+        sincospif(2.0f * (float)turns, &sn, &cs);
+        T[e] = make_float2(cs, -sn);
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_mvdr_analyse(MvdrAnalyseArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -32,10 +50,7 @@ __global__ __launch_bounds__(1024) void k_mvdr_analyse(MvdrAnalyseArgs p)
     const int tid = threadIdx.x, NT = blockDim.x;
     const int a = blockIdx.y, f = blockIdx.x;
     const float *base = p.pcm + (long long)a * p.stream_stride;
-    if (tid == 0) {
-        const long long o = (long long)a * p.n_frames + f;
-        p.cdoa[o] = cos((double)p.doa_rad[o] + 1.57079632679489661923);     // cos(DOA + M_PI/2), Beamformer.cpp:59
-    }
+    mvdr_steering_tables(p, a, f, tid, NT);
     load_frames(xs, zs, M, logH, base, p.mic_stride, (long long)f, p.window, tid, NT);
     block_fft_dit(xs, zs, M, logH, p.tw, p.N, tid, NT);
     split_forward(xs, zs, M, logH, p.tw, tid, NT);
@@ -66,10 +81,7 @@ __global__ __launch_bounds__(512) void k_mvdr_analyse_1024(MvdrAnalyseArgs p, in
     const float *base = p.pcm + (long long)a * p.stream_stride;
 
     fft_table_init(tab, p.window, tid, 512);
-    for (int f = f_begin + tid; f < f_end; f += 512) {
-        const long long o = (long long)a * p.n_frames + f;
-        p.cdoa[o] = cos((double)p.doa_rad[o] + 1.57079632679489661923);     // cos(DOA + M_PI/2), Beamformer.cpp:59
-    }
+    for (int f = f_begin; f < f_end; ++f) mvdr_steering_tables(p, a, f, tid, 512);
     __syncthreads();
     FftTw tw{tab};
     for (int f = f_begin; f < f_end; ++f) {
@@ -127,7 +139,7 @@ __device__ __forceinline__ float quad_bcast(float v, int b)
 }
 __device__ __forceinline__ float2 quad_bcast(float2 v, int b) { return make_float2(quad_bcast(v.x, b), quad_bcast(v.y, b)); }
 
-template <int Q>
+template <int Q, bool FULL>      // FULL: M == 4 Q, no partly empty row slot
 __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
 {
     constexpr int NE = 2 * Q * (Q + 1);          // row slot q holds 4 (q + 1) entries, starting at 2 q (q + 1)
@@ -142,17 +154,17 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
     const int tri = M * (M + 1) / 2;
     float2 *st = p.phi + pc * tri;
     float2 P[NE], L[NE];
-    double geo[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int i = 4 * q + l;
-        geo[q] = p.unit * p.mic_x[i < M ? i : 0];
 #pragma unroll
         for (int m = 0; m < 4 * (q + 1); ++m)
             P[2 * q * (q + 1) + m] = (i < M && m <= i) ? st[i * (i + 1) / 2 + m] : make_float2(0.f, 0.f);
     }
     float tr = p.trace[pc];
-    const double *cd = p.cdoa + (long long)a * F;
+    const int nhi = ((K - 1) >> 5) + 1, nph = nhi + 32;
+    const float2 *T = p.T + (long long)a * F * M * nph + (k >> 5);         // + (t M + m) nph: hi factor; + nhi - (k >> 5) + (k & 31): lo
+    const int lo_off = nhi - (k >> 5) + (k & 31);
     const long long fstride = (long long)K * M;
     const float2 *X = p.X + (long long)a * F * fstride + (long long)k * M + l;
     const float al = p.alpha, oma = p.one_minus_alpha;
@@ -160,21 +172,18 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
 
     float2 xn[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) xn[q] = 4 * q + l < M ? X[4 * q] : make_float2(0.f, 0.f);
+    for (int q = 0; q < Q; ++q) xn[q] = (FULL || 4 * q + l < M) ? X[4 * q] : make_float2(0.f, 0.f);
     for (int t = 0; t < F; ++t) {
         float2 x[Q], d[Q], rd[Q], rx[Q];
         float dsum[Q];
-        const double cdt = cd[t];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
+            const bool rv = FULL || 4 * q + l < M;
             x[q] = xn[q];
-            if (t + 1 < F && 4 * q + l < M) xn[q] = X[(long long)(t + 1) * fstride + 4 * q];
-            // steering d_i = exp(-j k s_i), s_i = 2 pi fs/N/c x_i cos(DOA + pi/2); the phase is reduced in double
-            double turns = (double)k * (geo[q] * cdt);
-            turns -= rint(turns);
-            float sn, cs;
-            sincospif(2.0f * (float)turns, &sn, &cs);
-            d[q] = 4 * q + l < M ? make_float2(cs, -sn) : make_float2(0.f, 0.f);
+            if (t + 1 < F && rv) xn[q] = X[(long long)(t + 1) * fstride + 4 * q];
+            // steering d_i = exp(-j k s_i), s_i = 2 pi fs/N/c x_i cos(DOA + pi/2), from the factored tables of the analysis
+            const float2 *tq = T + ((long long)t * M + (rv ? 4 * q + l : 0)) * nph;
+            d[q] = rv ? cmul(tq[0], tq[lo_off]) : make_float2(0.f, 0.f);
         }
         // Phi <- alpha Phi + (1 - alpha) x x^H (the rows of this lane), tr <- alpha tr + (1 - alpha) |x|^2
         float e = 0.f;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
             const float2 xs = make_float2(oma * x[q].x, oma * x[q].y);
 #pragma unroll
             for (int m = 0; m < 4 * (q + 1); ++m)
-                if (m < M) {
+                if (FULL || m < M) {
                     const float2 xm = quad_bcast(x[m >> 2], m & 3);
                     float2 &e_ = P[2 * q * (q + 1) + m];
                     e_ = cmacc(make_float2(al * e_.x, al * e_.y), xs, xm);
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
         for (int q = 0; q < Q; ++q) { rd[q] = d[q]; rx[q] = x[q]; dsum[q] = 0.f; }
 #pragma unroll
         for (int j = 0; j < 4 * Q; ++j)
-            if (j < M) {
+            if (FULL || j < M) {
                 const int jq = j >> 2, jl = j & 3, jo = 2 * jq * (jq + 1);
                 // pivot and the two substitution values of row j, from its owner
                 const float inv = __builtin_amdgcn_rsqf(quad_bcast(P[jo + j].x + delta - dsum[jq], jl));
@@ -252,10 +261,14 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
     }
 }
 
-template __global__ void k_mvdr_solve<1>(MvdrSolveArgs);
-template __global__ void k_mvdr_solve<2>(MvdrSolveArgs);
-template __global__ void k_mvdr_solve<3>(MvdrSolveArgs);
-template __global__ void k_mvdr_solve<4>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<1, false>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<2, false>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<3, false>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<4, false>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<1, true>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<2, true>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<3, true>(MvdrSolveArgs);
+template __global__ void k_mvdr_solve<4, true>(MvdrSolveArgs);
 
 // --------------------------------------------------------------------------------------
 // k_mvdr_synth: grid (runs of ft frames, streams), 256 threads, LDS = (H + 1) float2 + H floats.

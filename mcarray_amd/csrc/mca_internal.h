@@ -224,14 +224,17 @@ struct MvdrAnalyseArgs {
     const float2 *tw;         // [N/2]
     const float *doa_rad;     // [streams][n_frames]
     float2 *X;                // [streams][n_frames][K][M] one-sided spectra, microphone fastest
-    double *cdoa;             // [streams][n_frames] cos(DOA + pi/2) (Beamformer.cpp:59), evaluated in double
+    // steering phasors of every (stream, frame, microphone), factored: d_m[k] = T[k >> 5] * T[nhi + (k & 31)] with
+    // T[i < nhi] = exp(-j 2 pi 32 i u), T[nhi + i] = exp(-j 2 pi i u), u = fs/N/c x_m cos(DOA + pi/2) (Beamformer.cpp:59);
+    // the phase is reduced in double.  N/64 + 33 sincos per microphone and frame instead of N/2 + 1.
+    float2 *T;                // [streams][n_frames][M][nhi + 32], nhi = N/64 + 1
+    const double *mic_x;      // [M]
+    double unit;              // fs / N / 346.1
 };
 
 struct MvdrSolveArgs {
     const float2 *X;          // [streams][n_frames][K][M]
-    const double *cdoa;       // [streams][n_frames]
-    const double *mic_x;      // [M] x coordinates (Beamformer.cpp:59 uses x only)
-    double unit;              // fs / N / 346.1
+    const float2 *T;          // [streams][n_frames][M][nhi + 32] factored steering phasors (MvdrAnalyseArgs)
     int n_streams, n_frames, K, M;
     float alpha, one_minus_alpha, loading_over_m;
     float2 *phi;              // [streams][K][M(M+1)/2] lower triangle of the covariance, row-major
