@@ -68,6 +68,24 @@ def cpu_baseline(pcm_host, n_frames):
     return n_frames / dt, dt, r
 
 
+def _cpu_worker(args):
+    pcm, n_frames = args
+    return cpu_baseline(pcm, n_frames)[:2]
+
+
+def cpu_baseline_all_cores(pcm_host_arrays, n_frames):
+    """The same oracle on every host core at once: one independent array per process (arrays never interact),
+    frames of all processes / wall time of the slowest ("all host cores ... state the core count")."""
+    import multiprocessing as mp
+    cores = len(pcm_host_arrays)
+    ctx = mp.get_context("fork")            # the children only run the C oracle on numpy arrays: nothing touches the GPU
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(pcm_host_arrays[i], n_frames) for i in range(cores)])
+    dt = time.perf_counter() - t0
+    return cores * n_frames / dt, dt, cores
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +95,7 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="STFT frames per array per step")
     ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "fp16x3"))
     ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of array 0 timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle on all host cores, one array per process (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,6 +214,15 @@ def main():
             cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "array 0, first %d frames of the same input, %.1f s, double-precision scalar C restatement "
                              "(oracle/mca_oracle.c, -O3); GPU/oracle DOA-bin mismatches on the sample: %d" % (nf, dt, mism)}
+            if args.cpu_all_cores:
+                # the reference is single threaded (faithful baseline above); this is what its host could do with one
+                # independent array per core
+                nfa = min(nf, 2048)
+                ncpu = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores whatever nproc says
+                host = [pcm[i % A].cpu().numpy() for i in range(ncpu)]
+                fps_all, dt_all, cores = cpu_baseline_all_cores(host, nfa)
+                cpu["all_cores"] = {"value": fps_all, "unit": "frames/s", "cores": cores,
+                                    "sample": "one array per process, %d frames each, %.1f s wall" % (nfa, dt_all)}
         line = {
             "metric": "STFT frames/sec, 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum beamform @48kHz/1024-pt",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
