@@ -9,6 +9,8 @@
 #include <memory>
 #include <vector>
 
+#include "mcadefs.h"
+
 #include "HipContext.h"
 #include "SoundLocalisationImpl.h"
 #include "microhponeArrayHelpers.h"
@@ -62,6 +64,20 @@ public:
         return F;
     }
     const std::vector<int> &lastArgmax() const { return _lastArgmax; }
+
+    // the SignalVector / SignalVector16s overloads the reference's callers use (test_mcarray.cpp:618; mcadefs.h:86-88)
+    int process(const SignalVector &in, int nSamples)
+    {
+        std::vector<const BaseType *> pi;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        return process(pi, nSamples);
+    }
+    int process(const SignalVector16s &in, int nSamples)
+    {
+        std::vector<const BaseType16s *> pi;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        return process(pi, nSamples);
+    }
 
 private:
     static constexpr float _frameRate = 0.075f;      // BinauralLocalisation.h:196

@@ -89,6 +89,22 @@ public:
         return F * hop;
     }
 
+    // the SignalVector / SignalVector16s overloads the reference's callers use (test_mcarray.cpp:869,937; mcadefs.h:86-88)
+    int process(const SignalVector &in, int nSamples, SignalVector &out, int outSize)
+    {
+        std::vector<const BaseType *> pi; std::vector<BaseType *> po;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        for (size_t c = 0; c < out.size(); ++c) po.push_back(out[c].get());
+        return process(pi, nSamples, po, outSize);
+    }
+    int process(const SignalVector16s &in, int nSamples, SignalVector16s &out, int outSize)
+    {
+        std::vector<const BaseType16s *> pi; std::vector<BaseType16s *> po;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        for (size_t c = 0; c < out.size(); ++c) po.push_back(out[c].get());
+        return process(pi, nSamples, po, outSize);
+    }
+
 private:
     void check(int rc) const { if (rc != MCA_HIP_OK) throw MCArrayException(std::string("libmcarray_hip: ") + mca_hip_mask_last_error(_ctx)); }
     static constexpr float _frameRate = 0.050f;      // FastBinauralMasking.h:112

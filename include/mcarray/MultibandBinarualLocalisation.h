@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include "mcadefs.h"
+
 #include "../mcarray_hip.h"
 #include "SoundLocalisationImpl.h"
 #include "microhponeArrayHelpers.h"
@@ -76,6 +78,20 @@ public:
         }
         for (int c = 0; c < 2; ++c) _pending[c].erase(_pending[c].begin(), _pending[c].begin() + static_cast<long>(F) * hop);
         return F;
+    }
+
+    // the SignalVector / SignalVector16s overloads the reference's callers use (test_mcarray.cpp:618; mcadefs.h:86-88)
+    int process(const SignalVector &in, int nSamples)
+    {
+        std::vector<const BaseType *> pi;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        return process(pi, nSamples);
+    }
+    int process(const SignalVector16s &in, int nSamples)
+    {
+        std::vector<const BaseType16s *> pi;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        return process(pi, nSamples);
     }
 
 private:

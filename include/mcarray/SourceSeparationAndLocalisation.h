@@ -19,6 +19,8 @@
 #include <type_traits>
 #include <vector>
 
+#include "mcadefs.h"
+
 #include "BeamformingSeparationAndLocalistaion.h"
 
 namespace mca {
@@ -119,6 +121,22 @@ public:
         return F * hop;
     }
     const std::vector<int> &lastDoaBins() const { return _lastBins; }
+
+    // the SignalVector / SignalVector16s overloads the reference's callers use (test_mcarray.cpp:869,937; mcadefs.h:86-88)
+    int process(const SignalVector &in, int nSamples, SignalVector &out, int outSize)
+    {
+        std::vector<const BaseType *> pi; std::vector<BaseType *> po;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        for (size_t c = 0; c < out.size(); ++c) po.push_back(out[c].get());
+        return process(pi, nSamples, po, outSize);
+    }
+    int process(const SignalVector16s &in, int nSamples, SignalVector16s &out, int outSize)
+    {
+        std::vector<const BaseType16s *> pi; std::vector<BaseType16s *> po;
+        for (size_t c = 0; c < in.size(); ++c) pi.push_back(in[c].get());
+        for (size_t c = 0; c < out.size(); ++c) po.push_back(out[c].get());
+        return process(pi, nSamples, po, outSize);
+    }
 
 private:
     static constexpr float _frameRate = 0.025f;     // SourceSeparationAndLocalisation.h:60

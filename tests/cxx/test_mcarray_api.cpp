@@ -343,6 +343,35 @@ static void testMvdrBeamformer()
     EXPECT(gain > 10.0);
 }
 
+static void testSignalVectorOverloads()
+{
+    // process(SignalVector16s&, n, SignalVector16s&, outSize) (the 16-bit path: shorts go to the GPU as they are) gives the DOAs of
+    // process(std::vector<double*>&, ...) on the same samples
+    const int fs = 48000, n = 9 * 512;
+    const std::vector<double> xs = {0, 0.07, 0.175, 0.21};
+    ArrayDescription mics = ArrayDescription::make_linear_array_description(xs);
+    std::vector<std::vector<double> > ch;
+    make_source(xs, 25.0 * M_PI / 180, fs, n, 5u, ch);
+    SignalVector16s in16, out16;
+    std::vector<std::vector<double> > chd(xs.size(), std::vector<double>(n));
+    std::vector<double *> ind, outd;
+    std::vector<std::vector<double> > od(xs.size(), std::vector<double>(n));
+    for (size_t c = 0; c < xs.size(); ++c) {
+        SignalPtr16s p(new BaseType16s[n]), q(new BaseType16s[n]);
+        for (int i = 0; i < n; ++i) { p[i] = static_cast<BaseType16s>(std::lround(ch[c][i] * 8000.0)); chd[c][i] = p[i]; }
+        in16.push_back(p); out16.push_back(q);
+        ind.push_back(chd[c].data()); outd.push_back(od[c].data());
+    }
+    SourceSeparationAndLocalisation a(fs, mics, 1, false), b(fs, mics, 1, false);
+    const int wa = a.process(in16, n, out16, n), wb = b.process(ind, n, outd, n);
+    EXPECT(wa == wb && wa == 8 * 512);
+    EXPECT(a.lastDoaBins() == b.lastDoaBins());
+    double worst = 0;
+    for (int i = 0; i < wa; ++i) worst = std::fmax(worst, std::fabs(static_cast<double>(out16[0][i]) - od[0][i]));
+    EXPECT(worst <= 1.0);                       // the 16-bit output is the double output rounded toward zero
+    std::printf("SignalVector16s overload: %d samples, DOA bins equal, |int16 out - double out| <= %.2f\n", wa, worst);
+}
+
 int main(int argc, char **argv)
 {
     const bool cpu_only = argc > 1 && std::string(argv[1]) == "--cpu";
@@ -358,6 +387,7 @@ int main(int argc, char **argv)
             testSourceLocalisation();
             testMultibandBinauralLocalisation();
             testMvdrBeamformer();
+            testSignalVectorOverloads();
         } catch (const MCArrayException &e) {
             std::printf("FAIL: MCArrayException: %s\n", e.what());
             ++g_fail;
