@@ -36,6 +36,10 @@ public:
     }
     int getFrameSize() const { return 1 << (_order - 1); }
     int getWindowSize() const { return 1 << _order; }
+    int getAnalysisLength() const { return (1 << _order) + 2; }
+    int getOneSidedFFTLength() const { return (1 << (_order - 1)) + 1; }
+    int getMaxLatency() const { return 1 << _order; }
+    int getNumberOfChannels() const { return 2; }
 
     // chunked PCM in (2 channels); fires the callback once per completed frame: setDOA(degrees, prob, power, 1) (:521)
     template <typename Tin> int process(const std::vector<Tin *> &in, int nSamples)

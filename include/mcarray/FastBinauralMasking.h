@@ -50,6 +50,7 @@ public:
     int getWindowSize() const { return 1 << _order; }
     int getAnalysisLength() const { return (1 << _order) + 2; }
     int getFrameSize() const { return 1 << (_order - 1); }
+    int getOneSidedFFTLength() const { return (1 << (_order - 1)) + 1; }     // _oneSidedFFTLength (FastBinauralMasking.cpp:93)
     int getMaxLatency() const { return 1 << _order; }
     int getNumberOfChannels() const { return 2; }
     int getNonMaskingAngle() { return 10; }                               // _phi in degrees (.h:99,113)

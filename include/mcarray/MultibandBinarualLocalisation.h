@@ -54,6 +54,10 @@ public:
     }
     int getFrameSize() const { return 1 << (_order - 1); }
     int getWindowSize() const { return 1 << _order; }
+    int getAnalysisLength() const { return (1 << _order) + 2; }
+    int getOneSidedFFTLength() const { return (1 << (_order - 1)) + 1; }
+    int getMaxLatency() const { return 1 << _order; }
+    int getNumberOfChannels() const { return 2; }
     int getNumberOfBins() const { return _nbins; }
 
     // chunked PCM in (2 channels); fires setDOA(degrees, prob, power, 1) once per frame that passes the gate (:225-248).

@@ -41,6 +41,8 @@ public:
         return order < 8 ? 8 : (order > 14 ? 14 : order);
     }
     int getWindowSize() const { return 1 << _order; }
+    int getOneSidedFFTLength() const { return (1 << (_order - 1)) + 1; }
+    int getMaxLatency() const { return 1 << _order; }
     int getAnalysisLength() const { return (1 << _order) + 2; }
     int getFrameSize() const { return 1 << (_order - 1); }
     int getNumberOfChannels() const { return _nchannels; }
