@@ -243,6 +243,11 @@ int mca_hip_mask_frames_host(mca_hip_mask_ctx *ctx, const float *pcm, int n_stre
                              int *decisions);
 /* the DSPONE hook itself: one frame, left/right CCS double[N+2] modified in place (:199-200), double on the GPU */
 int mca_hip_mask_process_frame(mca_hip_mask_ctx *ctx, double *left, double *right, int ccs_len, int *decisions);
+/* checkpoint / resume as mca_hip_state_*: the short-time powers Q and noise estimates of every stream, the overlap-add
+ * tails, the frame counters (and the state of the frame hook) */
+long long mca_hip_mask_state_size(const mca_hip_mask_ctx *ctx);
+int mca_hip_mask_state_save(mca_hip_mask_ctx *ctx, void *blob, long long blob_bytes);
+int mca_hip_mask_state_load(mca_hip_mask_ctx *ctx, const void *blob, long long blob_bytes);
 
 /* ---- MultibandBinarualLocalisation (2 microphones) ---------------------------
  * Replaces mca::MultibandBinarualLocalisation(int sampleRate, ArrayDescription, int nbins = 15, bool usePowerFloor = 1)
@@ -277,6 +282,10 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *ctx, const float *pcm_dev, long long a
                           float *power_dev, int *band_idx_dev, float *energy_in_doa_dev, float *band_corr_dev, void *stream);
 int mca_hip_mb_frames_host(mca_hip_mb_ctx *ctx, const float *pcm, int n_arrays, int n_frames, float *doa_rad, float *prob,
                            unsigned char *voiced, float *power, int *band_idx, float *energy_in_doa, float *band_corr);
+/* checkpoint / resume as mca_hip_state_*: smoothed band correlations, power-floor estimation, _currentDOA / _prob of every array */
+long long mca_hip_mb_state_size(const mca_hip_mb_ctx *ctx);
+int mca_hip_mb_state_save(mca_hip_mb_ctx *ctx, void *blob, long long blob_bytes);
+int mca_hip_mb_state_load(mca_hip_mb_ctx *ctx, const void *blob, long long blob_bytes);
 
 /* ---- MVDR-style beamformer with a per-bin spatial covariance (BASELINE.json configs[3]) ---------
  * [BUILD-DEFINES -- NO REFERENCE COUNTERPART]: the reference's only beamformer is the delay-and-sum of
@@ -316,6 +325,10 @@ int mca_hip_mvdr_frames_host(mca_hip_mvdr_ctx *ctx, const float *pcm, int n_stre
                              float *out_pcm, float *out_spec);
 /* copy of the covariance of one stream: out[N/2+1][M][M] interleaved re,im double (full Hermitian matrices) */
 int mca_hip_mvdr_get_covariance(mca_hip_mvdr_ctx *ctx, int stream_index, double *out);
+/* checkpoint / resume as mca_hip_state_*: the covariances, their traces and the overlap-add tails of every stream */
+long long mca_hip_mvdr_state_size(const mca_hip_mvdr_ctx *ctx);
+int mca_hip_mvdr_state_save(mca_hip_mvdr_ctx *ctx, void *blob, long long blob_bytes);
+int mca_hip_mvdr_state_load(mca_hip_mvdr_ctx *ctx, const void *blob, long long blob_bytes);
 /* per-kernel timing as mca_hip_set_timing / mca_hip_get_timing: kernel_id 0 = analysis, 1 = solve, 2 = synthesis */
 int mca_hip_mvdr_set_timing(mca_hip_mvdr_ctx *ctx, int enable);
 int mca_hip_mvdr_get_timing(mca_hip_mvdr_ctx *ctx, int kernel_id, int *launches, double *total_ms);

@@ -147,6 +147,15 @@ SYMBOLS = [
     ("mca_hip_mvdr_get_covariance", C.c_int, [C.c_void_p, C.c_int, c_dp]),
     ("mca_hip_mvdr_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("mca_hip_mvdr_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
+    ("mca_hip_mask_state_size", C.c_longlong, [C.c_void_p]),
+    ("mca_hip_mask_state_save", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    ("mca_hip_mask_state_load", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    ("mca_hip_mb_state_size", C.c_longlong, [C.c_void_p]),
+    ("mca_hip_mb_state_save", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    ("mca_hip_mb_state_load", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    ("mca_hip_mvdr_state_size", C.c_longlong, [C.c_void_p]),
+    ("mca_hip_mvdr_state_save", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    ("mca_hip_mvdr_state_load", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
     ("mca_hip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("mca_hip_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
     ("mca_hip_reset_timing", C.c_int, [C.c_void_p]),

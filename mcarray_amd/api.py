@@ -366,7 +366,24 @@ class FreqGCCBinauralLocalisation:
         return r
 
 
-class MultibandBinarualLocalisation:
+class _StateBlob:
+    """state_save() / state_load() over mca_hip_<module>_state_* (checkpoint / resume of everything the module carries between calls)."""
+    _STATE = None    # module infix of the C entry points
+
+    def state_save(self):
+        size = getattr(self._lib, "mca_hip_%s_state_size" % self._STATE)(self.h)
+        if size < 0:
+            self._check(int(size))
+        blob = C.create_string_buffer(int(size))
+        self._check(getattr(self._lib, "mca_hip_%s_state_save" % self._STATE)(self.h, blob, size))
+        return blob.raw
+
+    def state_load(self, blob):
+        self._check(getattr(self._lib, "mca_hip_%s_state_load" % self._STATE)(self.h, blob, len(blob)))
+
+
+class MultibandBinarualLocalisation(_StateBlob):
+    _STATE = "mb"
     """mca::MultibandBinarualLocalisation(int sampleRate, ArrayDescription, int nbins = 15, bool usePowerFloor = 1)
     (MultibandBinarualLocalisation.h:38): per sub-band GCC-PHAT + energy-weighted DOA histogram over whole buffers."""
 
@@ -450,7 +467,8 @@ class MultibandBinarualLocalisation:
         return dict(doa=doa, prob=prob, voiced=voiced, power=power, band_idx=bi, energy_in_doa=eid, band_corr=bc)
 
 
-class MvdrBeamformer:
+class MvdrBeamformer(_StateBlob):
+    _STATE = "mvdr"
     """Frequency-domain beamformer with a per-bin spatial covariance (BASELINE.json configs[3]; SURVEY A.9).
     No reference counterpart: the interface follows mca::Beamformer (Beamformer.h:39,49: frames in, one channel out,
     a look direction in radians) with the delay-and-sum weights replaced by MVDR weights."""
@@ -537,7 +555,8 @@ FACTOR, RELATIVE, FULL, NOISY, NOTHING = 0, 1, 3, 4, 5      # BinauralMasking::M
 BOTH, SPATIAL, TEMPORAL = 0, 1, 2                           # BinauralMasking::MaskingAlg (ArrayModules.h:89)
 
 
-class FastBinauralMasking:
+class FastBinauralMasking(_StateBlob):
+    _STATE = "mask"
     """mca::FastBinauralMasking(int samplerate, double microDistance, float lowFreq, float highFreq,
     MaskingMethod = RELATIVE, MaskingAlg = BOTH) (FastBinauralMasking.h:71-76)."""
 

@@ -5,6 +5,7 @@
 #include "fft512.h"
 #include "kernels.h"
 #include "stage.h"
+#include "state_blob.h"
 
 #include <algorithm>
 #include <cmath>
@@ -275,6 +276,51 @@ int mca_hip_mask_frames_host(mca_hip_mask_ctx *c, const float *pcm, int n_stream
     MHIP_TRY(c, hipDeviceSynchronize());
     MHIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
     if (decisions) MHIP_TRY(c, hipMemcpy(decisions, d_dec, n_dec * 4, hipMemcpyDeviceToHost));
+    return MCA_HIP_OK;
+}
+
+extern "C++" {
+namespace {
+constexpr unsigned MASK_MAGIC = 0x4d434d4bu;   // "MCMK"
+std::vector<BlobPart> mask_parts(mca_hip_mask_ctx *c)
+{
+    const size_t ns = (size_t)c->cfg.max_streams;
+    return {{c->d_Q[c->q_cur], ns * 45 * 4}, {c->d_noise, ns * 45 * 4}, {c->d_tail[c->tail_cur], ns * 2 * c->hop * 4},
+            {c->d_Q64, 45 * 8}, {c->d_noise64, 45 * 8}};
+}
+unsigned mask_cfg_hash(const mca_hip_mask_ctx *c)
+{
+    const int v[5] = {c->N, c->cfg.sample_rate, c->cfg.method, c->cfg.algorithm, c->cfg.max_streams};
+    unsigned h = blob_fnv(v, sizeof(v));
+    h = blob_fnv(&c->cfg.micro_distance, sizeof(double), h);
+    h = blob_fnv(&c->cfg.low_freq, sizeof(float), h);
+    return blob_fnv(&c->cfg.high_freq, sizeof(float), h);
+}
+}  // namespace
+}  // extern "C++"
+
+long long mca_hip_mask_state_size(const mca_hip_mask_ctx *c)
+{
+    return c ? blob_size(mask_parts(const_cast<mca_hip_mask_ctx *>(c))) : (long long)MCA_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int mca_hip_mask_state_save(mca_hip_mask_ctx *c, void *blob, long long bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    MHIP_TRY(c, hipSetDevice(c->cfg.device));
+    BlobHeader h{MASK_MAGIC, 1, mask_cfg_hash(c), 0, {c->frames_done, (long long)c->first_call, 0, 0}};
+    const int rc = blob_save(mask_parts(c), h, blob, bytes);
+    return rc ? mfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc)) : MCA_HIP_OK;
+}
+
+int mca_hip_mask_state_load(mca_hip_mask_ctx *c, const void *blob, long long bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    MHIP_TRY(c, hipSetDevice(c->cfg.device));
+    BlobHeader h;
+    const int rc = blob_load(mask_parts(c), MASK_MAGIC, mask_cfg_hash(c), blob, bytes, &h);
+    if (rc) return mfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc));
+    c->frames_done = h.host[0]; c->first_call = (int)h.host[1];
     return MCA_HIP_OK;
 }
 

@@ -5,6 +5,7 @@
 #include "fft512.h"
 #include "kernels.h"
 #include "stage.h"
+#include "state_blob.h"
 
 #include <cmath>
 #include <cstring>
@@ -269,6 +270,45 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *c, const float *pcm, long long array_s
     BHIP_TRY(c, hipGetLastError());
     c->corr_cur ^= 1;
     return MCA_HIP_OK;
+}
+
+extern "C++" {
+namespace {
+constexpr unsigned MB_MAGIC = 0x4d434d42u;     // "MCMB"
+std::vector<BlobPart> mb_parts(mca_hip_mb_ctx *c)
+{
+    const size_t na = (size_t)c->cfg.max_arrays;
+    return {{c->d_corr[c->corr_cur], na * c->nb * c->D * 4}, {c->d_gate, na * 4 * 8}, {c->d_cur, na * 2 * 4}};
+}
+unsigned mb_cfg_hash(const mca_hip_mb_ctx *c)
+{
+    const int v[6] = {c->N, c->nb, c->D, c->cfg.max_arrays, c->cfg.sample_rate, c->cfg.use_power_floor};
+    return blob_fnv(c->delays.data(), c->delays.size() * sizeof(float), blob_fnv(v, sizeof(v)));
+}
+}  // namespace
+}  // extern "C++"
+
+long long mca_hip_mb_state_size(const mca_hip_mb_ctx *c)
+{
+    return c ? blob_size(mb_parts(const_cast<mca_hip_mb_ctx *>(c))) : (long long)MCA_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int mca_hip_mb_state_save(mca_hip_mb_ctx *c, void *blob, long long bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    BHIP_TRY(c, hipSetDevice(c->cfg.device));
+    BlobHeader h{MB_MAGIC, 1, mb_cfg_hash(c), 0, {0, 0, 0, 0}};
+    const int rc = blob_save(mb_parts(c), h, blob, bytes);
+    return rc ? bfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc)) : MCA_HIP_OK;
+}
+
+int mca_hip_mb_state_load(mca_hip_mb_ctx *c, const void *blob, long long bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    BHIP_TRY(c, hipSetDevice(c->cfg.device));
+    BlobHeader h;
+    const int rc = blob_load(mb_parts(c), MB_MAGIC, mb_cfg_hash(c), blob, bytes, &h);
+    return rc ? bfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc)) : MCA_HIP_OK;
 }
 
 int mca_hip_mb_frames_host(mca_hip_mb_ctx *c, const float *pcm, int n_arrays, int n_frames, float *doa_rad, float *prob,

@@ -6,6 +6,7 @@
 #include "fft512.h"
 #include "kernels.h"
 #include "stage.h"
+#include "state_blob.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -312,6 +313,47 @@ int mca_hip_mvdr_get_covariance(mca_hip_mvdr_ctx *c, int s, double *out)
                 up[0] = v.x; up[1] = i == j ? 0.0 : -(double)v.y;
             }
     return MCA_HIP_OK;
+}
+
+extern "C++" {
+namespace {
+constexpr unsigned MVDR_MAGIC = 0x4d435644u;   // "MCVD"
+std::vector<BlobPart> mvdr_parts(mca_hip_mvdr_ctx *c)
+{
+    const size_t ns = (size_t)c->cfg.max_streams;
+    return {{c->d_phi, ns * c->K * c->tri * sizeof(float2)}, {c->d_trace, ns * c->K * 4}, {c->d_tail[c->tail_cur], ns * c->H * 4}};
+}
+unsigned mvdr_cfg_hash(const mca_hip_mvdr_ctx *c)
+{
+    const int v[5] = {c->N, c->M, c->cfg.max_streams, c->cfg.sample_rate, 0};
+    unsigned h = blob_fnv(v, sizeof(v));
+    h = blob_fnv(&c->cfg.alpha, sizeof(double), h);
+    return blob_fnv(&c->cfg.loading, sizeof(double), h);
+}
+}  // namespace
+}  // extern "C++"
+
+long long mca_hip_mvdr_state_size(const mca_hip_mvdr_ctx *c)
+{
+    return c ? blob_size(mvdr_parts(const_cast<mca_hip_mvdr_ctx *>(c))) : (long long)MCA_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int mca_hip_mvdr_state_save(mca_hip_mvdr_ctx *c, void *blob, long long bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    VHIP_TRY(c, hipSetDevice(c->cfg.device));
+    BlobHeader h{MVDR_MAGIC, 1, mvdr_cfg_hash(c), 0, {0, 0, 0, 0}};
+    const int rc = blob_save(mvdr_parts(c), h, blob, bytes);
+    return rc ? vfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc)) : MCA_HIP_OK;
+}
+
+int mca_hip_mvdr_state_load(mca_hip_mvdr_ctx *c, const void *blob, long long bytes)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    VHIP_TRY(c, hipSetDevice(c->cfg.device));
+    BlobHeader h;
+    const int rc = blob_load(mvdr_parts(c), MVDR_MAGIC, mvdr_cfg_hash(c), blob, bytes, &h);
+    return rc ? vfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc)) : MCA_HIP_OK;
 }
 
 int mca_hip_mvdr_set_timing(mca_hip_mvdr_ctx *c, int enable)

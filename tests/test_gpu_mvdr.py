@@ -176,3 +176,50 @@ def test_mvdr_rejects_bad_configurations():
     bf = api.MvdrBeamformer(48000, synth.ULA8, 1024, max_streams=1)
     with pytest.raises(api.MCArrayHipError):
         bf.process(np.zeros((2, 8, 1024), dtype=np.float32), 0.0)      # more streams than the context holds
+
+
+def test_module_state_blobs_resume_streams():
+    """mca_hip_{mvdr,mask,mb}_state_save/_load: a second context of the same configuration continues a stream bit for bit;
+    a context of another configuration refuses the blob."""
+    fs, N, F = 16000, 512, 40
+    hop = N // 2
+    # MVDR
+    xs = synth.REEM_C
+    pcm = _scene(xs, fs, N, F, 0)[None]
+    a = api.MvdrBeamformer(fs, xs, N)
+    one = a.process(pcm, 0.2)["out"]
+    b, c = api.MvdrBeamformer(fs, xs, N), api.MvdrBeamformer(fs, xs, N)
+    first = b.process(pcm[:, :, :(15 + 1) * hop], 0.2)["out"]
+    c.state_load(b.state_save())
+    rest = c.process(pcm[:, :, 15 * hop:], 0.2)["out"]
+    assert np.array_equal(np.concatenate([first, rest], axis=1), one)
+    with pytest.raises(api.MCArrayHipError):
+        api.MvdrBeamformer(fs, xs, N, alpha=0.9).state_load(b.state_save())
+    # masking (1024 = tuned kernel, 512 = any-length kernel)
+    for Nm in (1024, 512):
+        h2 = Nm // 2
+        rng = np.random.default_rng(Nm)
+        x2 = (rng.standard_normal((1, 2, (F + 1) * h2)) * 0.1).astype(np.float32)
+        x2[0, 1] = np.roll(x2[0, 0], 1)
+        m1 = api.FastBinauralMasking(fs, 0.086, 300.0, 5000.0, api.RELATIVE, api.BOTH, fft_size=Nm)
+        o1, d1 = m1.process(x2)
+        m2, m3 = (api.FastBinauralMasking(fs, 0.086, 300.0, 5000.0, api.RELATIVE, api.BOTH, fft_size=Nm) for _ in range(2))
+        oa, da = m2.process(x2[:, :, :(15 + 1) * h2])
+        m3.state_load(m2.state_save())
+        ob, db = m3.process(x2[:, :, 15 * h2:])
+        assert np.array_equal(np.concatenate([da, db], axis=1), d1)
+        assert np.abs(np.concatenate([oa, ob], axis=2) - o1).max() <= 1e-6 * np.abs(o1).max()
+        with pytest.raises(api.MCArrayHipError):
+            api.FastBinauralMasking(fs, 0.086, 300.0, 5000.0, api.FULL, api.BOTH, fft_size=Nm).state_load(m2.state_save())
+    # multiband localiser
+    xb = synth.noise_source_stream(synth.BINAURAL, 0.5, 48000, (F + 1) * 512, 9)[None]
+    l1 = api.MultibandBinarualLocalisation(48000, synth.BINAURAL, 15, False)
+    r1 = l1.process(xb)
+    l2, l3 = (api.MultibandBinarualLocalisation(48000, synth.BINAURAL, 15, False) for _ in range(2))
+    ra = l2.process(xb[:, :, :(15 + 1) * 512])
+    l3.state_load(l2.state_save())
+    rb = l3.process(xb[:, :, 15 * 512:])
+    assert np.array_equal(np.concatenate([ra["doa"], rb["doa"]], axis=1), r1["doa"])
+    assert np.array_equal(np.concatenate([ra["prob"], rb["prob"]], axis=1), r1["prob"])
+    with pytest.raises(api.MCArrayHipError):
+        api.MultibandBinarualLocalisation(48000, synth.BINAURAL, 12, False).state_load(l2.state_save())
