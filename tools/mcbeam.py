@@ -59,9 +59,11 @@ def main():
     if a.binaural:
         if x.shape[0] != 2 or len(xs) != 2:
             raise SystemExit("--binaural needs a 2-channel file and two microphone positions")
-        loc = api.FreqGCCBinauralLocalisation(fs, xs, False, 3.0 if a.step == 5.0 else a.step)
+        loc = api.FreqGCCBinauralLocalisation(fs, xs, a.power_floor, 3.0 if a.step == 5.0 else a.step)
         r = loc.process(x)
         for t in range(F):
+            if "voiced" in r and not r["voiced"][0, t]:
+                continue                                   # gated out: the reference reports nothing for the frame
             out.write("%d %.3f %.4f\n" % (t, np.rad2deg(r["doa"][0, t]), r["prob"][0, t]))
         return
     if x.shape[0] != len(xs):
