@@ -30,6 +30,7 @@ struct mca_hip_ctx {
     std::vector<double> xyz;
     int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, H = 0, logH = 0, Kp = 0, S = 1, prec = 0;
     bool ula = false, stream_ok = false, generic = false, force_v1 = false;
+    bool n512 = false;             // 512-sample frames with <= 8 microphones: k_stft_phat_512 / k_beamform_512 instead of the any-length kernels
     std::string stream_why;       // why the stream API is unavailable for this configuration
     int v2_min_rows = 32768;
     float step = 0.f;
@@ -416,6 +417,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
             c->stream_ok = false; c->stream_why = "fft_size x n_mics exceeds the 160 KiB LDS of a CU in the stream API (use the frame API)";
         }
     }
+    c->n512 = c->N == 512 && c->M <= 8 && c->stream_ok && std::getenv("MCA_HIP_NO_N512") == nullptr;
     c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switches for measurements
     if (std::getenv("MCA_HIP_V2_MIN_ROWS")) c->v2_min_rows = std::atoi(std::getenv("MCA_HIP_V2_MIN_ROWS"));
 
@@ -631,7 +633,28 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         sa.window = c->d_window; sa.A = c->d_A; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
-        if (c->generic) {
+        if (c->n512) {
+            // 512-sample frames: two frames of up to 8 channels per pass on the wave-level transform
+            sa.fpb = 8;
+            while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
+            const size_t smem5 = ((size_t)2 * 8 * 258 + 8 * FFT_SCRATCH + TW_WIN + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
+            dim3 g5((nf + sa.fpb - 1) / sa.fpb, n_arrays);
+#define L512(MT, U, T)                                                                                                    \
+            do {                                                                                                          \
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_512<MT, U, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5)); \
+                hipLaunchKernelGGL((k_stft_phat_512<MT, U, T>), g5, dim3(512), smem5, st, sa);                            \
+            } while (0)
+#define L512T(T)                                                                                                          \
+            do {                                                                                                          \
+                if (c->M == 8 && c->ula) L512(8, true, T); else if (c->M == 8) L512(8, false, T);                         \
+                else if (c->M == 4 && c->ula) L512(4, true, T); else if (c->M == 4) L512(4, false, T);                    \
+                else if (c->ula) L512(0, true, T); else L512(0, false, T);                                                \
+            } while (0)
+            if (c->prec == MCA_HIP_SRP_FP32) L512T(float); else L512T(_Float16);
+#undef L512T
+#undef L512
+            rc = MCA_HIP_OK;
+        } else if (c->generic) {
             const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2) + 16;
 #define GEN_LAUNCH(K)                                                                                                     \
             do {                                                                                                          \
@@ -772,6 +795,19 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     ba.window = c->d_window; ba.mic_x = c->d_micx; ba.doa_rad = doa_rad; ba.out = out_pcm;
     ba.tail_in = c->d_tail[c->tail_cur]; ba.tail_out = c->d_tail[c->tail_cur ^ 1];
     ba.N = c->N; ba.logH = c->logH; ba.tw = c->d_tw;
+    if (c->n512) {
+        const size_t smem = ((size_t)2 * 8 * 258 + 8 * FFT_SCRATCH + TW_WIN + (size_t)2 * c->S * c->M * 41) * sizeof(float2) + (size_t)2 * c->S * sizeof(double);
+        ba.ft = 64;
+        const long long per_cu = smem <= 80 * 1024 ? 2 : 1;
+        while (ba.ft > 4 && (long long)n_arrays * ((n_frames + ba.ft - 1) / ba.ft) < 256 * per_cu) ba.ft >>= 1;
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_beamform_512), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        time_begin(c, MCA_HIP_K_BEAMFORM, st);
+        hipLaunchKernelGGL(k_beamform_512, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(512), smem, st, ba);
+        time_end(c, st);
+        HIP_TRY(c, hipGetLastError());
+        c->tail_cur ^= 1;
+        return MCA_HIP_OK;
+    }
     if (c->generic) {
         const size_t smem = (size_t)(c->M + c->S) * (c->H + 1) * sizeof(float2) + (size_t)c->S * c->H * sizeof(float) + (size_t)(ba.ft + 1) * c->S * sizeof(double);
         if (smem > 64 * 1024)

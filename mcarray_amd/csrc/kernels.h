@@ -14,6 +14,8 @@ __global__ void k_gate(GateArgs p);
 __global__ void k_doa_fill(DoaFillArgs p);
 template <int CPW, int OCC> __global__ void k_beamform_ola(BeamformArgs p);
 template <typename OutT> __global__ void k_stft_phat_gen(StftPhatArgs p);
+template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat_512(StftPhatArgs p);
+__global__ void k_beamform_512(BeamformArgs p);
 __global__ void k_beamform_gen(BeamformArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);

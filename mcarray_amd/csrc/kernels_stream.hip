@@ -37,7 +37,7 @@ __device__ __forceinline__ float2 whiten(float2 z)
 
 // pair products of one bin.  x: whitened spectra of the bin, element m at x[m * xstride].
 template <int MT, bool ULA, bool WHITEN, typename OutT>
-__device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, OutT *arow, const StftPhatArgs &p, int k)
+__device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, OutT *arow, const StftPhatArgs &p, int k, int kg = KG)
 {
     if constexpr (MT > 0) {
         float2 r[MT];
@@ -52,25 +52,25 @@ __device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, 
 #pragma unroll
                 for (int j = i + 1; j < MT; ++j) acc[j - i - 1] = cmacc(acc[j - i - 1], r[i], r[j]);
 #pragma unroll
-            for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * KG + k, acc[g]);
+            for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * kg + k, acc[g]);
         } else {
             int pi = 0;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = i + 1; j < MT; ++j) { store_a(arow, p, pi * KG + k, cmulc(r[i], r[j])); ++pi; }
+                for (int j = i + 1; j < MT; ++j) { store_a(arow, p, pi * kg + k, cmulc(r[i], r[j])); ++pi; }
         }
     } else {
         if (ULA) {
             for (int g = 0; g < M - 1; ++g) {
                 float2 acc = make_float2(0.f, 0.f);
                 for (int i = 0; i + g + 1 < M; ++i) acc = cmacc(acc, x[i * xstride], x[(i + g + 1) * xstride]);
-                store_a(arow, p, g * KG + k, acc);
+                store_a(arow, p, g * kg + k, acc);
             }
         } else {
             int pi = 0;
             for (int i = 0; i < M; ++i)
-                for (int j = i + 1; j < M; ++j) { store_a(arow, p, pi * KG + k, cmulc(x[i * xstride], x[j * xstride])); ++pi; }
+                for (int j = i + 1; j < M; ++j) { store_a(arow, p, pi * kg + k, cmulc(x[i * xstride], x[j * xstride])); ++pi; }
         }
     }
 }
@@ -717,6 +717,266 @@ __global__ __launch_bounds__(512, OCC) void k_beamform_ola(BeamformArgs p)
 template __global__ void k_beamform_ola<1, 2>(BeamformArgs);
 template __global__ void k_beamform_ola<1, 4>(BeamformArgs);
 template __global__ void k_beamform_ola<2, 2>(BeamformArgs);
+
+// --------------------------------------------------------------------------------------
+// 512-sample frames (16 kHz at the reference's 0.025 s frame rate) on the wave-level FFT
+// --------------------------------------------------------------------------------------
+// A 512-point complex transform takes TWO real 512-sample sequences at once: z = a + j b,
+// A[k] = (Z[k] + conj Z[512-k]) / 2, B[k] = -j (Z[k] - conj Z[512-k]) / 2, k = 0..256.  So the transform of
+// fft512.h serves two channels (analysis) or two frames (synthesis) per wave pass, and a workgroup of 8 waves
+// analyses two frames of 8 channels at a time.  Spectra rows have N512_ROW float2 words.
+constexpr int N512_H = 256, N512_K = 257, N512_ROW = 258;
+
+// v[r] = (a[m], b[m]) * w[m] / 2, m = lane + 64 r.  On return specA[k], specB[k], k = 0..256.
+__device__ __forceinline__ void rfft512_pair(float2 (&v)[8], float2 *buf, float2 *specA, float2 *specB, int lane, const FftTw &tw)
+{
+    cfft512_regs<false>(v, buf, lane, tw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[lane + 64 * br3(i)] = v[i];
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        const float2 zk = buf[k], zp = buf[(512 - k) & 511];
+        const float2 d = make_float2(zk.x - zp.x, zk.y + zp.y);                 // Z[k] - conj Z[512-k]
+        specA[k] = make_float2(zk.x + zp.x, zk.y - zp.y);
+        specB[k] = make_float2(d.y, -d.x);                                      // -j d
+    }
+    if (lane == 0) {
+        const float2 z = buf[256];
+        specA[256] = make_float2(2.f * z.x, 0.f);
+        specB[256] = make_float2(2.f * z.y, 0.f);
+    }
+    wave_lds_fence();
+}
+
+// inverse of two one-sided spectra Ya, Yb (k = 0..256; imaginary parts of k = 0 and 256 ignored, like a CCS inverse):
+// on return v[i] = (ya[n], yb[n]), n = lane + 64 br3(i), scaled by 1/512.
+__device__ __forceinline__ void irfft512_pair(const float2 *Ya, const float2 *Yb, float2 *buf, float2 (&v)[8], int lane, const FftTw &tw)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        float2 a = Ya[k], b = Yb[k];
+        if (k == 0) { a.y = 0.f; b.y = 0.f; }
+        buf[k] = make_float2(a.x - b.y, a.y + b.x);                             // Ya + j Yb
+        if (k != 0) buf[512 - k] = make_float2(a.x + b.y, -a.y + b.x);          // conj Ya + j conj Yb
+    }
+    if (lane == 0) buf[256] = make_float2(Ya[256].x, Yb[256].x);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
+    wave_lds_fence();
+    cfft512_regs<true>(v, buf, lane, tw);
+    const float sc = 1.0f / 512.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = make_float2(v[i].x * sc, v[i].y * sc);
+}
+
+// windowed samples of channels c0, c0 + 1 (zeros beyond M) of the frame that starts at sample `start`
+__device__ __forceinline__ void load_pair_512(float2 (&v)[8], const float *base, long long mic_stride, int c0, int M, long long start,
+                                              const float (&wreg)[8], int lane)
+{
+    const float *pa = base + (long long)c0 * mic_stride + start, *pb = pa + mic_stride;
+    const bool hb = c0 + 1 < M;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float xa = pa[lane + 64 * r], xb = hb ? pb[lane + 64 * r] : 0.f;
+        v[r] = make_float2(xa * wreg[r], xb * wreg[r]);
+    }
+}
+
+// k_stft_phat_512: grid (ceil(frames / fpb), arrays), 512 threads, M <= 8.  Wave w analyses channels (2 (w & 3), + 1) of
+// frame slot w >> 2; then thread (slot = tid >> 8, bin = tid & 255) whitens and forms the pair products.
+// LDS: [2][8][N512_ROW] spectra + 8 wave scratches + twiddles + [fpb][M] Nyquist bins + [fpb] powers.
+template <int MT, bool ULA, typename OutT>
+__global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);                   // [2][8][N512_ROW]
+    float2 *scr = spec + 2 * 8 * N512_ROW;                                  // [8][FFT_SCRATCH]
+    float2 *tab = scr + 8 * FFT_SCRATCH;                                    // [TW_WIN]
+    float2 *nyq = tab + TW_WIN;                                             // [fpb][M]
+    const int M = MT > 0 ? MT : p.M;
+    float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);               // [fpb]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.y;
+    const int f_begin = blockIdx.x * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+    fft_table_init(tab, nullptr, tid, 512);
+    if (tid < p.fpb) spow[tid] = 0.f;
+    float wreg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wreg[r] = 0.5f * p.window[lane + 64 * r];
+    __syncthreads();
+    FftTw tw{tab};
+    const float *base = p.pcm + (long long)a * p.array_stride;
+    const int slot = wave >> 2, c0 = 2 * (wave & 3);
+
+    for (int f = f_begin; f < f_end; f += 2) {
+        const int nfr = min(2, f_end - f);
+        if (slot < nfr && c0 < M) {
+            float2 v[8];
+            load_pair_512(v, base, p.mic_stride, c0, M, (long long)(p.frame0 + f + slot) * N512_H, wreg, lane);
+            rfft512_pair(v, scr + wave * FFT_SCRATCH, spec + (slot * 8 + c0) * N512_ROW, spec + (slot * 8 + c0 + 1) * N512_ROW, lane, tw);
+        }
+        __syncthreads();
+        const int fi = tid >> 8, k = tid & 255;
+        if (fi < nfr) {
+            float2 *xs = spec + fi * 8 * N512_ROW;
+            OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f + fi) * (long long)p.a_row_elems;
+            if (k < M) nyq[(f + fi - f_begin) * M + k] = whiten(xs[k * N512_ROW + N512_H]);
+            if (p.power) {
+                // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
+                float acc = 0.f;
+                for (int m = 0; m < M; ++m) { const float2 z = xs[m * N512_ROW + k]; acc += z.x * z.x + z.y * z.y; }
+                acc *= k == 0 ? 1.f : 2.f;
+                if (k < M) { const float2 z = xs[k * N512_ROW + N512_H]; acc += z.x * z.x + z.y * z.y; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+                if (lane == 0) atomicAdd(&spow[f + fi - f_begin], acc);
+            }
+            if constexpr (MT == 0)
+                for (int m = 0; m < M; ++m) xs[m * N512_ROW + k] = whiten(xs[m * N512_ROW + k]);
+            pair_stage<MT, ULA, true, OutT>(xs + k, N512_ROW, M, arow, p, k, N512_K);
+        }
+        __syncthreads();
+    }
+    if (p.power && tid < f_end - f_begin)
+        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = spow[tid] / (512.f * 512.f) / (float)M;
+    if (tid < f_end - f_begin) {
+        OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
+        pair_stage<MT, ULA, false, OutT>(nyq + tid * M, 1, M, arow, p, N512_H, N512_K);
+    }
+}
+
+#define INST_512(MT, ULA, T) template __global__ void k_stft_phat_512<MT, ULA, T>(StftPhatArgs);
+INST_512(0, false, float) INST_512(0, true, float) INST_512(4, false, float) INST_512(4, true, float) INST_512(8, false, float) INST_512(8, true, float)
+INST_512(0, false, _Float16) INST_512(0, true, _Float16) INST_512(4, false, _Float16) INST_512(4, true, _Float16) INST_512(8, false, _Float16) INST_512(8, true, _Float16)
+
+// k_beamform_512: grid (runs of ft frames, arrays), 512 threads, M <= 8.  Frames are taken two at a time: the 8 waves analyse
+// them as in k_stft_phat_512 and thread (slot, bin) applies the delay-and-sum with phasors factored hi[k >> 5] * lo[k & 31]
+// (Beamformer.cpp:51-71; a slot's table is rebuilt only when its DOA differs from the one it was built for).  Then wave s
+// inverse-transforms the two beamformed frames of source s in ONE complex transform, and threads 0..255 overlap-add the
+// frames in order with the carry in a register.  A run starts one frame early (carry).
+__global__ __launch_bounds__(512) void k_beamform_512(BeamformArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = p.M, S = p.S, a = blockIdx.y;
+    constexpr int NPH = 41;                                                 // 9 hi (k >> 5 = 0..8) + 32 lo phasors
+    // frame pairs per synthesis round.  One: the beamformed spectra sit in scratches that the next pair's analysis reuses, and
+    // with two workgroups per CU the other workgroup fills the SIMDs while S waves run the inverse transforms.
+    constexpr int NPB = 1;
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);                   // [2][8][N512_ROW]
+    float2 *scr = spec + 2 * 8 * N512_ROW;                                  // [8][FFT_SCRATCH]
+    float2 *tab = scr + 8 * FFT_SCRATCH;                                    // [TW_WIN]
+    float2 *steer = tab + TW_WIN;                                           // [2][S][M][NPH]
+    double *built = reinterpret_cast<double *>(steer + 2 * S * M * NPH);    // [2][S] cos(DOA + pi/2) each slot's table was built for
+    // 80 KiB with one source and 8 channels (two workgroups per CU): the beamformed spectra live in the scratches of
+    // waves 4..7 (written after the analysis; the inverse transforms use those of waves 0..3) and the time-domain
+    // frames take the place of the channel spectra, which are dead by then
+    float2 *ys = scr + 4 * FFT_SCRATCH;                                     // [NPB][S][2][N512_ROW] beamformed spectra
+    float *yt = reinterpret_cast<float *>(spec);                            // [NPB][S][2][512] time-domain frames
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * p.ft, t1 = min(t0 + p.ft, p.n_frames);
+    const int tfirst = t0 > 0 ? t0 - 1 : 0;
+    fft_table_init(tab, nullptr, tid, 512);
+    if (tid < 2 * S) built[tid] = 2.0;                                      // no cosine: every table is built on first use
+    float wreg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wreg[r] = 0.5f * p.window[lane + 64 * r];
+    float carry[MCA_MAX_SOURCES];
+#pragma unroll
+    for (int s = 0; s < MCA_MAX_SOURCES; ++s) carry[s] = (s < S && t0 == 0 && tid < N512_H) ? p.tail_in[((long long)a * S + s) * N512_H + tid] : 0.f;
+    __syncthreads();
+    FftTw tw{tab};
+    const float *base = p.pcm + (long long)a * p.array_stride;
+    const double unit = (double)p.fs / 512.0 / 346.1;                       // Beamformer.cpp:59 without 2 pi
+    const float inv = 1.0f / (float)M;
+    const int slot = wave >> 2, c0 = 2 * (wave & 3);
+
+    for (int tb = tfirst; tb < t1; tb += 2 * NPB) {
+        const int npair = min(NPB, (t1 - tb + 1) / 2);
+        for (int pr = 0; pr < npair; ++pr) {
+            const int t = tb + 2 * pr, nfr = min(2, t1 - t);
+            // steering phasors of the two frames (slots), rebuilt when the source moved
+            for (int fs_ = 0; fs_ < nfr * S; ++fs_) {
+                const int fi = fs_ / S, s_ = fs_ - fi * S;
+                const double cd = cos((double)p.doa_rad[((long long)a * p.n_frames + t + fi) * S + s_] + 1.57079632679489661923);
+                if (cd != built[fi * S + s_]) {                             // uniform over the workgroup
+                    for (int e = tid; e < M * NPH; e += 512) {
+                        const int c = e / NPH, q = e - c * NPH;
+                        const int kk = q < 9 ? (q << 5) : q - 9;
+                        double turns = (double)kk * (unit * p.mic_x[c] * cd);
+                        turns -= rint(turns);
+                        float sn, cs;
+                        sincospif(2.0f * (float)turns, &sn, &cs);
+                        steer[(fi * S + s_) * M * NPH + e] = make_float2(cs, sn);
+                    }
+                    __syncthreads();
+                    if (tid == 0) built[fi * S + s_] = cd;
+                }
+            }
+            if (slot < nfr && c0 < M) {
+                float2 v[8];
+                load_pair_512(v, base, p.mic_stride, c0, M, (long long)(t + slot) * N512_H, wreg, lane);
+                rfft512_pair(v, scr + wave * FFT_SCRATCH, spec + (slot * 8 + c0) * N512_ROW, spec + (slot * 8 + c0 + 1) * N512_ROW, lane, tw);
+            }
+            __syncthreads();
+            // delay-and-sum: Y[k] = (1/M) sum_c X_c[k] exp(j k s_c)
+            {
+                const int fi = tid >> 8, k = tid & 255;
+                const float2 *xs = spec + fi * 8 * N512_ROW;
+                for (int s = 0; s < S; ++s) {
+                    float2 *yo = ys + ((pr * S + s) * 2 + fi) * N512_ROW;
+                    if (fi < nfr) {
+                        const float2 *st = steer + (fi * S + s) * M * NPH;
+                        float2 acc = make_float2(0.f, 0.f), accn = make_float2(0.f, 0.f);
+                        for (int c = 0; c < M; ++c) {
+                            acc = cmac(acc, xs[c * N512_ROW + k], cmul(st[c * NPH + (k >> 5)], st[c * NPH + 9 + (k & 31)]));
+                            if (k == 0) accn = cmac(accn, xs[c * N512_ROW + N512_H], st[c * NPH + 8]);  // k = 256 = 32 * 8 + 0
+                        }
+                        yo[k] = make_float2(acc.x * inv, acc.y * inv);                                  // divC :70
+                        if (k == 0) yo[N512_H] = make_float2(accn.x * inv, accn.y * inv);
+                    } else {                                                                            // no second frame: zeros
+                        yo[k] = make_float2(0.f, 0.f);
+                        if (k == 0) yo[N512_H] = make_float2(0.f, 0.f);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // synthesis: one complex inverse transform per (pair, source) gives both frames of the pair
+        if (wave < npair * S) {
+            float2 v[8];
+            irfft512_pair(ys + (wave * 2) * N512_ROW, ys + (wave * 2 + 1) * N512_ROW, scr + wave * FFT_SCRATCH, v, lane, tw);
+            float *ya = yt + (wave * 2) * 512, *yb = ya + 512;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int n = lane + 64 * br3(i); ya[n] = v[i].x; yb[n] = v[i].y; }
+        }
+        __syncthreads();
+        // overlap-add, hop samples per frame, frames in order
+        if (tid < N512_H) {
+            for (int pr = 0; pr < npair; ++pr)
+                for (int fi = 0; fi < 2; ++fi) {
+                    const int tt = tb + 2 * pr + fi;
+                    if (tt >= t1) break;
+#pragma unroll
+                    for (int s = 0; s < MCA_MAX_SOURCES; ++s)
+                        if (s < S) {
+                            const float *y = yt + ((pr * S + s) * 2 + fi) * 512;
+                            if (tt >= t0) p.out[((long long)a * S + s) * (long long)p.n_frames * N512_H + (long long)tt * N512_H + tid] = carry[s] + y[tid];
+                            carry[s] = y[tid + N512_H];
+                        }
+                }
+        }
+        __syncthreads();
+    }
+    if (t1 == p.n_frames && tid < N512_H) {
+#pragma unroll
+        for (int s = 0; s < MCA_MAX_SOURCES; ++s)
+            if (s < S) p.tail_out[((long long)a * S + s) * N512_H + tid] = carry[s];
+    }
+}
 
 // --------------------------------------------------------------------------------------
 // k_gcc2_scan -- FreqGCCBinauralLocalisation, deterministic part (BinauralLocalisation.cpp:438-523)
