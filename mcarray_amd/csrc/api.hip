@@ -531,6 +531,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     return init_last_state(c, st);
 }
 
+extern "C++" {
 namespace {
 
 struct StateHeader {
@@ -561,6 +562,7 @@ std::vector<StatePart> state_parts(mca_hip_ctx *c)
 }
 
 }  // namespace
+}  // extern "C++"
 
 long long mca_hip_state_size(const mca_hip_ctx *c)
 {
