@@ -224,6 +224,13 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
         const size_t smem1 = (size_t)(8 * 580 + TW_WORDS) * sizeof(float2);
         VHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mvdr_analyse_1024), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
         hipLaunchKernelGGL(k_mvdr_analyse_1024, dim3((n_frames + fpb - 1) / fpb, n_streams), dim3(512), smem1, st, aa, fpb);
+    } else if (c->N == 512 && !no_tuned) {
+        // 512-sample frames: two channels per wave pass (kernels_stream.hip)
+        int fpb = 8;
+        while (fpb > 1 && (long long)n_streams * ((n_frames + fpb - 1) / fpb) < 1024) fpb >>= 1;
+        const size_t smem1 = (size_t)(16 * 258 + 8 * FFT_SCRATCH + TW_WIN) * sizeof(float2);
+        VHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mvdr_analyse_512), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+        hipLaunchKernelGGL(k_mvdr_analyse_512, dim3((n_frames + fpb - 1) / fpb, n_streams), dim3(512), smem1, st, aa, fpb);
     } else {
         const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2);
         if (smem1 > 64 * 1024)

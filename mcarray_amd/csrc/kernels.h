@@ -44,6 +44,7 @@ __global__ void k_mb_scan(MbScanArgs p);
 __global__ void k_mb_summary(MbSummaryArgs p);
 __global__ void k_mvdr_analyse(MvdrAnalyseArgs p);
 __global__ void k_mvdr_analyse_1024(MvdrAnalyseArgs p, int fpb);
+__global__ void k_mvdr_analyse_512(MvdrAnalyseArgs p, int fpb);
 template <int Q, bool FULL> __global__ void k_mvdr_solve(MvdrSolveArgs p);
 __global__ void k_mvdr_synth(MvdrSynthArgs p);
 

@@ -853,6 +853,56 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
 INST_512(0, false, float) INST_512(0, true, float) INST_512(4, false, float) INST_512(4, true, float) INST_512(8, false, float) INST_512(8, true, float)
 INST_512(0, false, _Float16) INST_512(0, true, _Float16) INST_512(4, false, _Float16) INST_512(4, true, _Float16) INST_512(8, false, _Float16) INST_512(8, true, _Float16)
 
+// k_mvdr_analyse_512: the analysis stage of the MVDR path (kernels_mvdr.hip: k_mvdr_analyse_1024) for 512-sample frames: wave w
+// transforms channels 2 w, 2 w + 1 of the frame in one pass (up to 16 channels), then the spectra go out transposed,
+// [bin][mic].  grid (ceil(frames / fpb), streams), 512 threads; LDS = 16 spectra + 8 wave scratches + twiddles.
+__global__ __launch_bounds__(512) void k_mvdr_analyse_512(MvdrAnalyseArgs p, int fpb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);                   // [16][N512_ROW]
+    float2 *scr = spec + 16 * N512_ROW;                                     // [8][FFT_SCRATCH]
+    float2 *tab = scr + 8 * FFT_SCRATCH;                                    // [TW_WIN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.y, M = p.M;
+    const int f_begin = blockIdx.x * fpb, f_end = min(f_begin + fpb, p.n_frames);
+    fft_table_init(tab, nullptr, tid, 512);
+    float wreg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wreg[r] = 0.5f * p.window[lane + 64 * r];
+    // factored steering phasors of the block's frames (MvdrAnalyseArgs::T)
+    {
+        const int nhi = (512 >> 6) + 1, nph = nhi + 32;
+        for (int e = tid; e < (f_end - f_begin) * M * nph; e += 512) {
+            const int f = f_begin + e / (M * nph), rem = e % (M * nph), m = rem / nph, i = rem - m * nph;
+            const long long o = (long long)a * p.n_frames + f;
+            const double cd = cos((double)p.doa_rad[o] + 1.57079632679489661923);   // cos(DOA + M_PI/2), Beamformer.cpp:59
+            const int kk = i < nhi ? (i << 5) : i - nhi;
+            double turns = (double)kk * (p.unit * p.mic_x[m] * cd);
+            turns -= rint(turns);
+            float sn, cs;
+            sincospif(2.0f * (float)turns, &sn, &cs);
+            p.T[(o * M + m) * nph + i] = make_float2(cs, -sn);
+        }
+    }
+    __syncthreads();
+    FftTw tw{tab};
+    const float *base = p.pcm + (long long)a * p.stream_stride;
+    for (int f = f_begin; f < f_end; ++f) {
+        if (2 * wave < M) {
+            float2 v[8];
+            load_pair_512(v, base, p.mic_stride, 2 * wave, M, (long long)f * N512_H, wreg, lane);
+            rfft512_pair(v, scr + wave * FFT_SCRATCH, spec + (2 * wave) * N512_ROW, spec + (2 * wave + 1) * N512_ROW, lane, tw);
+        }
+        __syncthreads();
+        float2 *xo = p.X + ((long long)a * p.n_frames + f) * (long long)N512_K * M;
+        for (int e = tid; e < N512_K * M; e += 512) {
+            const int k = e / M, m = e - k * M;
+            xo[e] = spec[m * N512_ROW + k];
+        }
+        __syncthreads();
+    }
+}
+
 // k_beamform_512: grid (runs of ft frames, arrays), 512 threads, M <= 8.  Frames are taken two at a time: the 8 waves analyse
 // them as in k_stft_phat_512 and thread (slot, bin) applies the delay-and-sum with phasors factored hi[k >> 5] * lo[k & 31]
 // (Beamformer.cpp:51-71; a slot's table is rebuilt only when its DOA differs from the one it was built for).  Then wave s
