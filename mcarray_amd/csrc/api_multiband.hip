@@ -238,6 +238,13 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *c, const float *pcm, long long array_s
         const size_t smem1 = (size_t)8 * FFT_SCRATCH * 8 + (size_t)4 * 520 * (8 + 4) + (size_t)TW_WORDS * 8 + 16 * 4;
         BHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mb_analyse_1024), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
         hipLaunchKernelGGL(k_mb_analyse_1024, dim3((n_frames + fpb - 1) / fpb, n_arrays), dim3(512), smem1, st, aa, fpb);
+    } else if (c->N == 512 && !no_tuned) {
+        // 512-sample frames: both channels of a frame in one 512-point complex transform, 8 frames per pass
+        int fpb = 32;
+        while (fpb > 8 && (long long)n_arrays * ((n_frames + fpb - 1) / fpb) < 512) fpb >>= 1;
+        const size_t smem1 = (size_t)(16 * 258 + 8 * FFT_SCRATCH + TW_WIN) * 8 + 16 * 4;
+        BHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mb_analyse_512), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+        hipLaunchKernelGGL(k_mb_analyse_512, dim3((n_frames + fpb - 1) / fpb, n_arrays), dim3(512), smem1, st, aa, fpb);
     } else {
         const size_t smem1 = (size_t)2 * (c->H + 1) * 8 + (size_t)c->K * 8 + (size_t)c->K * 4 + 8 * 4;
         if (smem1 > 64 * 1024)

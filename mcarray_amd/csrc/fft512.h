@@ -285,4 +285,67 @@ __device__ __forceinline__ void irfft1024(float2 *buf, int lane, const FftTw &tw
     wave_lds_fence();
 }
 
+// ---- 512-sample real frames, two per 512-point complex transform --------------------------------------------------
+constexpr int N512_H = 256, N512_K = 257, N512_ROW = 258;
+
+// v[r] = (a[m], b[m]) * w[m] / 2, m = lane + 64 r.  On return specA[k], specB[k], k = 0..256.
+__device__ __forceinline__ void rfft512_pair(float2 (&v)[8], float2 *buf, float2 *specA, float2 *specB, int lane, const FftTw &tw)
+{
+    cfft512_regs<false>(v, buf, lane, tw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[lane + 64 * br3(i)] = v[i];
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        const float2 zk = buf[k], zp = buf[(512 - k) & 511];
+        const float2 d = make_float2(zk.x - zp.x, zk.y + zp.y);                 // Z[k] - conj Z[512-k]
+        specA[k] = make_float2(zk.x + zp.x, zk.y - zp.y);
+        specB[k] = make_float2(d.y, -d.x);                                      // -j d
+    }
+    if (lane == 0) {
+        const float2 z = buf[256];
+        specA[256] = make_float2(2.f * z.x, 0.f);
+        specB[256] = make_float2(2.f * z.y, 0.f);
+    }
+    wave_lds_fence();
+}
+
+// inverse of two one-sided spectra Ya, Yb (k = 0..256; imaginary parts of k = 0 and 256 ignored, like a CCS inverse):
+// on return v[i] = (ya[n], yb[n]), n = lane + 64 br3(i), scaled by 1/512.
+__device__ __forceinline__ void irfft512_pair(const float2 *Ya, const float2 *Yb, float2 *buf, float2 (&v)[8], int lane, const FftTw &tw)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        float2 a = Ya[k], b = Yb[k];
+        if (k == 0) { a.y = 0.f; b.y = 0.f; }
+        buf[k] = make_float2(a.x - b.y, a.y + b.x);                             // Ya + j Yb
+        if (k != 0) buf[512 - k] = make_float2(a.x + b.y, -a.y + b.x);          // conj Ya + j conj Yb
+    }
+    if (lane == 0) buf[256] = make_float2(Ya[256].x, Yb[256].x);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
+    wave_lds_fence();
+    cfft512_regs<true>(v, buf, lane, tw);
+    const float sc = 1.0f / 512.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = make_float2(v[i].x * sc, v[i].y * sc);
+}
+
+// windowed samples of channels c0, c0 + 1 (zeros beyond M) of the frame that starts at sample `start`
+__device__ __forceinline__ void load_pair_512(float2 (&v)[8], const float *base, long long mic_stride, int c0, int M, long long start,
+                                              const float (&wreg)[8], int lane)
+{
+    const float *pa = base + (long long)c0 * mic_stride + start, *pb = pa + mic_stride;
+    const bool hb = c0 + 1 < M;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float xa = pa[lane + 64 * r], xb = hb ? pb[lane + 64 * r] : 0.f;
+        v[r] = make_float2(xa * wreg[r], xb * wreg[r]);
+    }
+}
+
+
 }  // namespace mca

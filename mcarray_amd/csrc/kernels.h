@@ -40,6 +40,7 @@ __global__ void k_mask_stream_gen(MaskGenArgs p);
 __global__ void k_mask_frame(MaskFrameArgs p);
 __global__ void k_mb_analyse(MbAnalyseArgs p);
 __global__ void k_mb_analyse_1024(MbAnalyseArgs p, int fpb);
+__global__ void k_mb_analyse_512(MbAnalyseArgs p, int fpb);
 __global__ void k_mb_scan(MbScanArgs p);
 __global__ void k_mb_summary(MbSummaryArgs p);
 __global__ void k_mvdr_analyse(MvdrAnalyseArgs p);

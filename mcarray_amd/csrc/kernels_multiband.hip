@@ -161,6 +161,91 @@ __global__ __launch_bounds__(512) void k_mb_analyse_1024(MbAnalyseArgs p, int fp
     }
 }
 
+// The same stage for N = 512 (16 kHz at the module's 0.025 s frame rate): the two channels of a frame are ONE 512-point
+// complex transform (fft512.h: rfft512_pair), so a pass takes 8 frames (wave = frame slot).  LDS: spec [8][2][N512_ROW],
+// 8 wave scratches (reused for G [8][260] float2 and pw [8][260] float once the transforms are done), table, red.
+__global__ __launch_bounds__(512) void k_mb_analyse_512(MbAnalyseArgs p, int fpb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int K = N512_K, Kh = N512_K / 2, GS = 260;
+    float2 *spec = reinterpret_cast<float2 *>(smem_raw);        // [8][2][N512_ROW]
+    float2 *scr = spec + 16 * N512_ROW;                          // [8][FFT_SCRATCH]
+    float2 *G = scr;                                             // [8][GS]   (after the transforms)
+    float *pw = reinterpret_cast<float *>(G + 8 * GS);           // [8][GS]
+    float2 *tab = scr + 8 * FFT_SCRATCH;                         // [TW_WIN]
+    float *red = reinterpret_cast<float *>(tab + TW_WIN);        // [2][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.y;
+    const int f_begin = blockIdx.x * fpb, f_end = min(f_begin + fpb, p.n_frames);
+    const float *base = p.pcm + (long long)a * p.array_stride;
+    const int BD = p.nbins * p.D;
+
+    fft_table_init(tab, nullptr, tid, 512);
+    float wreg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wreg[r] = 0.5f * p.window[lane + 64 * r];
+    __syncthreads();
+    FftTw tw{tab};
+    for (int f = f_begin; f < f_end; f += 8) {
+        const int nb = min(8, f_end - f);
+        if (wave < nb) {
+            float2 v[8];
+            load_pair_512(v, base, p.ch_stride, 0, 2, (long long)(f + wave) * N512_H, wreg, lane);
+            rfft512_pair(v, scr + wave * FFT_SCRATCH, spec + (2 * wave) * N512_ROW, spec + (2 * wave + 1) * N512_ROW, lane, tw);
+        }
+        __syncthreads();
+        // per-bin power and PHAT cross-spectrum: wave j -> frame j
+        {
+            const int j = wave;
+            float full = 0.f, half = 0.f;
+            if (j < nb) {
+                const float2 *L = spec + (2 * j) * N512_ROW, *R = L + N512_ROW;
+                for (int k = lane; k < K; k += 64) {
+                    const float2 l = L[k], r = R[k];
+                    const float pk = l.x * l.x + l.y * l.y + r.x * r.x + r.y * r.y;
+                    pw[j * GS + k] = pk;
+                    full += (k == 0 || k == K - 1) ? pk : 2.f * pk;
+                    if (k < Kh) half += (k == 0 || k == Kh - 1) ? pk : 2.f * pk;
+                    G[j * GS + k] = whiten_g(cmulc(l, r));
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { full += __shfl_down(full, off); half += __shfl_down(half, off); }
+            if (lane == 0) { red[wave] = full; red[8 + wave] = half; }
+        }
+        __syncthreads();
+        if (tid < nb) {
+            const long long row = (long long)a * p.n_frames + f + tid;
+            const float n2 = 512.f * 512.f, h2 = (float)(K - 2) * (float)(K - 2);
+            p.p_full[row] = red[tid] / n2 * 0.5f;                               // mean over the 2 channels
+            p.p_half[row] = red[8 + tid] / h2 * 0.5f;
+        }
+        // band energies: 8 lanes per (frame, band)
+        for (int q = tid >> 3; q < nb * p.nbins; q += 64) {
+            const int j = q / p.nbins, b = q - j * p.nbins;
+            float s = 0.f;
+            for (int k = p.lo[b] + (tid & 7); k <= p.hi[b]; k += 8) {
+                const float h = p.coef[(long long)b * K + k];
+                const float w = (k == 0 || k == K - 1) ? 1.f : 2.f;
+                s += w * h * h * pw[j * GS + k];
+            }
+            s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+            if ((tid & 7) == 0) p.band_energy[((long long)a * p.n_frames + f + j) * p.nbins + b] = s / (512.f * 512.f) * 0.5f;
+        }
+        // band correlations at the steering delays
+        for (int e = tid; e < nb * BD; e += 512) {
+            const int j = e / BD, r = e - j * BD, b = r / p.D, d = r - b * p.D;
+            float s = 0.f;
+            for (int k = p.lo[b]; k <= p.hi[b]; ++k) {
+                const float2 g = G[j * GS + k], t = p.T[(long long)k * p.D + d];
+                s += g.x * t.x - g.y * t.y;
+            }
+            p.raw[((long long)a * p.n_frames + f + j) * BD + r] = s;
+        }
+        __syncthreads();
+    }
+}
+
 // grid (chunks, arrays), blockDim = roundup(nbins * D, 64).  LDS: sC [chunk][BD] float, sE [chunk][D] float, sIdx [chunk][nbins] int
 __global__ __launch_bounds__(1024) void k_mb_scan(MbScanArgs p)
 {
