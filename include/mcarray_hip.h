@@ -60,8 +60,8 @@ typedef struct {
     int device;                /* HIP device ordinal */
     int sample_rate;           /* Hz */
     int fft_size;              /* N; the reference derives it with calculateOrderFromSampleRate
-                                  (SourceSeparationAndLocalisation.cpp:52).  Stream API: N = 1024 runs the tuned
-                                  kernels, any other power of two 64..8192 the any-length kernels as long as
+                                  (SourceSeparationAndLocalisation.cpp:52).  Stream API: N = 1024 and N = 512 (up to 8
+                                  microphones) run the tuned kernels, any other power of two 64..8192 the any-length kernels as long as
                                   (n_mics + n_sources) spectra of N/2+1 bins fit the 160 KiB LDS; the frame API
                                   takes any even N with N/2+1 <= 4097 */
     int n_mics;                /* M, 2..16 */
