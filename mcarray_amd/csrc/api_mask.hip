@@ -237,6 +237,18 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
             MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         dim3 g((n_frames + a.ft - 1) / a.ft, n_streams);
         hipLaunchKernelGGL(k_mask_stream, g, dim3(512), smem, st, a);
+    } else if (c->N == 2048 && !no_tuned) {
+        // 2048-sample frames (44.1 / 48 kHz): four 512-sample sub-sequences per frame on the wave-level transform
+        MaskGenArgs ga{};
+        ga.a = a; ga.N = c->N; ga.logH = c->logH; ga.tw = c->d_tw; ga.kw = c->d_kw; ga.kb = c->d_kb;
+        if (!(c->cfg.method == MCA_HIP_MASK_NOISY && c->frames_done == 0)) {
+            ga.a.ft = 256;
+            while (ga.a.ft > 16 && (long long)n_streams * ((n_frames + ga.a.ft - 1) / ga.a.ft) < 512) ga.a.ft >>= 1;
+        }
+        const size_t smem = (size_t)(16 * 258 + 8 * FFT_SCRATCH + TW_WIN) * sizeof(float2) + (size_t)2 * 48 * 8 * sizeof(float);
+        MHIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_stream_2048), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        dim3 g((n_frames + ga.a.ft - 1) / ga.a.ft, n_streams);
+        hipLaunchKernelGGL(k_mask_stream_2048, g, dim3(512), smem, st, ga);
     } else {
         // any other power of two: one frame at a time, block-cooperative FFT (runs re-analyse MK_WARM + 1 frames)
         MaskGenArgs ga{};

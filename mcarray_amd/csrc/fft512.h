@@ -348,4 +348,40 @@ __device__ __forceinline__ void load_pair_512(float2 (&v)[8], const float *base,
 }
 
 
+// ---- 2048-sample real frames by decimation in time over four 512-sample sub-sequences x[4 n + r] ---------------------
+// The sub-sequences are real, so two of them share one 512-point complex transform (rfft512_pair); then
+//   X[k] = sum_r W^(r k) S_r[k mod 512],  W = exp(-j 2 pi / 2048),  k = 0..1024
+// with the Hermitian extension S_r[m] = conj S_r[512 - m] for m > 256.  S: the four one-sided sub-spectra of a channel,
+// N512_ROW words apart; tw2048[i] = exp(-j 2 pi i / 2048), i < 1024.
+__device__ __forceinline__ float2 sub512_at(const float2 *S, int m) { return m <= 256 ? S[m] : cconj(S[512 - m]); }
+
+__device__ __forceinline__ float2 combine2048(const float2 *S, int k, const float2 *tw2048)
+{
+    const int m = k & 511;
+    const float2 s0 = sub512_at(S, m), s1 = sub512_at(S + N512_ROW, m), s2 = sub512_at(S + 2 * N512_ROW, m), s3 = sub512_at(S + 3 * N512_ROW, m);
+    const float2 w1 = k < 1024 ? tw2048[k] : make_float2(-1.f, 0.f);
+    float2 w2;                                                          // W^(2k), 2k = 0..2048
+    if (k < 512) w2 = tw2048[2 * k];
+    else if (k < 1024) { const float2 t = tw2048[2 * k - 1024]; w2 = make_float2(-t.x, -t.y); }
+    else w2 = make_float2(1.f, 0.f);
+    const float2 w3 = cmul(w1, w2);
+    float2 x = cmac(s0, w1, s1);
+    x = cmac(x, w2, s2);
+    return cmac(x, w3, s3);
+}
+
+// inverse: the four one-sided sub-spectra at bin m = 0..256 of a spectrum Y[0..1024] (imaginary parts of Y[0], Y[1024] ignored):
+//   Y_r[m] = W^(-r m) / 4 * sum_q exp(+j 2 pi r q / 4) Yext[m + 512 q],  Yext[i > 1024] = conj Y[2048 - i]
+__device__ __forceinline__ void split2048_inv(const float2 *Y, int m, const float2 *tw2048, float2 (&out)[4])
+{
+    float2 y0 = Y[m], y1 = Y[m + 512], y2 = cconj(Y[1024 - m]), y3 = cconj(Y[512 - m]);
+    if (m == 0) { y0.y = 0.f; y2.y = 0.f; }                             // DC and Nyquist (Yext[1024] = Y[1024]) are real
+    const float2 t0 = cadd(y0, y2), t1 = csub(y0, y2), t2 = cadd(y1, y3), t3 = csub(y1, y3);
+    const float2 jt3 = make_float2(-t3.y, t3.x);                        // j (y1 - y3)
+    const float2 w1 = cconj(tw2048[m]), w2 = cconj(tw2048[2 * m]), w3 = cconj(tw2048[3 * m]);   // 3 m <= 768 < 1024
+    const float2 a0 = cadd(t0, t2), a1 = cmul(cadd(t1, jt3), w1), a2 = cmul(csub(t0, t2), w2), a3 = cmul(csub(t1, jt3), w3);
+    out[0] = make_float2(0.25f * a0.x, 0.25f * a0.y); out[1] = make_float2(0.25f * a1.x, 0.25f * a1.y);
+    out[2] = make_float2(0.25f * a2.x, 0.25f * a2.y); out[3] = make_float2(0.25f * a3.x, 0.25f * a3.y);
+}
+
 }  // namespace mca

@@ -37,6 +37,7 @@ __global__ void k_gcc2_compact(const unsigned char *voiced, int n_frames, int *v
 __global__ void k_gcc2_fill(Gcc2FillArgs p);
 __global__ void k_mask_stream(MaskArgs p);
 __global__ void k_mask_stream_gen(MaskGenArgs p);
+__global__ void k_mask_stream_2048(MaskGenArgs p);
 __global__ void k_mask_frame(MaskFrameArgs p);
 __global__ void k_mb_analyse(MbAnalyseArgs p);
 __global__ void k_mb_analyse_1024(MbAnalyseArgs p, int fpb);

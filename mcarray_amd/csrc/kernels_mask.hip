@@ -340,6 +340,196 @@ __global__ __launch_bounds__(1024) void k_mask_stream_gen(MaskGenArgs pg)
 }
 
 // ---------------------------------------------------------------------------------------
+// k_mask_stream_2048: the module at 2048-sample frames (44.1 / 48 kHz: N = 2^round(log2(0.050 fs)), FastBinauralMasking.h:112)
+// on the wave-level transform.  A 2048-sample real frame is four 512-sample real sub-sequences x[4 n + r] (decimation in
+// time, fft512.h): wave w = (frame slot, channel, pair of sub-sequences) transforms two of them in one 512-point complex
+// transform, thread = bin recombines them (radix 4); the inverse is the mirror image.  Two frames x two channels per pass.
+// grid (runs of ft frames, streams), 512 threads, 80 KiB of LDS (two workgroups per CU): the spectra take the place of
+// the wave scratches between the transforms, the per-bin products that of the sub-spectra.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_mask_stream_2048(MaskGenArgs pg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const MaskArgs &p = pg.a;
+    constexpr int H = 1024, K = 1025, XR = 1026, BQ = 1028;
+    float2 *sub = reinterpret_cast<float2 *>(smem_raw);                    // [2 frames][2 ch][4][N512_ROW] sub-spectra
+    float *binq = reinterpret_cast<float *>(sub);                          // [2][3][BQ] per-bin products (sub-spectra are dead)
+    float *yt = reinterpret_cast<float *>(sub);                            // [2][2][2064] time-domain frames (after the inverse)
+    float2 *scr = sub + 16 * N512_ROW;                                      // [8][FFT_SCRATCH] wave scratches
+    float2 *X = scr;                                                        // [2][2][XR] spectra (between the transforms)
+    float2 *tab = scr + 8 * FFT_SCRATCH;                                    // [TW_WIN]
+    float *sums = reinterpret_cast<float *>(tab + TW_WIN);                  // [2][48][6]
+    float *gains = sums + 2 * 48 * 6;                                       // [2][48][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.y;
+    const MaskParams &mp = *p.mp;
+    const int t0 = blockIdx.x * p.ft, t1 = min(t0 + p.ft, p.n_frames);
+    const int tfull = t0 > 0 ? t0 - 1 : 0;
+    const int tbeg = t0 > 0 ? max(0, tfull - MK_WARM) : 0;
+    const bool passthrough = mp.method == 5;                                // NOTHING :130-134
+
+    fft_table_init(tab, nullptr, tid, 512);
+    float Q = 0.f, noise_b = 0.f;
+    if (tid < 45) {
+        if (tbeg == 0) Q = p.Q_in[s * 45 + tid];
+        noise_b = p.noise[s * 45 + tid];
+    }
+    float carry[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                           // samples tid, tid + 512 of the hop, per channel
+    if (t0 == 0) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) { carry[ch][0] = p.tail_in[((long long)s * 2 + ch) * H + tid]; carry[ch][1] = p.tail_in[((long long)s * 2 + ch) * H + tid + 512]; }
+    }
+    // wave -> (frame slot, channel, sub-sequence pair); the pair's samples x[4 n + 2 pr], x[4 n + 2 pr + 1] are one float2
+    const int jw = wave >> 2, cw = (wave >> 1) & 1, pr = wave & 1;
+    const float *base = p.pcm + (long long)s * p.stream_stride + (long long)cw * p.ch_stride;
+    float2 wreg[8];                                                         // window at those samples, halved (rfft512_pair)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float2 w = reinterpret_cast<const float2 *>(p.window)[2 * (lane + 64 * r) + pr];
+        wreg[r] = make_float2(0.5f * w.x, 0.5f * w.y);
+    }
+    __syncthreads();
+    FftTw tw{tab};
+
+    for (int tb = tbeg; tb < t1; tb += 2) {
+        const int nb = min(2, t1 - tb);
+        // (1) analysis
+        if (jw < nb) {
+            const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(tb + jw) * H);
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float2 x = src[2 * (lane + 64 * r) + pr], w = wreg[r];
+                v[r] = make_float2(x.x * w.x, x.y * w.y);
+            }
+            float2 *S = sub + ((jw * 2 + cw) * 4 + 2 * pr) * N512_ROW;
+            rfft512_pair(v, scr + wave * FFT_SCRATCH, S, S + N512_ROW, lane, tw);
+        }
+        __syncthreads();
+        // (2) radix-4 recombination: X[k], k = 0..1024
+        for (int e = tid; e < nb * 2 * K; e += 512) {
+            const int jc = e / K, k = e - jc * K;
+            X[jc * XR + k] = combine2048(sub + jc * 4 * N512_ROW, k, pg.tw);
+        }
+        __syncthreads();
+        // (3) per-bin products
+        for (int e = tid; e < nb * K; e += 512) {
+            const int j = e / K, k = e - j * K;
+            const float2 L = X[(j * 2) * XR + k], R = X[(j * 2 + 1) * XR + k];
+            float *bq = binq + j * 3 * BQ + k;
+            bq[0] = L.x * L.x + L.y * L.y; bq[BQ] = R.x * R.x + R.y * R.y; bq[2 * BQ] = L.x * R.x + L.y * R.y;
+        }
+        __syncthreads();
+        // (4) band sums: 8 lanes per (frame, band)
+        for (int q = tid >> 3; q < nb * 45; q += 64) {
+            const int j = q / 45, b = q - j * 45;
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+            for (int k = mp.lo[b] + (tid & 7); k <= mp.hi[b]; k += 8) {
+                const float2 hw = pg.kw[k];
+                const float h = pg.kb[k] == b ? hw.x : hw.y;
+                const float w = h * h;
+                const float *bq = binq + j * 3 * BQ + k;
+                const float ll = bq[0], rr = bq[BQ], lr = bq[2 * BQ];
+                a0 += w * ll; a1 += w * rr; a2 += w * lr;
+                if (k < H) { a3 += w * lr; a4 += w * ll; a5 += w * rr; }
+            }
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {
+                a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
+                a3 += __shfl_xor(a3, off); a4 += __shfl_xor(a4, off); a5 += __shfl_xor(a5, off);
+            }
+            if ((tid & 7) == 0) {
+                float *o = sums + (j * 48 + b) * 6;
+                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = 0.25f * (a4 + a5 + 2.f * a3); o[4] = a4; o[5] = a5;
+            }
+        }
+        __syncthreads();
+        // (5) the recursion over frames: thread = band
+        if (tid < 45) {
+            for (int j = 0; j < nb; ++j) {
+                const float *o = sums + (j * 48 + tid) * 6;
+                int dec; float gL, gR;
+                const long long gframe = p.frames_done + tb + j;
+                mask_decide(mp, tid, o[3], o[0], o[1], o[2], o[4], o[5], Q, noise_b, gframe, dec, gL, gR, H, K);
+                if (gframe == 0) noise_b = Q;                               // noise <- Q after the first call :193-197
+                gains[(j * 48 + tid) * 2] = gL; gains[(j * 48 + tid) * 2 + 1] = gR;
+                if (p.decisions && tb + j >= t0) p.decisions[((long long)s * p.n_frames + tb + j) * 45 + tid] = dec;
+            }
+        }
+        __syncthreads();
+        if (tb + nb > tfull) {
+            // (6) out[k] = X[k] * sum_b g_b H_b[k]  (Nyquist bin: gain 1)
+            for (int e = tid; e < nb * 2 * K; e += 512) {
+                const int jc = e / K, k = e - jc * K, j = jc >> 1, ch = jc & 1;
+                float m = 1.f;
+                if (!passthrough) {
+                    const int b0 = pg.kb[k];
+                    m = 0.f;
+                    if (b0 >= 0) {
+                        const float g0 = k < H ? gains[(j * 48 + b0) * 2 + ch] : 1.f;
+                        const float g1 = (k < H && b0 + 1 < 45) ? gains[(j * 48 + b0 + 1) * 2 + ch] : 1.f;
+                        const float2 hw = pg.kw[k];
+                        m = g0 * hw.x + g1 * hw.y;
+                    }
+                }
+                const float2 x = X[jc * XR + k];
+                X[jc * XR + k] = make_float2(x.x * m, x.y * m);
+            }
+            __syncthreads();
+            // (7) the four sub-spectra of every masked spectrum (radix 4, inverse)
+            for (int e = tid; e < nb * 2 * 257; e += 512) {
+                const int jc = e / 257, m = e - jc * 257;
+                float2 o4[4];
+                split2048_inv(X + jc * XR, m, pg.tw, o4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sub[(jc * 4 + r) * N512_ROW + m] = o4[r];
+            }
+            __syncthreads();
+            // (8) synthesis: two sub-sequences per inverse transform; the spectra are dead, the scratches are scratches again
+            float2 v[8];
+            if (jw < nb) {
+                const float2 *Ya = sub + ((jw * 2 + cw) * 4 + 2 * pr) * N512_ROW;
+                irfft512_pair(Ya, Ya + N512_ROW, scr + wave * FFT_SCRATCH, v, lane, tw);
+            }
+            __syncthreads();                                                // every wave has read its sub-spectra: yt may overwrite them
+            if (jw < nb) {
+                float *y = yt + (jw * 2 + cw) * 2064;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int n = lane + 64 * br3(i);
+                    *reinterpret_cast<float2 *>(y + 4 * n + 2 * pr) = v[i];      // y[4 n + 2 pr], y[4 n + 2 pr + 1]
+                }
+            }
+            __syncthreads();
+            // (9) overlap-add, frames in order
+            for (int j = 0; j < nb; ++j) {
+                const int t = tb + j;
+                if (t < tfull) continue;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float *y = yt + (j * 2 + ch) * 2064;
+                    if (t >= t0) {
+                        float *o = p.out + ((long long)s * 2 + ch) * (long long)p.n_frames * H + (long long)t * H;
+                        o[tid] = carry[ch][0] + y[tid]; o[tid + 512] = carry[ch][1] + y[tid + 512];
+                    }
+                    carry[ch][0] = y[H + tid]; carry[ch][1] = y[H + tid + 512];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (t1 == p.n_frames) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            p.tail_out[((long long)s * 2 + ch) * H + tid] = carry[ch][0];
+            p.tail_out[((long long)s * 2 + ch) * H + tid + 512] = carry[ch][1];
+        }
+        if (tid < 45) p.Q_out[s * 45 + tid] = Q;
+    }
+    if (tid < 45 && p.frames_done == 0 && tbeg == 0) p.noise[s * 45 + tid] = noise_b;
+}
+
+// ---------------------------------------------------------------------------------------
 // one frame in double, the reference's own loop order (band by band), dense filter table
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double block_sum_d(double v, double *sred)

@@ -24,5 +24,5 @@ for fs, N in ((16000, 1024), (48000, 2048), (8000, 512)):
     dt = (time.perf_counter() - t0) / n
     bpf = 2 * hop * 4 * 2
     print("%s, fs %d, N %d: %d streams x %d frames: %.3f ms per call, %.2f M frames/s, %.0f GB/s algorithmic (%d B/frame)"
-          % ("k_mask_stream" if N == 1024 else "k_mask_stream_gen", fs, N, A, F, dt * 1e3, A * F / dt / 1e6, A * F * bpf / dt / 1e9, bpf))
+          % ("k_mask_stream" if N == 1024 else ("k_mask_stream_2048" if N == 2048 else "k_mask_stream_gen"), fs, N, A, F, dt * 1e3, A * F / dt / 1e6, A * F * bpf / dt / 1e9, bpf))
     m.close()
