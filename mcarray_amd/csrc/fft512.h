@@ -355,19 +355,17 @@ __device__ __forceinline__ void load_pair_512(float2 (&v)[8], const float *base,
 // N512_ROW words apart; tw2048[i] = exp(-j 2 pi i / 2048), i < 1024.
 __device__ __forceinline__ float2 sub512_at(const float2 *S, int m) { return m <= 256 ? S[m] : cconj(S[512 - m]); }
 
-__device__ __forceinline__ float2 combine2048(const float2 *S, int k, const float2 *tw2048)
+// One radix-4 butterfly per m = k mod 512 gives X[m + 512 q]: t_r = W^(r m) S_r[m], then the 4-point DFT over r.
+// Writes the one-sided part: X[m], X[m + 512], and X[1024] for m = 0.
+__device__ __forceinline__ void combine2048_m(const float2 *S, int m, const float2 *tw2048, float2 *X)
 {
-    const int m = k & 511;
-    const float2 s0 = sub512_at(S, m), s1 = sub512_at(S + N512_ROW, m), s2 = sub512_at(S + 2 * N512_ROW, m), s3 = sub512_at(S + 3 * N512_ROW, m);
-    const float2 w1 = k < 1024 ? tw2048[k] : make_float2(-1.f, 0.f);
-    float2 w2;                                                          // W^(2k), 2k = 0..2048
-    if (k < 512) w2 = tw2048[2 * k];
-    else if (k < 1024) { const float2 t = tw2048[2 * k - 1024]; w2 = make_float2(-t.x, -t.y); }
-    else w2 = make_float2(1.f, 0.f);
-    const float2 w3 = cmul(w1, w2);
-    float2 x = cmac(s0, w1, s1);
-    x = cmac(x, w2, s2);
-    return cmac(x, w3, s3);
+    const float2 w1 = tw2048[m], w2 = tw2048[2 * m];                    // m < 512
+    const float2 t0 = sub512_at(S, m), t1 = cmul(sub512_at(S + N512_ROW, m), w1), t2 = cmul(sub512_at(S + 2 * N512_ROW, m), w2),
+                 t3 = cmul(sub512_at(S + 3 * N512_ROW, m), cmul(w1, w2));
+    const float2 a = cadd(t0, t2), b = csub(t0, t2), c = cadd(t1, t3), d = csub(t1, t3);
+    X[m] = cadd(a, c);
+    X[m + 512] = make_float2(b.x + d.y, b.y - d.x);                     // b - j d
+    if (m == 0) X[1024] = csub(a, c);
 }
 
 // inverse: the four one-sided sub-spectra at bin m = 0..256 of a spectrum Y[0..1024] (imaginary parts of Y[0], Y[1024] ignored):
@@ -382,6 +380,36 @@ __device__ __forceinline__ void split2048_inv(const float2 *Y, int m, const floa
     const float2 a0 = cadd(t0, t2), a1 = cmul(cadd(t1, jt3), w1), a2 = cmul(csub(t0, t2), w2), a3 = cmul(csub(t1, jt3), w3);
     out[0] = make_float2(0.25f * a0.x, 0.25f * a0.y); out[1] = make_float2(0.25f * a1.x, 0.25f * a1.y);
     out[2] = make_float2(0.25f * a2.x, 0.25f * a2.y); out[3] = make_float2(0.25f * a3.x, 0.25f * a3.y);
+}
+
+// ---- 4096-sample real frames: eight 512-sample sub-sequences x[8 n + r] ----------------------------------------------
+//   X[k] = sum_{r<8} W^(r k) S_r[k mod 512],  W = exp(-j 2 pi / 4096),  k = 0..2048;  tw4096[i] = W^i, i < 2048.
+__device__ __forceinline__ float2 tw4096_at(const float2 *tw4096, int i)       // W^i for any i >= 0
+{
+    i &= 4095;
+    if (i < 2048) return tw4096[i];
+    const float2 t = tw4096[i - 2048];
+    return make_float2(-t.x, -t.y);
+}
+
+// One radix-8 butterfly per m = k mod 512 gives X[m + 512 q], q = 0..7: t_r = W^(r m) S_r[m], then the 8-point DFT over r
+// (W^(512 r q) = exp(-j 2 pi r q / 8)).  Writes the one-sided part, X[m + 512 q] for q = 0..3, and X[2048] for m = 0.
+__device__ __forceinline__ void combine4096_m(const float2 *S, int m, const float2 *tw4096, float2 *X)
+{
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = sub512_at(S + r * N512_ROW, m);
+    const float2 w1 = tw4096[m], w2 = tw4096[2 * m], w4 = tw4096_at(tw4096, 4 * m);    // m < 512: m, 2 m < 2048
+    const float2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+    v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+    v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+    fft8<false>(v);                                                     // v[i] = X[m + 512 br3(i)]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = br3(i);
+        if (q < 4) X[m + 512 * q] = v[i];
+        else if (q == 4 && m == 0) X[2048] = v[i];
+    }
 }
 
 }  // namespace mca

@@ -407,9 +407,9 @@ __global__ __launch_bounds__(512) void k_mask_stream_2048(MaskGenArgs pg)
         }
         __syncthreads();
         // (2) radix-4 recombination: X[k], k = 0..1024
-        for (int e = tid; e < nb * 2 * K; e += 512) {
-            const int jc = e / K, k = e - jc * K;
-            X[jc * XR + k] = combine2048(sub + jc * 4 * N512_ROW, k, pg.tw);
+        for (int e = tid; e < nb * 2 * 512; e += 512) {                     // thread = (frame, channel, m): one radix-4 butterfly
+            const int jc = e >> 9, m = e & 511;
+            combine2048_m(sub + jc * 4 * N512_ROW, m, pg.tw, X + jc * XR);
         }
         __syncthreads();
         // (3) per-bin products
