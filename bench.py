@@ -119,10 +119,11 @@ def main():
     from mcarray_amd import dist as mdist
     A, F = args.arrays, args.frames
     mine = mdist.local_range(A * world, rank, world)          # this rank's block of the global array list
-    pcm, theta = synth_batch([mdist.array_seed(0x5EED0000, g) for g in mine], F, dev)
+    # context first (host-side table building, the GPU idles), input synthesis on the GPU right before the warm-up
     ctx = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=A, device=local_rank)
     assert ctx.D == D and ctx.P == P
     ctx.reserve(A, F)
+    pcm, theta = synth_batch([mdist.array_seed(0x5EED0000, g) for g in mine], F, dev)
     # DOA bin (int32) and probability (fp32) share one 4-byte-word buffer so that the only exchange of the path is ONE
     # all_gather per step; two buffers alternate so that step i+1 can run while the gather of step i is in flight
     packed = [torch.empty(2, A, F, 1, dtype=torch.int32, device=dev) for _ in range(2)]
