@@ -656,19 +656,20 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
 #undef L512T
 #undef L512
             rc = MCA_HIP_OK;
-        } else if (c->N == 4096 && c->M == 2 && c->stream_ok && std::getenv("MCA_HIP_NO_N4096") == nullptr) {
-            // two microphones at 4096-sample frames (FreqGCC at 44.1 / 48 kHz): eight 512-sample sub-sequences per channel
+        } else if ((c->N == 4096 || c->N == 2048) && c->M == 2 && c->stream_ok && std::getenv("MCA_HIP_NO_SUB2") == nullptr) {
+            // two microphones at 2048- / 4096-sample frames (FreqGCC at 32 / 44.1 / 48 kHz): 512-sample sub-sequences per channel
             sa.fpb = 8;
-            while (sa.fpb > 1 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
+            while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
             const size_t smem4 = ((size_t)16 * 258 + 8 * FFT_SCRATCH + TW_WIN) * sizeof(float2) + 16;
             dim3 g4((nf + sa.fpb - 1) / sa.fpb, n_arrays);
-            if (c->prec == MCA_HIP_SRP_FP32) {
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_4096x2<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4));
-                hipLaunchKernelGGL((k_stft_phat_4096x2<float>), g4, dim3(512), smem4, st, sa);
-            } else {
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_4096x2<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4));
-                hipLaunchKernelGGL((k_stft_phat_4096x2<_Float16>), g4, dim3(512), smem4, st, sa);
-            }
+#define LSUB(RR, T)                                                                                                       \
+            do {                                                                                                          \
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_sub2<RR, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)); \
+                hipLaunchKernelGGL((k_stft_phat_sub2<RR, T>), g4, dim3(512), smem4, st, sa);                              \
+            } while (0)
+            if (c->N == 4096) { if (c->prec == MCA_HIP_SRP_FP32) LSUB(8, float); else LSUB(8, _Float16); }
+            else { if (c->prec == MCA_HIP_SRP_FP32) LSUB(4, float); else LSUB(4, _Float16); }
+#undef LSUB
             rc = MCA_HIP_OK;
         } else if (c->generic) {
             const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2) + 16;

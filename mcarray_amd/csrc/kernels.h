@@ -16,7 +16,7 @@ template <int CPW, int OCC> __global__ void k_beamform_ola(BeamformArgs p);
 template <typename OutT> __global__ void k_stft_phat_gen(StftPhatArgs p);
 template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat_512(StftPhatArgs p);
 __global__ void k_beamform_512(BeamformArgs p);
-template <typename OutT> __global__ void k_stft_phat_4096x2(StftPhatArgs p);
+template <int R, typename OutT> __global__ void k_stft_phat_sub2(StftPhatArgs p);
 __global__ void k_beamform_gen(BeamformArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);

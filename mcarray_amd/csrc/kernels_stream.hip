@@ -794,79 +794,90 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
 INST_512(0, false, float) INST_512(0, true, float) INST_512(4, false, float) INST_512(4, true, float) INST_512(8, false, float) INST_512(8, true, float)
 INST_512(0, false, _Float16) INST_512(0, true, _Float16) INST_512(4, false, _Float16) INST_512(4, true, _Float16) INST_512(8, false, _Float16) INST_512(8, true, _Float16)
 
-// k_stft_phat_4096x2: the analysis + PHAT stage for TWO microphones at 4096-sample frames -- FreqGCCBinauralLocalisation at
-// 44.1 / 48 kHz (0.075 s frames, BinauralLocalisation.h:196; the configuration of the reference's own test,
-// test_mcarray.cpp:283).  A frame is eight 512-sample real sub-sequences x[8 n + r] per channel: wave w = (channel, pair of
-// sub-sequences) transforms two of them in one 512-point complex transform (rfft512_pair), thread = bin recombines them
-// (radix 8, fft512.h) and forms the PHAT cross-spectrum of the one pair.  grid (ceil(frames / fpb), arrays), 512 threads;
-// LDS: [2][8][N512_ROW] sub-spectra + 8 wave scratches (reused for the two spectra) + twiddles.
-template <typename OutT>
-__global__ __launch_bounds__(512) void k_stft_phat_4096x2(StftPhatArgs p)
+// k_stft_phat_sub2<R>: the analysis + PHAT stage for TWO microphones at frames of N = 512 R samples, R = 4 or 8 --
+// FreqGCCBinauralLocalisation's 0.075 s frames (BinauralLocalisation.h:196) at 32 kHz (2048) and 44.1 / 48 kHz (4096; the
+// configuration of the reference's own test, test_mcarray.cpp:283).  A frame is R 512-sample real sub-sequences x[R n + r]
+// per channel: wave w = (frame slot, channel, pair of sub-sequences) transforms two of them in one 512-point complex
+// transform (rfft512_pair), one radix-R butterfly per m = k mod 512 recombines them (fft512.h), thread = bin forms the PHAT
+// cross-spectrum of the one pair.  8 / R frames per pass.  grid (ceil(frames / fpb), arrays), 512 threads;
+// LDS: 16 sub-spectra + 8 wave scratches (reused for the spectra) + twiddles.
+template <int R, typename OutT>
+__global__ __launch_bounds__(512) void k_stft_phat_sub2(StftPhatArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int H = 2048, K = 2049, XR = 2050;
-    float2 *sub = reinterpret_cast<float2 *>(smem_raw);                    // [2][8][N512_ROW]
+    constexpr int N = 512 * R, H = N / 2, K = H + 1, XR = H + 2, FPP = 8 / R;      // FPP: frames per pass
+    float2 *sub = reinterpret_cast<float2 *>(smem_raw);                    // [FPP][2][R][N512_ROW]
     float2 *scr = sub + 16 * N512_ROW;                                      // [8][FFT_SCRATCH]
-    float2 *X = scr;                                                        // [2][XR] (after the transforms)
+    float2 *X = scr;                                                        // [FPP][2][XR] (after the transforms)
     float2 *tab = scr + 8 * FFT_SCRATCH;                                    // [TW_WIN]
-    float *spow = reinterpret_cast<float *>(tab + TW_WIN);                  // [1]
+    float *spow = reinterpret_cast<float *>(tab + TW_WIN);                  // [FPP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = blockIdx.y;
     const int f_begin = blockIdx.x * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
     fft_table_init(tab, nullptr, tid, 512);
-    const int cw = wave >> 2, pr = wave & 3;                                // samples x[8 n + 2 pr], x[8 n + 2 pr + 1]: one float2
+    // wave -> (frame slot, channel, pair): samples x[R n + 2 pr], x[R n + 2 pr + 1] are one float2
+    const int slot = wave / R, cw = (wave % R) / (R / 2), pr = wave % (R / 2);
     float2 wreg[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const float2 w = reinterpret_cast<const float2 *>(p.window)[4 * (lane + 64 * r) + pr];
+        const float2 w = reinterpret_cast<const float2 *>(p.window)[(R / 2) * (lane + 64 * r) + pr];
         wreg[r] = make_float2(0.5f * w.x, 0.5f * w.y);
     }
     __syncthreads();
     FftTw tw{tab};
     const float *base = p.pcm + (long long)a * p.array_stride + (long long)cw * p.mic_stride;
-    for (int f = f_begin; f < f_end; ++f) {
-        {
-            const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(p.frame0 + f) * H);
+    for (int f = f_begin; f < f_end; f += FPP) {
+        const int nfr = min(FPP, f_end - f);
+        if (slot < nfr) {
+            const float2 *src = reinterpret_cast<const float2 *>(base + (long long)(p.frame0 + f + slot) * H);
             float2 v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float2 x = src[4 * (lane + 64 * r) + pr], w = wreg[r];
+                const float2 x = src[(R / 2) * (lane + 64 * r) + pr], w = wreg[r];
                 v[r] = make_float2(x.x * w.x, x.y * w.y);
             }
-            float2 *S = sub + (cw * 8 + 2 * pr) * N512_ROW;
+            float2 *S = sub + ((slot * 2 + cw) * R + 2 * pr) * N512_ROW;
             rfft512_pair(v, scr + wave * FFT_SCRATCH, S, S + N512_ROW, lane, tw);
         }
-        if (tid == 0) spow[0] = 0.f;
+        if (tid < FPP) spow[tid] = 0.f;
         __syncthreads();
-        for (int e = tid; e < 2 * 512; e += 512) {                          // thread = (channel, m): one radix-8 butterfly
-            const int c = e >> 9, m = e & 511;
-            combine4096_m(sub + c * 8 * N512_ROW, m, p.tw, X + c * XR);
+        for (int e = tid; e < nfr * 2 * 512; e += 512) {                    // thread = (frame, channel, m): one radix-R butterfly
+            const int jc = e >> 9, m = e & 511;
+            if constexpr (R == 8) combine4096_m(sub + jc * R * N512_ROW, m, p.tw, X + jc * XR);
+            else combine2048_m(sub + jc * R * N512_ROW, m, p.tw, X + jc * XR);
         }
         __syncthreads();
-        OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f) * (long long)p.a_row_elems;
-        float acc = 0.f;
-        for (int k = tid; k < K; k += 512) {
-            const float2 x0 = X[k], x1 = X[XR + k];
-            if (p.power) {
-                // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
-                const float pw = x0.x * x0.x + x0.y * x0.y + x1.x * x1.x + x1.y * x1.y;
-                acc += (k == 0 || k == H) ? pw : 2.f * pw;
+        for (int j = 0; j < nfr; ++j) {
+            OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f + j) * (long long)p.a_row_elems;
+            const float2 *X0 = X + (j * 2) * XR, *X1 = X0 + XR;
+            float acc = 0.f;
+            for (int k = tid; k < K; k += 512) {
+                const float2 x0 = X0[k], x1 = X1[k];
+                if (p.power) {
+                    // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
+                    const float pw = x0.x * x0.x + x0.y * x0.y + x1.x * x1.x + x1.y * x1.y;
+                    acc += (k == 0 || k == H) ? pw : 2.f * pw;
+                }
+                store_a(arow, p, k, cmulc(whiten(x0), whiten(x1)));
             }
-            store_a(arow, p, k, cmulc(whiten(x0), whiten(x1)));
+            if (p.power) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+                if (lane == 0) atomicAdd(&spow[j], acc);
+            }
         }
         if (p.power) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-            if (lane == 0) atomicAdd(spow, acc);
             __syncthreads();
-            if (tid == 0) p.power[(long long)a * p.total_frames + p.frame0 + f] = spow[0] / (4096.f * 4096.f) / 2.f;
+            if (tid < nfr) p.power[(long long)a * p.total_frames + p.frame0 + f + tid] = spow[tid] / ((float)N * (float)N) / 2.f;
         }
         __syncthreads();
     }
 }
 
-template __global__ void k_stft_phat_4096x2<float>(StftPhatArgs);
-template __global__ void k_stft_phat_4096x2<_Float16>(StftPhatArgs);
+template __global__ void k_stft_phat_sub2<8, float>(StftPhatArgs);
+template __global__ void k_stft_phat_sub2<8, _Float16>(StftPhatArgs);
+template __global__ void k_stft_phat_sub2<4, float>(StftPhatArgs);
+template __global__ void k_stft_phat_sub2<4, _Float16>(StftPhatArgs);
 
 // k_mvdr_analyse_512: the analysis stage of the MVDR path (kernels_mvdr.hip: k_mvdr_analyse_1024) for 512-sample frames: wave w
 // transforms channels 2 w, 2 w + 1 of the frame in one pass (up to 16 channels), then the spectra go out transposed,

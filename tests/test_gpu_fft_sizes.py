@@ -101,8 +101,9 @@ def test_any_length_kernels_agree_with_tuned_kernels_at_1024():
     assert np.abs(g["out"] - r["out"]).max() <= 4e-6 * np.abs(r["out"]).max()
 
 
-def test_two_microphone_gcc_at_512():
-    fs, N, F = 16000, 512, 90
+@pytest.mark.parametrize("fs,N,F", [(16000, 512, 90), (32000, 2048, 40), (48000, 4096, 21)])
+def test_two_microphone_gcc_other_frame_lengths(fs, N, F):
+    """512: the any-M tuned kernel; 2048 / 4096 (FreqGCC's 0.075 s frames at 32 / 48 kHz): 512-sample sub-sequences per channel"""
     pcm = synth.noise_source_stream(synth.BINAURAL, np.deg2rad(33.0), fs, (F + 1) * N // 2, 4)
     ctx = api.Context(fs, synth.BINAURAL, N, 3.0, 1)
     r = ctx.gcc2_frames_host(pcm[None], want_corr=True)
