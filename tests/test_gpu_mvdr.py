@@ -223,3 +223,24 @@ def test_module_state_blobs_resume_streams():
     assert np.array_equal(np.concatenate([ra["prob"], rb["prob"]], axis=1), r1["prob"])
     with pytest.raises(api.MCArrayHipError):
         api.MultibandBinarualLocalisation(48000, synth.BINAURAL, 12, False).state_load(l2.state_save())
+
+
+def test_localise_then_mvdr_16_microphones():
+    """BASELINE configs[3] end to end: the 16-microphone localiser (SRP over 361 angles) supplies the look direction per frame,
+    the MVDR beamformer steers with it; both stages against the oracle's (DOA bins bit-exact, then the MVDR audio)."""
+    fs, N, F, A = 48000, 1024, 48, 3
+    xs = synth.ULA16
+    pcm = np.stack([_scene(xs, fs, N, F, a) for a in range(A)])
+    loc = api.Context(fs, xs, N, 0.5, 1, max_arrays=A)
+    r = loc.process_frames_host(pcm, want_audio=False)
+    bf = api.MvdrBeamformer(fs, xs, N, max_streams=A)
+    out = bf.process(pcm, r["doa"][:, :, 0])["out"]
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, 0.5, want_audio=False)
+        assert np.array_equal(r["bin"][a], o["bin"]), a
+        om = po.MVDR(fs, N, xs).stream(pcm[a].astype(np.float64), r["doa"][a, :, 0].astype(np.float64))
+        assert np.abs(out[a] - om["out"]).max() <= AUDIO_TOL * np.abs(om["out"]).max(), a
+    # the localiser settles on one of the two (equally loud) sources of every scene
+    for a in range(A):
+        med = np.rad2deg(np.median(r["doa"][a, 8:, 0]))
+        assert min(abs(med - (20.0 - 30 * a)), abs(med - (-50.0 + 40 * a))) <= 1.0, (a, med)
