@@ -1075,7 +1075,7 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
         if (!ga.prob) ga.prob = c->d_g2_prob;
     }
     const int nslot = GCC2_DOAWARM + ga.chunk;
-    const size_t smem = (size_t)nslot * ((c->D + 3) / 4 * 4 + 4) * sizeof(float) + (size_t)nslot * 3 * sizeof(float);
+    const size_t smem = (size_t)nslot * ((c->D + 3) / 4 * 4 + 4) * sizeof(float) + ((size_t)nslot * 5 + 1) * sizeof(float);
     if (smem > 64 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcc2_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 g((n_frames + ga.chunk - 1) / ga.chunk, n_arrays);

@@ -1132,41 +1132,52 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
         if (lane == 0) { sIdx[tl] = bi; sMin[tl] = mn; sSum[tl] = sm; }
     }
     __syncthreads();
+    // Phase 3a: the angles of the argmaxes (all threads), then ONE thread runs the scalar recursion DOA = m DOA + (1-m) angle
+    // over the kept frames (:504) and leaves the DOA BEFORE every frame in LDS; phase 3b: thread = frame evaluates
+    // setProbability of that previous DOA (:454, :590-630) and writes the outputs.  (The serial thread used to do all of it:
+    // 192 frames x ~800 cycles of dependent LDS reads and divisions per workgroup.)
+    float *sAng = sSum + nslot;                                        // [nslot] doaIdx2angle(argmax)
+    float *sPrev = sAng + nslot;                                       // [nslot + 1] DOA before the frame (entry tl + 1: after it)
+    const int nkept = t_end - keep_start;
+    for (int tl = d; tl < nkept; tl += blockDim.x) sAng[tl] = p.grid[sIdx[tl]];       // :503
+    __syncthreads();
     if (d == 0) {
         float doa = keep_start == 0 ? p.doa_in[a] : 0.f;
-        const float halfpi = 1.57079632679489661923f;
-        for (int t = keep_start; t < t_end; ++t) {
-            const int tl = t - keep_start;
-            const float *cr = sC + tl * Dl;
-            if (t >= t_start) {
-                // setProbability(_currentDOA, _prob, 1) with the DOA of the previous frame (:454)
-                const float mn = sMin[tl];
-                const float sum = sSum[tl] - mn * (float)D;              // :588
-                float ang = fminf(fmaxf(doa, -halfpi), halfpi);          // angle2DOAidx :110-115
-                int idx = (int)((ang + halfpi) / p.step);
-                idx = min(max(idx, 0), D - 1);
-                const float angle = p.grid[idx];
-                float pr;
-                if (0 < idx && idx < D - 1) {
-                    float pc, nc, pd, nd;
-                    if (angle > doa) { pc = cr[idx - 1]; pd = p.grid[idx - 1]; nc = cr[idx]; nd = angle; }
-                    else { pc = cr[idx]; pd = angle; nc = cr[idx + 1]; nd = p.grid[idx + 1]; }
-                    pr = (nc - pc) / (nd - pd) * (doa - pd) + pc;
-                } else pr = cr[idx];
-                float pb = sum > 0.f ? (pr - mn) / sum : 0.f;
-                pb = pb < 0.01f ? 0.f : pb;
-                if (p.prob) p.prob[(long long)a * p.n_frames + (vi ? vi[t] : t)] = pb;
-            }
-            const bool first = (done + t) == 0;
-            const float angle = p.grid[sIdx[tl]];                        // doaIdx2angle(idx) :503
-            doa = first ? angle : (p.doa_mem * doa + p.one_minus_doa_mem * angle);   // :504
-            if (t >= t_start) {
-                const long long o = (long long)a * p.n_frames + (vi ? vi[t] : t);
-                p.argmax[o] = sIdx[tl];
-                if (p.doa_rad) p.doa_rad[o] = doa;
-            }
+        for (int tl = 0; tl < nkept; ++tl) {
+            sPrev[tl] = doa;
+            const bool first = (done + keep_start + tl) == 0;
+            doa = first ? sAng[tl] : (p.doa_mem * doa + p.one_minus_doa_mem * sAng[tl]);   // :504
         }
+        sPrev[nkept] = doa;
         if (t_end == nf) { p.doa_out[a] = doa; p.vdone_out[a] = done + nf; }
+    }
+    __syncthreads();
+    const float halfpi = 1.57079632679489661923f;
+    for (int t = t_start + d; t < t_end; t += blockDim.x) {
+        const int tl = t - keep_start;
+        const float *cr = sC + tl * Dl;
+        const float doa = sPrev[tl];
+        // setProbability(_currentDOA, _prob, 1) with the DOA of the previous frame (:454)
+        const float mn = sMin[tl];
+        const float sum = sSum[tl] - mn * (float)D;                     // :588
+        float ang = fminf(fmaxf(doa, -halfpi), halfpi);                 // angle2DOAidx :110-115
+        int idx = (int)((ang + halfpi) / p.step);
+        idx = min(max(idx, 0), D - 1);
+        const float angle = p.grid[idx];
+        float pr;
+        if (0 < idx && idx < D - 1) {
+            float pc, nc, pd, nd;
+            if (angle > doa) { pc = cr[idx - 1]; pd = p.grid[idx - 1]; nc = cr[idx]; nd = angle; }
+            else { pc = cr[idx]; pd = angle; nc = cr[idx + 1]; nd = p.grid[idx + 1]; }
+            pr = (nc - pc) / (nd - pd) * (doa - pd) + pc;
+        } else pr = cr[idx];
+        float pb = sum > 0.f ? (pr - mn) / sum : 0.f;
+        pb = pb < 0.01f ? 0.f : pb;
+        const float doa_after = sPrev[tl + 1];
+        const long long o = (long long)a * p.n_frames + (vi ? vi[t] : t);
+        if (p.prob) p.prob[o] = pb;
+        p.argmax[o] = sIdx[tl];
+        if (p.doa_rad) p.doa_rad[o] = doa_after;
     }
 }
 
