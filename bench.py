@@ -92,15 +92,30 @@ def main():
     ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "fp16x3"))
     ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of array 0 timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle on all host cores, one array per process (0 = skip)")
+    ap.add_argument("--gather-audio", action="store_true",
+                    help="N > 1: also gather the beamformed audio (2 KB per frame) to rank 0 every step (BASELINE configs[4]: 'RCCL gather of DOA/output')")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the N ranks ourselves.  Nothing has touched the GPU yet (device_count() does not
+        # initialise HIP on this image), and this parent only waits for its children.
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to report a %d-GPU number from fewer devices"
+                             % (args.gpus, n_dev, args.gpus))
+        from mcarray_amd import dist as mdist
+        raise SystemExit(mdist.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -119,32 +134,24 @@ def main():
     assert ctx.D == D and ctx.P == P
     ctx.reserve(A, F)
     pcm, theta = synth_batch([mdist.array_seed(0x5EED0000, g) for g in mine], F, dev)
-    # DOA bin (int32) and probability (fp32) share one 4-byte-word buffer so that the only exchange of the path is ONE
-    # all_gather per step; two buffers alternate so that step i+1 can run while the gather of step i is in flight
-    packed = [torch.empty(2, A, F, 1, dtype=torch.int32, device=dev) for _ in range(2)]
+    # the only exchange of the path (mcarray_amd/dist.py, StepGather): ONE all_gather of the packed DOA bin + probability
+    # buffers per step (RCCL over xGMI, asynchronous, double buffered: it overlaps the next step's kernels), plus, with
+    # --gather-audio, a gather of the beamformed audio to rank 0
+    xg = mdist.StepGather(A, F, 1, dev, audio_samples=F * HOP if args.gather_audio else 0)
     doa_rad = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
-    out = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
-    gathered = [torch.empty(world, 2, A, F, 1, dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
-    pending = [None, None]
-    state = {"i": 0}
+    out_local = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    state = {"last": 0}
 
     def step():
-        b = state["i"] & 1
-        state["i"] += 1
-        if pending[b] is not None:          # the gather that last read this buffer pair (two steps ago)
-            pending[b].wait()
-            pending[b] = None
-        doa_bin, prob = packed[b][0], packed[b][1].view(torch.float32)
+        b = xg.begin_step()
+        doa_bin, prob = xg.doa_buffers(b)
+        out = xg.audio_buffer(b) if args.gather_audio else out_local
         ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=stream)
-        if use_dist:    # RCCL over xGMI, asynchronous: overlaps the next step's kernels
-            pending[b] = dist.all_gather_into_tensor(gathered[b], packed[b], async_op=True)
+        xg.end_step(b)
+        state["last"] = b
 
-    def drain():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+    drain = xg.drain
 
     for _ in range(args.warmup):
         step()
@@ -169,8 +176,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    last = (state["i"] - 1) & 1
-    last_bin = packed[last][0]
+    last = state["last"]
+    last_bin = xg.doa_buffers(last)[0]
     frames_per_step = A * F * world
     value = frames_per_step * args.steps / elapsed
 
@@ -228,16 +235,25 @@ def main():
             "config": {"workload": "BASELINE configs[2] geometry (8-mic ULA 0.04 m, 48 kHz, N=1024, hop 512, 361 angles, "
                                    "1 source, no power floor), %d arrays x %d frames per GPU per step" % (A, F),
                        "arrays_per_gpu": A, "frames_per_array": F, "srp_precision": args.precision,
-                       "parallelism": "arrays sharded over %d GPU(s), all_gather of DOA bins+prob" % world},
+                       "parallelism": "arrays sharded over %d GPU(s), all_gather of DOA bins+prob%s" % (world, " + gather of the beamformed audio to rank 0" if args.gather_audio else "")},
             "algorithmic_GBps": value * BYTES_PER_FRAME / 1e9,
             "hbm_roofline_frac": value * BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world),
             "kernels": kt, "roofline": roof, "cpu_baseline": cpu,
+            "exchange": {"backend": dist.get_backend() if use_dist else None, "gather_audio": bool(args.gather_audio),
+                         "bytes_per_step_per_rank": 8 * A * F + (4 * A * F * HOP if args.gather_audio else 0)},
         }
         print(json.dumps(line))
     if use_dist:
         # the gathered buffers hold every rank's block at its global position
-        if not torch.equal(gathered[last][rank], packed[last]):
-            print("rank %d: gathered DOA buffers do not contain this rank's block" % rank, file=sys.stderr)
+        all_bin, all_prob = xg.gathered_doa(last)
+        mine_bin, mine_prob = xg.doa_buffers(last)
+        ok = torch.equal(all_bin[rank * A:(rank + 1) * A], mine_bin) and torch.equal(all_prob[rank * A:(rank + 1) * A], mine_prob)
+        if args.gather_audio and rank == 0:
+            ok = ok and torch.equal(xg.gathered_audio(last)[:A], xg.audio_buffer(last))
+        if not ok:
+            print("rank %d: gathered buffers do not contain this rank's block" % rank, file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
         dist.destroy_process_group()
 
 

@@ -57,6 +57,9 @@ struct mca_hip_ctx {
     long long gcc2_frames_done = 0;         // (kept in the state header for blob compatibility; the counters below are what runs)
     long long *d_vdone[2] = {nullptr, nullptr};   // 2-mic path: frames that fired so far, per array (double-buffered with d_doa)
     int *d_g2_vidx = nullptr, *d_g2_nv = nullptr; float *d_g2_rad = nullptr, *d_g2_prob = nullptr; size_t g2_rows = 0;   // gated 2-mic path
+    unsigned char *d_g2_reset = nullptr;    // [rows] per fired frame: the memory factors are zero (silence rule)
+    int *d_g2_post0 = nullptr;              // [max_arrays] first frame of the call at which the floor estimate exists
+    int *d_silence = nullptr;               // [max_arrays] _silenceFramesCounter (BinauralLocalisation.cpp:326), stream state
     // workspace
     void *d_A = nullptr; size_t a_bytes = 0;
     float *d_C = nullptr; size_t c_bytes = 0;
@@ -117,6 +120,7 @@ void free_ctx(mca_hip_ctx *c)
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
+    F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
     F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
@@ -479,6 +483,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_last_rad, na * MCA_MAX_SOURCES * 4)) || (rc = zalloc((void **)&c->d_last_prob, na * MCA_MAX_SOURCES * 4)) ||
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
         (rc = zalloc((void **)&c->d_vdone[0], na * 8)) || (rc = zalloc((void **)&c->d_vdone[1], na * 8)) ||
+        (rc = zalloc((void **)&c->d_silence, na * 4)) || (rc = zalloc((void **)&c->d_g2_post0, na * 4)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
@@ -527,6 +532,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
         HIP_TRY(c, hipMemsetAsync(c->d_doa[i], 0, na * 4, st));
         HIP_TRY(c, hipMemsetAsync(c->d_vdone[i], 0, na * 8, st));
     }
+    HIP_TRY(c, hipMemsetAsync(c->d_silence, 0, na * 4, st));
     c->gcc2_frames_done = 0;
     return init_last_state(c, st);
 }
@@ -540,6 +546,7 @@ struct StateHeader {
     long long gcc2_frames_done;
 };
 constexpr unsigned STATE_MAGIC = 0x4d434153u;   // "MCAS"
+constexpr int STATE_VERSION = 2;                // 2: + _silenceFramesCounter per array
 
 unsigned delays_hash(const mca_hip_ctx *c)
 {
@@ -558,6 +565,7 @@ std::vector<StatePart> state_parts(mca_hip_ctx *c)
         {c->d_E[c->e_cur], na * c->D * 4}, {c->d_tail[c->tail_cur], na * c->S * c->H * 4}, {c->d_gate_state, na * 4 * 8},
         {c->d_last_bin, na * MCA_MAX_SOURCES * 4}, {c->d_last_rad, na * MCA_MAX_SOURCES * 4}, {c->d_last_prob, na * MCA_MAX_SOURCES * 4},
         {c->d_doa[c->doa_cur], na * 4}, {c->d_E64[c->e64_cur], (size_t)c->D * 8}, {c->d_vdone[c->doa_cur], na * 8},
+        {c->d_silence, na * 4},
     };
 }
 
@@ -578,7 +586,7 @@ int mca_hip_state_save(mca_hip_ctx *c, void *blob, long long blob_bytes)
     if (!blob || blob_bytes < mca_hip_state_size(c)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is NULL or smaller than mca_hip_state_size()");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipDeviceSynchronize());
-    StateHeader h{STATE_MAGIC, 1, c->M, c->D, c->S, c->H, c->cfg.max_arrays, c->cfg.use_power_floor, delays_hash(c), c->gcc2_frames_done};
+    StateHeader h{STATE_MAGIC, STATE_VERSION, c->M, c->D, c->S, c->H, c->cfg.max_arrays, c->cfg.use_power_floor, delays_hash(c), c->gcc2_frames_done};
     unsigned char *out = static_cast<unsigned char *>(blob);
     std::memcpy(out, &h, sizeof(h)); out += sizeof(h);
     for (const StatePart &p : state_parts(c)) { HIP_TRY(c, hipMemcpy(out, p.ptr, p.bytes, hipMemcpyDeviceToHost)); out += p.bytes; }
@@ -591,7 +599,7 @@ int mca_hip_state_load(mca_hip_ctx *c, const void *blob, long long blob_bytes)
     if (!blob || blob_bytes < (long long)sizeof(StateHeader)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is NULL or truncated");
     StateHeader h;
     std::memcpy(&h, blob, sizeof(h));
-    if (h.magic != STATE_MAGIC || h.version != 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "not a state blob of this library version");
+    if (h.magic != STATE_MAGIC || h.version != STATE_VERSION) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "not a state blob of this library version");
     if (h.M != c->M || h.D != c->D || h.S != c->S || h.H != c->H || h.max_arrays != c->cfg.max_arrays || h.use_floor != c->cfg.use_power_floor ||
         h.delays_hash != delays_hash(c))
         return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob was saved by a context with a different configuration");
@@ -1054,12 +1062,13 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
         const size_t rows = (size_t)n_arrays * n_frames;
         if (rows > c->g2_rows) {
             auto Fr = [](void *q) { if (q) (void)hipFree(q); };
-            Fr(c->d_g2_vidx); Fr(c->d_g2_nv); Fr(c->d_g2_rad); Fr(c->d_g2_prob);
-            c->d_g2_vidx = c->d_g2_nv = nullptr; c->d_g2_rad = c->d_g2_prob = nullptr; c->g2_rows = 0;
+            Fr(c->d_g2_vidx); Fr(c->d_g2_nv); Fr(c->d_g2_rad); Fr(c->d_g2_prob); Fr(c->d_g2_reset);
+            c->d_g2_vidx = c->d_g2_nv = nullptr; c->d_g2_rad = c->d_g2_prob = nullptr; c->d_g2_reset = nullptr; c->g2_rows = 0;
             HIP_TRY(c, hipMalloc((void **)&c->d_g2_vidx, rows * 4));
             HIP_TRY(c, hipMalloc((void **)&c->d_g2_nv, (size_t)c->cfg.max_arrays * 4));
             HIP_TRY(c, hipMalloc((void **)&c->d_g2_rad, rows * 4));
             HIP_TRY(c, hipMalloc((void **)&c->d_g2_prob, rows * 4));
+            HIP_TRY(c, hipMalloc((void **)&c->d_g2_reset, rows));
             c->g2_rows = rows;
         }
         GateArgs gg{};
@@ -1067,10 +1076,13 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
         gg.needed_samples = (int)(3.0 * c->cfg.sample_rate);              // _durationToEstimatePowerFloor (SoundLocalisationImpl.h:77)
         gg.margin_db = 6.f;                                                // _noiseMarginDB (BinauralLocalisation.h:197)
         gg.eps = 1e-10;                                                    // BinauralLocalisation.cpp:391
-        gg.state = c->d_gate_state; gg.voiced = c->d_voiced; gg.power_out = c->d_power_out;
+        gg.state = c->d_gate_state; gg.voiced = c->d_voiced; gg.power_out = c->d_power_out; gg.post0 = c->d_g2_post0;
         hipLaunchKernelGGL(k_gate, dim3(n_arrays), dim3(256), 0, st, gg);
-        hipLaunchKernelGGL(k_gcc2_compact, dim3(n_arrays), dim3(256), 0, st, c->d_voiced, n_frames, c->d_g2_vidx, c->d_g2_nv);
-        ga.vidx = c->d_g2_vidx; ga.nv = c->d_g2_nv;
+        // the silence rule (:530-560): windowsToDecay = 3 * fs / (analysisLength / 2 - 1), int arithmetic, analysisLength = N + 2
+        const int windows_to_decay = 3 * c->cfg.sample_rate / c->H;
+        hipLaunchKernelGGL(k_gcc2_compact, dim3(n_arrays), dim3(256), 0, st, c->d_voiced, n_frames, c->d_g2_vidx, c->d_g2_nv,
+                           c->d_g2_post0, c->d_silence, windows_to_decay, c->d_g2_reset);
+        ga.vidx = c->d_g2_vidx; ga.nv = c->d_g2_nv; ga.vreset = c->d_g2_reset;
         if (!ga.doa_rad) ga.doa_rad = c->d_g2_rad;                         // the hold-over needs them whatever the caller asked for
         if (!ga.prob) ga.prob = c->d_g2_prob;
     }

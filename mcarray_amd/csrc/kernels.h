@@ -34,7 +34,8 @@ __global__ void k_frame_beamform(const C2<T> *X, int M, int K, int fs, const dou
 template <typename T> __global__ void k_frame_power(const C2<T> *X, int M, int K, T *out);
 
 __global__ void k_gcc2_scan(Gcc2ScanArgs p);
-__global__ void k_gcc2_compact(const unsigned char *voiced, int n_frames, int *vidx, int *nv);
+__global__ void k_gcc2_compact(const unsigned char *voiced, int n_frames, int *vidx, int *nv, const int *post0, int *silence,
+                               int windows_to_decay, unsigned char *vreset);
 __global__ void k_gcc2_fill(Gcc2FillArgs p);
 __global__ void k_mask_stream(MaskArgs p);
 __global__ void k_mask_stream_gen(MaskGenArgs p);

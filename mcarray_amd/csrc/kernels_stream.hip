@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void k_gate(GateArgs p)
     if (tid == 0) {
         double acc = st[0], consumed = st[1], floor_db = st[2];
         bool est = st[3] != 0.0;
+        const bool est_at_entry = est;
         int t = 0;
         for (; t < p.n_frames && !est; ++t) {
             acc += (double)pl[t] * (double)p.fft_n + p.eps;              // _powerFloor += FFTPower * (fftCCSLength - 2) :58-59
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(256) void k_gate(GateArgs p)
         }
         st[0] = acc; st[1] = consumed; st[2] = floor_db; st[3] = est ? 1.0 : 0.0;
         s_first_free = t; s_floor = floor_db;
+        if (p.post0) p.post0[a] = est_at_entry ? 0 : (est ? t - 1 : p.n_frames);
     }
     __syncthreads();
     const double floor_db = s_floor;
@@ -1079,6 +1081,7 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
     const int nf = p.nv ? p.nv[a] : p.n_frames;
     const long long done = p.vdone_in[a];
     const int *vi = p.vidx ? p.vidx + (long long)a * p.n_frames : nullptr;
+    const unsigned char *vr = p.vreset ? p.vreset + (long long)a * p.n_frames : nullptr;
     if (nf == 0) {                                                      // nothing fired: the state carries over unchanged
         if (blockIdx.x == 0) {
             if (d < D) p.corr_out[(long long)a * D + d] = p.corr_in[(long long)a * D + d];
@@ -1104,7 +1107,9 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
             for (int i = 0; i < 8; ++i) {
                 const int t = t0 + i;
                 if (t < t_end) {
-                    const bool first = (done + t) == 0;                     // _corrMemoryFactor = 0 on the first frame
+                    // _corrMemoryFactor = 0: on the stream's first frame (:323), or -- with the gate -- on the first
+                    // frame that fires after more than windowsToDecay gated-out frames (:530-560)
+                    const bool first = vr ? vr[t] != 0 : (done + t) == 0;
                     c = first ? r8[i] : (p.one_minus_mu * r8[i] + p.mu * c);   // :445-447
                     if (t >= keep_start) sC[(t - keep_start) * Dl + d] = c;
                     if (t >= t_start && p.corr) p.corr[((long long)a * p.n_frames + (vi ? vi[t] : t)) * D + d] = c;
@@ -1145,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
         float doa = keep_start == 0 ? p.doa_in[a] : 0.f;
         for (int tl = 0; tl < nkept; ++tl) {
             sPrev[tl] = doa;
-            const bool first = (done + keep_start + tl) == 0;
+            const bool first = vr ? vr[keep_start + tl] != 0 : (done + keep_start + tl) == 0;   // _doaMemoryFactor = 0, as above
             doa = first ? sAng[tl] : (p.doa_mem * doa + p.one_minus_doa_mem * sAng[tl]);   // :504
         }
         sPrev[nkept] = doa;
@@ -1182,28 +1187,49 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
 }
 
 // --------------------------------------------------------------------------------------
-// k_gcc2_compact -- the frames of every array that passed the gate, in order (grid (arrays), 256 threads)
+// k_gcc2_compact -- the frames of every array that passed the gate, in order (grid (arrays), 256 threads), and for each
+// of them whether the memory factors are zero when it fires -- the silence rule of BinauralLocalisation.cpp:530-560:
+// every gated-out frame after the floor estimate exists sets the factors to their maxima while _silenceFramesCounter <
+// windowsToDecay and to zero from then on, then increments the counter (:536-559); a frame that fires resets it (:525).
+// So a frame that fires after a run of r such frames restarts the recursions iff r >= windowsToDecay + 1.  The run
+// before the call's first fired frame continues the counter carried in `silence` (per array, updated here).
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gcc2_compact(const unsigned char *voiced, int n_frames, int *vidx, int *nv)
+__global__ __launch_bounds__(256) void k_gcc2_compact(const unsigned char *voiced, int n_frames, int *vidx, int *nv, const int *post0,
+                                                      int *silence, int windows_to_decay, unsigned char *vreset)
 {
-    __shared__ int s_w[4];
+    __shared__ int s_w[4], s_last[4];
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned char *vc = voiced + (long long)a * n_frames;
     int *out = vidx + (long long)a * n_frames;
-    int base = 0;
+    unsigned char *rs = vreset + (long long)a * n_frames;
+    const int sil_in = silence[a], p0 = post0[a];
+    int base = 0, lastf = -1;                       // fired frames so far, the last of them
     for (int t0 = 0; t0 < n_frames; t0 += 256) {
         const int t = t0 + tid;
         const bool v = t < n_frames && vc[t] != 0;
         const unsigned long long m = __ballot(v);
-        if (lane == 0) s_w[wave] = __popcll(m);
+        if (lane == 0) { s_w[wave] = __popcll(m); s_last[wave] = m ? t0 + wave * 64 + 63 - __clzll(m) : -1; }
         __syncthreads();
         int off = base;
         for (int w = 0; w < wave; ++w) off += s_w[w];
-        if (v) out[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        if (v) {
+            const unsigned long long below = m & ((1ull << lane) - 1ull);
+            int prev = lastf;
+            for (int w = 0; w < wave; ++w) if (s_last[w] >= 0) prev = s_last[w];
+            if (below) prev = t0 + wave * 64 + 63 - __clzll(below);
+            const int run = prev >= 0 ? t - prev - 1 : sil_in + (t - p0);
+            const int o = off + __popcll(below);
+            out[o] = t;
+            rs[o] = run >= windows_to_decay + 1 ? 1 : 0;
+        }
         base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        for (int w = 0; w < 4; ++w) if (s_last[w] >= 0) lastf = s_last[w];
         __syncthreads();
     }
-    if (tid == 0) nv[a] = base;
+    if (tid == 0) {
+        nv[a] = base;
+        silence[a] = lastf >= 0 ? n_frames - 1 - lastf : sil_in + (n_frames - p0);   // _silenceFramesCounter at the end of the call
+    }
 }
 
 // --------------------------------------------------------------------------------------

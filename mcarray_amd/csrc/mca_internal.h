@@ -90,6 +90,8 @@ struct GateArgs {
     double *state;           // [arrays][4]
     unsigned char *voiced;   // [arrays][n_frames]
     float *power_out;        // [arrays][n_frames] value handed to setDOA / compared with the floor (may be NULL)
+    int *post0;              // [arrays] first frame of this call at which the floor estimate exists (the frame that completes it
+                             // counts; 0 if it existed before the call, n_frames if it still does not); may be NULL
 };
 
 struct DoaFillArgs {
@@ -122,6 +124,8 @@ struct Gcc2ScanArgs {
     const long long *vdone_in; long long *vdone_out;   // [arrays] voiced frames processed before / after this call (0 = the stream's first)
     const int *vidx;         // [arrays][n_frames] frames that passed the gate, in order (NULL: ungated, every frame)
     const int *nv;           // [arrays] their number (NULL: n_frames)
+    const unsigned char *vreset;   // [arrays][n_frames] per fired frame: 1 = both memory factors are zero at this frame (the
+                             // silence rule, BinauralLocalisation.cpp:530-560); NULL (ungated): only the stream's first frame
     float mu, one_minus_mu;  // _maxCorrMemoryFactor 0.8f and 1 - 0.8f (float arithmetic)
     float doa_mem, one_minus_doa_mem;   // _maxDoaMemoryFactor 0.6f
     float step;              // _doaStep

@@ -602,6 +602,7 @@ struct mca_or_freqgcc {
     float corrMem, doaMem;
     double curDOA, prob;
     double powerFloor; int noiseEstimated; int samplesConsumed;
+    int silenceFramesCounter;                              /* :326 */
 };
 
 mca_or_freqgcc *mca_or_freqgcc_create(int fs, const double *xyz, int M, int ccs_len, int use_floor, double step_deg)
@@ -613,6 +614,7 @@ mca_or_freqgcc *mca_or_freqgcc_create(int fs, const double *xyz, int M, int ccs_
     g->D = mca_or_num_steps(g->step);                      /* :329 */
     g->micDist = mca_or_distance(xyz, 0, 1);               /* :325 */
     g->corrMem = 0; g->doaMem = 0;                         /* :323-324 */
+    g->silenceFramesCounter = 0;                           /* :326 */
     g->curDOA = 0; g->prob = -1;                           /* :339-340 */
     g->delays = (double *)malloc(sizeof(double) * (size_t)g->D);
     g->T = (double *)malloc(sizeof(double) * 2 * (size_t)g->D * g->K);
@@ -673,7 +675,22 @@ int mca_or_freqgcc_process(mca_or_freqgcc *g, const double *left, const double *
         if (argmax_idx) *argmax_idx = idx;
         if (doa_rad) *doa_rad = g->curDOA;
         g->corrMem = maxCorrMem; g->doaMem = maxDoaMem;                              /* :523-524 */
+        g->silenceFramesCounter = 0;                                                 /* :525 */
         return 1;
+    }
+    if (g->noiseEstimated) {                                                         /* :530-560 */
+        /* the memory factors stay at their maxima for 3 s of gated-out frames, then drop to zero: the first frame
+           that fires after a longer silence restarts both recursions (corr = R_t, DOA = raw angle).  Note that the
+           frame which completes the floor estimation already lands here, so with usePowerFloor the factors are at
+           their maxima before any frame can fire (the stream's first fired frame is smoothed against the zero state). */
+        const int secondsToDecay = 3;
+        const int windowsToDecay = secondsToDecay * g->fs / (g->ccs_len / 2 - 1);    /* :533-534, int arithmetic */
+        if (g->silenceFramesCounter < windowsToDecay) {                              /* :536 */
+            g->corrMem = maxCorrMem; g->doaMem = maxDoaMem;                          /* :541-542 (the decay is commented out) */
+        } else {
+            g->corrMem = 0; g->doaMem = 0;                                           /* :556-557 */
+        }
+        ++g->silenceFramesCounter;                                                   /* :559 */
     }
     return 0;
 }

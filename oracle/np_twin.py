@@ -364,6 +364,76 @@ def multiband_stream(fs, N, xs, pcm, nbins=15, use_power_floor=True):
     return out
 
 
+# ---- FreqGCCBinauralLocalisation, whole stream incl. power gate and silence rule (BinauralLocalisation.cpp:387-631) ----
+def freqgcc_set_probability(corr, doa, step):
+    """setProbability :569-631 for one DOA."""
+    D = len(corr)
+    mn = corr.min()
+    total = corr.sum() - mn * D
+    a = float(f32(max(float(f32(doa)), -np.pi / 2)))         # angle2DOAidx, microhponeArrayHelpers.cpp:110-115:
+    a = float(f32(min(a, np.pi / 2)))                        # clamps in double, stored back into the float argument
+    idx = int((a + np.pi / 2) / float(step))
+    angle = float(doaidx2angle(idx, step))
+    if 0 < idx < D - 1:
+        if angle > doa:
+            pc, pd, nc, nd = corr[idx - 1], float(doaidx2angle(idx - 1, step)), corr[idx], angle
+        else:
+            pc, pd, nc, nd = corr[idx], angle, corr[idx + 1], float(doaidx2angle(idx + 1, step))
+        pr = (nc - pc) / (nd - pd) * (doa - pd) + pc
+    else:
+        pr = corr[idx]
+    pr = (pr - mn) / total if total > 0 else 0.0
+    return 0.0 if pr < 0.01 else pr
+
+
+def freqgcc_stream(fs, N, xs, pcm, step_deg=3.0, use_power_floor=True):
+    """Per frame: fired, power, argmax, smoothed corr, smoothed DOA and prob (of the previous DOA, :454).
+
+    The memory factors follow :523-524 (a frame fired -> maxima), :536-542 (fewer than windowsToDecay gated-out
+    frames since -> maxima) and :556-557 (more -> zero): written here as a run length of gated-out frames."""
+    xyz = xyz_of(xs)
+    step = doa_step(step_deg)
+    tau = delay_table(fs, xyz, step_deg)[0]
+    D, K = len(tau), N // 2 + 1
+    X = stft_frames(np.asarray(pcm, dtype=np.float64), N)
+    F = X.shape[0]
+    mu_max, dm_max = float(f32(0.8)), float(f32(0.6))
+    windows_to_decay = (3 * fs) // (N // 2)
+    out = dict(fired=np.zeros(F, bool), power=np.zeros(F), argmax=np.full(F, -1, np.int32), corr=np.zeros((F, D)),
+               doa=np.zeros(F), prob=np.full(F, -1.0), restart=np.zeros(F, bool))
+    prev, cur_doa, cur_prob = np.zeros(D), 0.0, -1.0
+    acc, consumed, est, floor = 0.0, 0, False, 0.0
+    mu, dm = 0.0, 0.0                   # :323-324
+    gated_run = 0                       # gated-out frames since the estimate exists / since the last fired frame
+    for t in range(F):
+        if not est:
+            acc += fft_power([X[t, 0], X[t, 1]], N + 2) * N + 1e-10
+            consumed += N
+            if consumed >= int(3 * fs):
+                est = True
+                floor = 10 * np.log10(acc / consumed) + 6.0
+                acc = floor
+            power = acc
+            thr = acc
+        else:
+            power = 10 * np.log10(fft_power([X[t, 0], X[t, 1]], N + 2))
+            thr = floor
+        out["power"][t] = power
+        if power > thr or not use_power_floor:
+            c = float(f32(1) - f32(mu)) * gcc_phat(X[t, 0], X[t, 1], tau, K).real + mu * prev   # 1 - float factor: float arithmetic
+            prev = c
+            cur_prob = freqgcc_set_probability(c, cur_doa, step)
+            i = int(np.argmax(c))
+            cur_doa = dm * cur_doa + float(f32(1) - f32(dm)) * float(doaidx2angle(i, step))
+            out["fired"][t], out["argmax"][t], out["restart"][t] = True, i, mu == 0.0
+            mu, dm, gated_run = mu_max, dm_max, 0
+        elif est:
+            mu, dm = (mu_max, dm_max) if gated_run < windows_to_decay else (0.0, 0.0)
+            gated_run += 1
+        out["corr"][t], out["doa"][t], out["prob"][t] = prev, cur_doa, cur_prob
+    return out
+
+
 # ---- MVDR-style beamformer with a per-bin spatial covariance (SURVEY A.9, no reference counterpart) ----
 def mvdr_stream(fs, N, xs, pcm, doa_rad, alpha=0.95, loading=1e-3):
     """Independent of the C oracle: full-matrix numpy.linalg.solve instead of the Cholesky / forward-substitution form.

@@ -83,6 +83,24 @@ def freqgcc_case(name, fs, N, d, step_deg, theta_deg, F, seed):
     print(name, "argmax", idxs, "expected angle", [float(np.rad2deg(tw.doaidx2angle(i, step))) for i in idxs[:2]])
 
 
+def freqgcc_gated_case(name, fs, N, d, F, bursts, seed):
+    """usePowerFloor = true with silences around the 3 s decay window (BinauralLocalisation.cpp:530-560): 16-bit PCM (a quiet
+    floor of ~1.5 LSB, loud bursts from two directions), so the fixture stays small and the input is exact in float32."""
+    xs = [0.0, d]
+    hop = N // 2
+    n = (F + 1) * hop
+    srcs = [synth.noise_source_stream(xs, np.deg2rad(a), fs, n, seed + i) for i, a in enumerate((35.0, -50.0))]
+    x = srcs[0] * (1.5 / 32768 / 0.1)
+    for k, (b0, b1) in enumerate(bursts):
+        x[:, b0 * hop:b1 * hop] = srcs[k % 2][:, b0 * hop:b1 * hop]
+    q = np.round(x * 32768).astype(np.int16)
+    r = tw.freqgcc_stream(fs, N, xs, q.astype(np.float32) / 32768, 3.0, True)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), xs=np.asarray(xs), fs=fs, N=N, step_deg=3.0, pcm_i16=q,
+                        fired=r["fired"], restart=r["restart"], argmax=r["argmax"], doa=r["doa"], prob=r["prob"],
+                        power=r["power"], corr_fired=r["corr"][r["fired"]].astype(np.float32))
+    print(name, "fired", np.nonzero(r["fired"])[0], "restarts at", np.nonzero(r["restart"])[0])
+
+
 def multiband_case(name, fs, N, d, nbins, theta_deg, F, seed):
     xs = [0.0, d]
     pcm = synth.noise_source_stream(xs, np.deg2rad(theta_deg), fs, (F + 1) * N // 2, seed)
@@ -113,6 +131,9 @@ if __name__ == "__main__":
     masking_case("mask_factor_temporal", 16000, 1024, 0.086, 500.0, 5000.0, 0, 2, 7, 23)
     masking_case("mask_noisy_spatial", 16000, 1024, 0.086, 500.0, 5000.0, 4, 1, 7, 24, delay=1, nlev=0.003)
     freqgcc_case("freqgcc_16k_d61", 16000, 1024, 0.086, 3.0, 30.0, 6, 31)
+    # 8 kHz -> 512-sample frames (0.075 s, BinauralLocalisation.h:196), windowsToDecay = 3 * 8000 / 256 = 93: the second burst
+    # fires after exactly 94 gated-out frames (the recursions restart), the third after 93 (they do not)
+    freqgcc_gated_case("freqgcc_8k_gated_silence", 8000, 512, 0.086, 256, [(50, 56), (151, 157), (251, 256)], 61)
     multiband_case("multiband_48k_b15", 48000, 1024, 0.086, 15, -35.0, 8, 41)
     mvdr_case("mvdr_ula16_48k", synth.ULA16, 48000, 1024, 6, 51, 25.0, -40.0)
     mvdr_case("mvdr_reemc_16k", synth.REEM_C, 16000, 512, 10, 52, -15.0, 55.0)

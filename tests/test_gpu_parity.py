@@ -385,6 +385,121 @@ def test_freqgcc_power_gate_matches_oracle():
     assert 150 < fired_total <= 2 * 148                        # the bursts after the 47 frames of floor estimation, both arrays
 
 
+def _check_gated_golden(r, g, F):
+    fired = g["fired"][:F]
+    assert np.array_equal(r["voiced"][0].astype(bool), fired)
+    k = 0
+    last = None
+    for t in range(F):
+        if fired[t]:
+            c = g["corr_fired"][k]
+            assert r["argmax"][0, t] == g["argmax"][t], t
+            assert np.abs(r["corr"][0, t] - c).max() <= 2e-5 * np.abs(c).max(), t
+            assert abs(r["doa"][0, t] - g["doa"][t]) <= 2e-5, (t, r["doa"][0, t], g["doa"][t])
+            assert abs(r["prob"][0, t] - g["prob"][t]) <= 2e-4, t
+            k += 1
+            last = t
+        elif last is None:
+            assert r["argmax"][0, t] == -1 and r["doa"][0, t] == 0 and r["prob"][0, t] == -1
+        else:
+            assert r["argmax"][0, t] == r["argmax"][0, last] and r["doa"][0, t] == r["doa"][0, last]
+
+
+def test_freqgcc_silence_rule_matches_golden(golden_dir):
+    """The silence rule of BinauralLocalisation.cpp:530-560 (3 s of gated-out frames zero both memory factors): the golden
+    stream fires after 94 gated-out frames (restart: corr = R_t, DOA = raw angle) and after 93 (no restart); the frame that
+    completes the floor estimation already sets the factors to their maxima, so the first fired frame is smoothed against
+    the zero state.  One call; the silences cut by call boundaries (the counter is carried); a checkpoint inside a silence."""
+    g = _golden(golden_dir, "freqgcc_8k_gated_silence")
+    fs, N = int(g["fs"]), int(g["N"])
+    hop = N // 2
+    pcm = g["pcm_i16"].astype(np.float32) / 32768
+    F = pcm.shape[1] // hop - 1
+    assert list(np.nonzero(g["restart"])[0]) == [150]
+    loc = api.FreqGCCBinauralLocalisation(fs, g["xs"], True, float(g["step_deg"]))
+    assert loc.ctx.N == 512 and loc.ctx.D == 61
+    r = loc.process(pcm, want_corr=True)
+    _check_gated_golden(r, g, F)
+    # restart frame: raw grid angle; frame 250 (93 gated-out frames before it): pulled 0.6 : 0.4
+    grid = loc.ctx.doa_grid()
+    assert r["doa"][0, 150] == grid[r["argmax"][0, 150]]
+    assert abs(r["doa"][0, 250] - (0.6 * r["doa"][0, 249] + 0.4 * grid[r["argmax"][0, 250]])) < 1e-5
+    # the same stream in calls that cut both silences, the estimation phase and a burst
+    for cuts in ([100, 200], [30, 47, 53, 149, 150, 151, 230], [48, 49, 156, 157]):
+        loc.ctx.reset()
+        parts = []
+        b = [0] + cuts + [F]
+        for i in range(len(b) - 1):
+            parts.append(loc.process(pcm[:, b[i] * hop:(b[i + 1] + 1) * hop], want_corr=True))
+        rc = {k: np.concatenate([q[k] for q in parts], axis=1) for k in ("argmax", "doa", "prob", "corr", "voiced")}
+        _check_gated_golden(rc, g, F)
+        assert np.array_equal(rc["argmax"], r["argmax"])
+        np.testing.assert_allclose(rc["doa"], r["doa"], atol=1e-6)
+    # checkpoint in the middle of the long silence, resumed in a fresh context
+    loc.ctx.reset()
+    ra = loc.process(pcm[:, :(120 + 1) * hop], want_corr=True)
+    blob = loc.ctx.state_save()
+    loc2 = api.FreqGCCBinauralLocalisation(fs, g["xs"], True, float(g["step_deg"]))
+    loc2.ctx.state_load(blob)
+    rb = loc2.process(pcm[:, 120 * hop:], want_corr=True)
+    rc = {k: np.concatenate([ra[k], rb[k]], axis=1) for k in ("argmax", "doa", "prob", "corr", "voiced")}
+    _check_gated_golden(rc, g, F)
+
+
+def test_freqgcc_silence_rule_vs_oracle_long_stream():
+    """1024-sample frames at 16 kHz (windowsToDecay = 93), two arrays with different burst patterns in one batch, silences
+    of 92 ... 200 frames, chunked scan (> 128 fired frames), against the C oracle frame by frame."""
+    fs, N, F = 16000, 1024, 900
+    hop = N // 2
+    xs = synth.BINAURAL
+    # a burst over hops [b0, b1) fires frames b0 - 1 ... b1 - 1, so the next burst follows b0' - b1 - 1 gated-out frames
+    patterns = [[(50, 60), (155, 160), (254, 420), (621, 640), (734, 740)],       # gaps: 94 (restart), 93 (none), 200 (restart), 93
+                [(60, 200), (294, 300), (501, 510), (605, 700)]]                   # gaps: 93 (none), 200 (restart), 94 (restart)
+    pcm = []
+    for a, bursts in enumerate(patterns):
+        x = synth.noise_source_stream(xs, np.deg2rad(-40.0 + 60 * a), fs, (F + 1) * hop, 90 + a)
+        y = synth.noise_source_stream(xs, np.deg2rad(25.0 - 70 * a), fs, (F + 1) * hop, 95 + a)
+        env = np.full(F + 1, 0.005)
+        sel = np.zeros(F + 1, bool)
+        for i, (b0, b1) in enumerate(bursts):
+            env[b0:b1] = 1.0
+            if i % 2:
+                sel[b0:b1] = True
+        e, s_ = np.repeat(env, hop), np.repeat(sel, hop)
+        pcm.append(np.where(s_[None, :], y, x) * e[None, :])
+    pcm = np.stack(pcm).astype(np.float32)
+    loc = api.FreqGCCBinauralLocalisation(fs, xs, True, 3.0, max_arrays=2)
+    h = 450
+    ra = loc.process(pcm[:, :, :(h + 1) * hop], want_corr=True)
+    rb = loc.process(pcm[:, :, h * hop:], want_corr=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=1) for k in ("argmax", "doa", "prob", "corr", "voiced")}
+    restarts = []
+    for a in range(2):
+        og = po.FreqGCC(fs, xs, N + 2, True, 3.0)
+        X = po.stft_frames(pcm[a].astype(np.float64), N)
+        prev_doa, run, nbad = 0.0, 0, 0
+        grid = loc.ctx.doa_grid()
+        for t in range(F):
+            voiced, corr, idx, doa, power = og.process(X[t, 0], X[t, 1])
+            assert bool(r["voiced"][a, t]) == voiced, (a, t)
+            if voiced:
+                if run >= 94:
+                    restarts.append((a, t))
+                    assert abs(doa - grid[idx]) < 1e-6                       # the oracle restarted ...
+                    assert r["doa"][a, t] == grid[r["argmax"][a, t]]         # ... and so did the GPU
+                if idx != r["argmax"][a, t]:
+                    assert abs(corr[idx] - corr[r["argmax"][a, t]]) < 1e-5 * np.abs(corr).max()   # numerical tie
+                    nbad += 1
+                assert np.abs(r["corr"][a, t] - corr).max() <= 2e-5 * np.abs(corr).max(), (a, t)
+                assert abs(r["doa"][a, t] - doa) <= 2e-5 + 0.06 * nbad, (a, t)
+                assert abs(r["prob"][a, t] - og.set_probability(np.array([prev_doa]))[0]) <= 2e-4, (a, t)
+                prev_doa, run = doa, 0
+            else:
+                run += 1
+        assert nbad <= 2
+    assert len(restarts) == 4, restarts
+
+
 def _mask_margins(m, X, t_count):
     """oracle decisions plus a flag per (frame, band): decision sits within 1e-4 (relative) of a threshold"""
     decs, near = [], []

@@ -66,6 +66,42 @@ def test_freqgcc_matches_golden(golden_dir):
     assert min(ref[40], ref[41]) - 1e-9 <= mid[0] <= max(ref[40], ref[41]) + 1e-9
 
 
+def test_freqgcc_gate_and_silence_rule_match_golden(golden_dir):
+    """usePowerFloor = true: floor estimation, the gate, and the silence rule of BinauralLocalisation.cpp:530-560 -- the
+    memory factors drop to zero after windowsToDecay (93) gated-out frames, so the burst that follows 94 of them restarts
+    the recursions and the one that follows 93 does not.  Also: the frame that completes the floor estimation already sets
+    the factors to their maxima, so the stream's first fired frame is smoothed against the zero state."""
+    g = _load(golden_dir, "freqgcc_8k_gated_silence")
+    fs, N = int(g["fs"]), int(g["N"])
+    pcm = g["pcm_i16"].astype(np.float64) / 32768
+    fg = po.FreqGCC(fs, g["xs"], N + 2, True, float(g["step_deg"]))
+    X = po.stft_frames(pcm, N)
+    fired = np.nonzero(g["fired"])[0]
+    assert list(np.nonzero(g["restart"])[0]) == [150]
+    assert fired[7] - fired[6] - 1 == 94 and fired[14] - fired[13] - 1 == 93
+    prev_doa, k = 0.0, 0
+    for t in range(X.shape[0]):
+        voiced, corr, idx, doa, power = fg.process(X[t, 0], X[t, 1])
+        assert voiced == bool(g["fired"][t]), t
+        np.testing.assert_allclose(power, g["power"][t], rtol=1e-9)
+        if voiced:
+            assert idx == g["argmax"][t]
+            np.testing.assert_allclose(corr, g["corr_fired"][k], rtol=0, atol=3e-7 * np.abs(corr).max())   # float32 fixture
+            np.testing.assert_allclose(doa, g["doa"][t], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(fg.set_probability(np.array([prev_doa]))[0], g["prob"][t], rtol=0, atol=1e-9)
+            prev_doa = doa
+            k += 1
+    # the restart: corr of frame 150 is the raw GCC-PHAT (no trace of the first burst), its DOA the raw grid angle
+    t = 150
+    assert g["doa"][t] == float(po.doaidx2angle(int(g["argmax"][t]), 3.0))
+    # no restart after 93 gated-out frames: the DOA of frame 250 is pulled 0.6 : 0.4 towards the new source
+    t = 250
+    np.testing.assert_allclose(g["doa"][t], 0.6 * g["doa"][t - 1] + 0.4 * float(po.doaidx2angle(int(g["argmax"][t]), 3.0)), atol=1e-6)
+    # the first fired frame: factors already at their maxima, zero state
+    t = int(fired[0])
+    np.testing.assert_allclose(g["doa"][t], 0.4 * float(po.doaidx2angle(int(g["argmax"][t]), 3.0)), atol=1e-6)
+
+
 def test_multiband_matches_golden(golden_dir):
     g = _load(golden_dir, "multiband_48k_b15")
     N, nb = int(g["N"]), int(g["nbins"])
@@ -106,7 +142,7 @@ def test_multiband_oracle_vs_twin_gated():
 def test_all_golden_files_are_covered(golden_dir):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_dir, "*.npz")))
     assert names == sorted(["ssl_reemc_d37", "ssl_ula8_d361", "ssl_reemc_d37_s2", "mask_relative_both", "mask_full_both",
-                            "mask_factor_temporal", "mask_noisy_spatial", "freqgcc_16k_d61", "multiband_48k_b15",
+                            "mask_factor_temporal", "mask_noisy_spatial", "freqgcc_16k_d61", "freqgcc_8k_gated_silence", "multiband_48k_b15",
                             "mvdr_ula16_48k", "mvdr_reemc_16k"])   # the mvdr_* files are covered by tests/test_oracle_mvdr.py
 
 
