@@ -246,13 +246,17 @@ class StreamGraph:
 
     def __init__(self, ctx, h, keep):
         self.ctx, self.h, self._keep = ctx, h, keep
+        self._lib = ctx._lib
 
     def launch(self, stream=None):
-        self.ctx._check(self.ctx._lib.mca_hip_graph_launch(self.h, stream))
+        rc = self.ctx._lib.mca_hip_graph_launch(self.h, stream)
+        if rc != 0:     # (the context may be gone: its error string then lives in the library, not in the context)
+            raise MCArrayHipError("libmcarray_hip error %d: %s" % (rc, self.ctx._lib.mca_hip_last_error(self.ctx.h).decode()))
 
     def close(self):
-        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
-            self.ctx._lib.mca_hip_graph_destroy(self.h)
+        # safe in either order: a context that is destroyed first orphans its graphs (their recordings go with it)
+        if getattr(self, "h", None):
+            self._lib.mca_hip_graph_destroy(self.h)
         self.h = None
 
     def __del__(self):

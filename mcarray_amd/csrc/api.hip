@@ -25,6 +25,8 @@ struct TimedEvent { int id; hipEvent_t a, b; };
 
 }  // namespace
 
+struct mca_hip_graph;
+
 struct mca_hip_ctx {
     mca_hip_config cfg{};
     std::vector<double> xyz;
@@ -61,6 +63,8 @@ struct mca_hip_ctx {
     int *d_g2_post0 = nullptr;              // [max_arrays] first frame of the call at which the floor estimate exists
     int *d_silence = nullptr;               // [max_arrays] _silenceFramesCounter (BinauralLocalisation.cpp:326), stream state
     // workspace
+    unsigned long long ws_gen = 0;          // bumped whenever a workspace buffer is reallocated: recorded graphs hold the old pointers
+    std::vector<mca_hip_graph *> graphs;   // live graphs of this context (orphaned by mca_hip_destroy)
     void *d_A = nullptr; size_t a_bytes = 0;
     float *d_C = nullptr; size_t c_bytes = 0;
     int c_planes = 1;              // partial maps (split-K) the last contraction left in d_C
@@ -257,7 +261,7 @@ int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
         c->d_A = nullptr; c->a_bytes = 0;
         HIP_TRY(c, hipMalloc(&c->d_A, need_a));
         HIP_TRY(c, hipMemset(c->d_A, 0, need_a));       // the Kp padding columns stay zero forever
-        c->a_bytes = need_a;
+        c->a_bytes = need_a; ++c->ws_gen;
     }
     const int planes = std::max(2, plan_gemm(c, rows_chunk).ksplit);
     size_t need_c = (size_t)rows_total * c->Dp * sizeof(float) * planes;   // room for the partial maps of a split-K contraction
@@ -265,7 +269,7 @@ int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
         if (c->d_C) (void)hipFree(c->d_C);
         c->d_C = nullptr; c->c_bytes = 0;
         HIP_TRY(c, hipMalloc((void **)&c->d_C, need_c));
-        c->c_bytes = need_c;
+        c->c_bytes = need_c; ++c->ws_gen;
     }
     return MCA_HIP_OK;
 }
@@ -281,7 +285,7 @@ int ensure_scan_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chun
         HIP_TRY(c, hipMalloc((void **)&c->d_part, need * c->D * 4));
         HIP_TRY(c, hipMalloc((void **)&c->d_estart, need * c->D * 4));
         HIP_TRY(c, hipMalloc((void **)&c->d_nv, need * 4));
-        c->scan_ws_chunks = need;
+        c->scan_ws_chunks = need; ++c->ws_gen;
     }
     const size_t nf = (size_t)n_arrays * n_frames;
     if (c->cfg.use_power_floor && nf > c->gate_frames) {
@@ -292,7 +296,7 @@ int ensure_scan_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chun
         HIP_TRY(c, hipMalloc((void **)&c->d_power, nf * 4));
         HIP_TRY(c, hipMalloc((void **)&c->d_power_out, nf * 4));
         HIP_TRY(c, hipMalloc((void **)&c->d_voiced, nf));
-        c->gate_frames = nf;
+        c->gate_frames = nf; ++c->ws_gen;
     }
     return MCA_HIP_OK;
 }
@@ -494,11 +498,18 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     return MCA_HIP_OK;
 }
 
+static void graph_drop_recordings(mca_hip_graph *g);
+static void graph_orphan(mca_hip_graph *g);
+
 void mca_hip_destroy(mca_hip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipDeviceSynchronize();
+    // graphs that outlive their context: their recordings point into this context's buffers, so they go now; the handle
+    // stays valid for mca_hip_graph_destroy and fails cleanly in mca_hip_graph_launch
+    for (mca_hip_graph *g : ctx->graphs) graph_orphan(g);
+    ctx->graphs.clear();
     free_ctx(ctx);
 }
 
@@ -888,7 +899,21 @@ struct mca_hip_graph {
     hipStream_t cap = nullptr;                 // recording stream
     hipGraph_t graph[4] = {};                  // one per (e_cur, tail_cur): the state buffers a call reads / writes
     hipGraphExec_t exec[4] = {};
+    unsigned long long ws_gen = 0;             // c->ws_gen the recordings were made under
 };
+
+static void graph_orphan(mca_hip_graph *g);
+// a recording bakes in the workspace pointers (d_A, d_C, scan / gate buffers): drop every recording of the graph
+static void graph_drop_recordings(mca_hip_graph *g)
+{
+    for (int i = 0; i < 4; ++i) {
+        if (g->exec[i]) (void)hipGraphExecDestroy(g->exec[i]);
+        if (g->graph[i]) (void)hipGraphDestroy(g->graph[i]);
+        g->exec[i] = nullptr; g->graph[i] = nullptr;
+    }
+}
+
+static void graph_orphan(mca_hip_graph *g) { graph_drop_recordings(g); g->c = nullptr; }
 
 int mca_hip_graph_create(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride, int n_arrays,
                          int n_frames, int *doa_bin, float *doa_rad, float *prob, float *energy, float *out_pcm,
@@ -906,6 +931,8 @@ int mca_hip_graph_create(mca_hip_ctx *c, const float *pcm, long long array_strid
     g->c = c; g->pcm = pcm; g->array_stride = array_stride; g->mic_stride = mic_stride; g->n_arrays = n_arrays; g->n_frames = n_frames;
     g->doa_bin = doa_bin; g->doa_rad = doa_rad; g->prob = prob; g->energy = energy; g->out_pcm = out_pcm;
     if (hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking) != hipSuccess) { delete g; return fail(c, MCA_HIP_ERR_HIP, "hipStreamCreateWithFlags failed"); }
+    g->ws_gen = c->ws_gen;
+    c->graphs.push_back(g);
     *out = g;
     return MCA_HIP_OK;
 }
@@ -936,7 +963,17 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
 {
     if (!g) return MCA_HIP_ERR_INVALID_ARGUMENT;
     mca_hip_ctx *c = g->c;
+    if (!c) { g_create_error = "mca_hip_graph_launch: the context of this graph has been destroyed"; return MCA_HIP_ERR_INVALID_ARGUMENT; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (g->ws_gen != c->ws_gen) {
+        // an eager call with more arrays / frames reallocated the workspace since the recording: the recorded kernels
+        // would run on freed memory.  Make sure the workspace (still) fits this graph's shape, then record afresh.
+        HIP_TRY(c, hipDeviceSynchronize());      // launches of the old recordings may still be in flight
+        graph_drop_recordings(g);
+        const int rc = mca_hip_reserve(c, g->n_arrays, g->n_frames);
+        if (rc) return rc;
+        g->ws_gen = c->ws_gen;
+    }
     const int idx = c->e_cur | (c->tail_cur << 1);
     if (!g->exec[idx]) {
         const int rc = graph_record(g, idx);
@@ -952,12 +989,13 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
 void mca_hip_graph_destroy(mca_hip_graph *g)
 {
     if (!g) return;
-    (void)hipSetDevice(g->c->cfg.device);
-    (void)hipDeviceSynchronize();
-    for (int i = 0; i < 4; ++i) {
-        if (g->exec[i]) (void)hipGraphExecDestroy(g->exec[i]);
-        if (g->graph[i]) (void)hipGraphDestroy(g->graph[i]);
+    if (g->c) {
+        (void)hipSetDevice(g->c->cfg.device);
+        (void)hipDeviceSynchronize();
+        auto &v = g->c->graphs;
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == g) { v.erase(v.begin() + i); break; }
     }
+    graph_drop_recordings(g);
     if (g->cap) (void)hipStreamDestroy(g->cap);
     delete g;
 }

@@ -59,3 +59,41 @@ def test_graph_rejects_bad_arguments():
         ctx.graph_create(b["pcm"], 5, b["bin"], b["rad"], b["prob"])          # pcm too short for 5 frames
     with pytest.raises(api.MCArrayHipError):
         ctx.graph_create(b["pcm"], 2, b["bin"], None, b["prob"], None, b["out"])   # separation needs doa_rad
+
+
+def test_graph_survives_workspace_growth_and_context_destruction():
+    """A recorded graph bakes in the workspace pointers.  A later eager call with more arrays / frames reallocates the
+    workspace: the next launch must notice (workspace generation counter), re-record and still equal the eager result.
+    A context destroyed before its graph orphans it: launch fails cleanly, destroy is safe."""
+    fs, N, A, F = 48000, 1024, 2, 4
+    hop = N // 2
+    xs = synth.ULA8
+    dev = torch.device("cuda:0")
+    n_chunks = 4
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-35.0 + 50 * a), fs, (n_chunks * F + 1) * hop, 170 + a) for a in range(A)])
+    eager = api.Context(fs, xs, N, 0.5, 1, max_arrays=A)
+    graph = api.Context(fs, xs, N, 0.5, 1, max_arrays=A)
+    be, bg = _bufs(A, 8, F, hop, 1, eager.D, dev), _bufs(A, 8, F, hop, 1, eager.D, dev)
+    g = graph.graph_create(bg["pcm"], F, bg["bin"], bg["rad"], bg["prob"], bg["energy"], bg["out"])
+    st = torch.cuda.current_stream().cuda_stream
+    big = _bufs(A, 8, 700, hop, 1, eager.D, dev)
+    big["pcm"].normal_(0, 0.1)
+    for i in range(n_chunks):
+        chunk = torch.from_numpy(pcm[:, :, i * F * hop:(i * F + F + 1) * hop].copy()).to(dev)
+        be["pcm"].copy_(chunk); bg["pcm"].copy_(chunk)
+        eager.process_frames_dev(be["pcm"], F, be["bin"], be["rad"], be["prob"], be["energy"], be["out"], stream=st)
+        if i == 2:
+            # grow the workspace of the graph's context behind the graph's back (a throw-away state: saved and restored)
+            blob = graph.state_save()
+            graph.process_frames_dev(big["pcm"], 700, big["bin"], big["rad"], big["prob"], big["energy"], big["out"], stream=st)
+            torch.cuda.synchronize()
+            graph.state_load(blob)
+        g.launch(st)
+        torch.cuda.synchronize()
+        for k in ("bin", "rad", "prob", "energy", "out"):
+            assert torch.equal(be[k], bg[k]), (i, k)
+    graph.close()                                   # the context goes first
+    with pytest.raises(api.MCArrayHipError):
+        g.launch(st)
+    g.close()
+    eager.close()
