@@ -30,8 +30,8 @@ import torch  # noqa: E402
 FS, NFFT, HOP, M, STEP_DEG, D, P, K = 48000, 1024, 512, 8, 0.5, 361, 28, 513
 BYTES_PER_FRAME = M * HOP * 4 + HOP * 4 + 8          # 18 440 B (PCM in once, audio out, DOA idx + prob)
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0 TB/s spec
-PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0}   # dense MFMA peaks, same guide
-PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2}
+PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0, "adaptive": 2500.0}   # dense MFMA peaks, same guide
+PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2, "adaptive": 3}
 
 
 def synth_batch(seeds, n_frames, device):
@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--arrays", type=int, default=8, help="independent 8-mic arrays per GPU")
     ap.add_argument("--frames", type=int, default=4096, help="STFT frames per array per step")
-    ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "fp16x3"))
+    ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "adaptive"))
     ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of array 0 timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle on all host cores, one array per process (0 = skip)")
     ap.add_argument("--gather-audio", action="store_true",
@@ -239,6 +239,7 @@ def main():
             "algorithmic_GBps": value * BYTES_PER_FRAME / 1e9,
             "hbm_roofline_frac": value * BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world),
             "kernels": kt, "roofline": roof, "cpu_baseline": cpu,
+            "repair": ctx.repair_stats() if args.precision == "adaptive" else None,
             "exchange": {"backend": dist.get_backend() if use_dist else None, "gather_audio": bool(args.gather_audio),
                          "bytes_per_step_per_rank": 8 * A * F + (4 * A * F * HOP if args.gather_audio else 0)},
         }

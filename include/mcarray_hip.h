@@ -46,7 +46,12 @@ typedef enum {
 typedef enum {
     MCA_HIP_SRP_FP32 = 0,    /* v_mfma_f32_32x32x2_f32, exact fp32 (parity anchor) */
     MCA_HIP_SRP_FP16X3 = 1,  /* fp16 hi/lo split operands, 3 MFMAs per k-step, ~fp32 accuracy */
-    MCA_HIP_SRP_FP16 = 2     /* single fp16 MFMA per k-step (fast; energy map error ~1.5e-5 of the peak) */
+    MCA_HIP_SRP_FP16 = 2,    /* single fp16 MFMA per k-step (fast; energy map error ~1.5e-5 of the peak) */
+    MCA_HIP_SRP_ADAPTIVE = 3 /* fp16 coarse scan of every frame + exact repair: the frames whose peak pick is sensitive to the
+                                fp16 error (and the rows their energy depends on) are recomputed with the FP16X3 split and
+                                picked again, so the DOA bins are those of FP16X3 at about the cost of FP16.  Applies to large
+                                batches on the 1024-sample / 361-angle path without the power gate; every other call of such a
+                                context runs as FP16X3.  The optional energy map keeps fp16 accuracy on unrepaired frames. */
 } mca_hip_srp_precision;
 
 typedef struct mca_hip_ctx mca_hip_ctx;
@@ -342,13 +347,20 @@ typedef enum {
     MCA_HIP_K_GCC2_SCAN = 4,   /* 2-mic correlation smoothing + argmax + probability */
     MCA_HIP_K_MASK = 5,        /* binaural masking */
     MCA_HIP_K_FOLD = 6,        /* sum of the partial maps of a deep split-K contraction (small batches only) */
-    MCA_HIP_K_COUNT = 7
+    MCA_HIP_K_REPAIR = 7,      /* MCA_HIP_SRP_ADAPTIVE: plan + exact recomputation of the sensitive rows + second pick */
+    MCA_HIP_K_COUNT = 8
 } mca_hip_kernel_id;
 /* enable = 1: bracket every launch of the stream API with hipEvents on its stream */
 int mca_hip_set_timing(mca_hip_ctx *ctx, int enable);
 /* synchronises the recorded events; *launches and *total_ms accumulate since the last reset */
 int mca_hip_get_timing(mca_hip_ctx *ctx, int kernel_id, int *launches, double *total_ms);
 int mca_hip_reset_timing(mca_hip_ctx *ctx);
+/* MCA_HIP_SRP_ADAPTIVE: totals since the last mca_hip_reset_timing (synchronises the device): frames that went through the
+ * adaptive path, frames whose pick was flagged as sensitive to the fp16 error (includes the last frame of every array and
+ * call, which is always repeated so that the carried state is exact), and frames whose rows were recomputed exactly.  The
+ * reference has no counterpart (it computes every pair and delay in double, SteeringBeamforming.cpp:104-130). */
+int mca_hip_get_repair_stats(mca_hip_ctx *ctx, unsigned long long *frames, unsigned long long *flagged_frames,
+                             unsigned long long *recomputed_frames);
 
 /* library version string */
 const char *mca_hip_version(void);

@@ -13,10 +13,10 @@ import numpy as np
 from . import _lib
 from ._lib import MCArrayHipError
 
-SRP_FP32, SRP_FP16X3, SRP_FP16 = 0, 1, 2
-K_STFT_PHAT, K_SRP_GEMM, K_SCAN_PICK, K_BEAMFORM, K_GCC2_SCAN, K_MASK, K_FOLD = 0, 1, 2, 3, 4, 5, 6
+SRP_FP32, SRP_FP16X3, SRP_FP16, SRP_ADAPTIVE = 0, 1, 2, 3
+K_STFT_PHAT, K_SRP_GEMM, K_SCAN_PICK, K_BEAMFORM, K_GCC2_SCAN, K_MASK, K_FOLD, K_REPAIR = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {K_STFT_PHAT: "k_stft_phat", K_SRP_GEMM: "k_srp_gemm", K_SCAN_PICK: "k_scan_pick", K_BEAMFORM: "k_beamform_ola",
-                K_FOLD: "k_sum_planes"}
+                K_FOLD: "k_sum_planes", K_REPAIR: "repair"}
 
 
 def _xyz(x):
@@ -233,6 +233,12 @@ class Context:
 
     def reset_timing(self):
         self._check(self._lib.mca_hip_reset_timing(self.h))
+
+    def repair_stats(self):
+        """SRP_ADAPTIVE: dict(frames, flagged, recomputed) since the last reset_timing()"""
+        a, b, c_ = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self._lib.mca_hip_get_repair_stats(self.h, C.byref(a), C.byref(b), C.byref(c_)))
+        return {"frames": a.value, "flagged": b.value, "recomputed": c_.value}
 
     def get_timing(self, kernel_id):
         n = C.c_int(0)
@@ -548,6 +554,12 @@ class MvdrBeamformer(_StateBlob):
 
     def set_timing(self, enable):
         self._check(self._lib.mca_hip_mvdr_set_timing(self.h, int(enable)))
+
+    def repair_stats(self):
+        """SRP_ADAPTIVE: dict(frames, flagged, recomputed) since the last reset_timing()"""
+        a, b, c_ = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self._lib.mca_hip_get_repair_stats(self.h, C.byref(a), C.byref(b), C.byref(c_)))
+        return {"frames": a.value, "flagged": b.value, "recomputed": c_.value}
 
     def get_timing(self, kernel_id):
         n, ms = C.c_int(0), C.c_double(0)

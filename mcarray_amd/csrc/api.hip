@@ -67,6 +67,16 @@ struct mca_hip_ctx {
     std::vector<mca_hip_graph *> graphs;   // live graphs of this context (orphaned by mca_hip_destroy)
     void *d_A = nullptr; size_t a_bytes = 0;
     float *d_C = nullptr; size_t c_bytes = 0;
+    // adaptive SRP precision: fp16 coarse scan (d_A, one plane) + exact repair (d_Ax, hi + lo planes; also the A buffer of
+    // the calls of an ADAPTIVE context that run as plain FP16X3)
+    int tab_planes = 1;            // planes of the steering tables (2: FP16X3 and ADAPTIVE)
+    void *d_Ax = nullptr; size_t ax_bytes = 0;
+    float *d_Cx = nullptr; size_t cx_bytes = 0;
+    unsigned char *d_flags = nullptr; int *d_chunk_flag = nullptr, *d_list = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
+    int *d_nlist = nullptr; unsigned long long *d_rstats = nullptr;
+    unsigned long long adapt_frames_total = 0;
+    float tau_en = 0.f;            // normalised energies closer than this cannot be ordered from the coarse map
+    long long adapt_min_rows = 8192;
     int c_planes = 1;              // partial maps (split-K) the last contraction left in d_C
     long long c_plane = 0;
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
@@ -125,6 +135,7 @@ void free_ctx(mca_hip_ctx *c)
     F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
+    F(c->d_Ax); F(c->d_Cx); F(c->d_flags); F(c->d_chunk_flag); F(c->d_list); F(c->d_nlist); F(c->d_rstats);
     F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
@@ -171,7 +182,7 @@ int build_steering_table(mca_hip_ctx *c)
         HIP_TRY(c, hipMalloc(&c->d_B, B.size() * sizeof(float)));
         HIP_TRY(c, hipMemcpy(c->d_B, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice));
     } else {
-        const int planes = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
+        const int planes = c->tab_planes;
         std::vector<_Float16> B((size_t)planes * Dp * Kp, (_Float16)0.f);
         for (int g = 0; g < c->G; ++g)
             for (int d = 0; d < D; ++d)
@@ -252,17 +263,30 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
     return g;
 }
 
-int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
+// the A buffer of the current call: an ADAPTIVE context keeps its two-plane rows (repair pass, FP16X3 calls) apart from the
+// one-plane rows of the coarse pass, so that a buffer only ever sees one row layout (its Kp padding columns stay zero)
+void *&a_buf(mca_hip_ctx *c) { return (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 2) ? c->d_Ax : c->d_A; }
+size_t &a_buf_bytes(mca_hip_ctx *c) { return (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 2) ? c->ax_bytes : c->a_bytes; }
+
+int ensure_a(mca_hip_ctx *c, long long rows)
 {
     // rows rounded up to the 256-row tile of the split-K MFMA kernel, which loads whole tiles unclamped
-    size_t need_a = (size_t)((rows_chunk + 255) / 256 * 256) * c->a_row_elems * c->a_elem;
-    if (need_a > c->a_bytes) {
-        if (c->d_A) (void)hipFree(c->d_A);
-        c->d_A = nullptr; c->a_bytes = 0;
-        HIP_TRY(c, hipMalloc(&c->d_A, need_a));
-        HIP_TRY(c, hipMemset(c->d_A, 0, need_a));       // the Kp padding columns stay zero forever
-        c->a_bytes = need_a; ++c->ws_gen;
+    size_t need_a = (size_t)((rows + 255) / 256 * 256) * c->a_row_elems * c->a_elem;
+    void *&buf = a_buf(c); size_t &bytes = a_buf_bytes(c);
+    if (need_a > bytes) {
+        if (buf) (void)hipFree(buf);
+        buf = nullptr; bytes = 0;
+        HIP_TRY(c, hipMalloc(&buf, need_a));
+        HIP_TRY(c, hipMemset(buf, 0, need_a));          // the Kp padding columns stay zero forever
+        bytes = need_a; ++c->ws_gen;
     }
+    return MCA_HIP_OK;
+}
+
+int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
+{
+    int rc_a = ensure_a(c, rows_chunk);
+    if (rc_a) return rc_a;
     const int planes = std::max(2, plan_gemm(c, rows_chunk).ksplit);
     size_t need_c = (size_t)rows_total * c->Dp * sizeof(float) * planes;   // room for the partial maps of a split-K contraction
     if (need_c > c->c_bytes) {
@@ -317,6 +341,67 @@ long long chunk_frames_for(const mca_hip_ctx *c, int n_arrays, int n_frames)
     fc = fc / 8 * 8;
     if (fc < 8) fc = 8;
     return fc < n_frames ? fc : n_frames;
+}
+
+// ---- adaptive SRP precision (MCA_HIP_SRP_ADAPTIVE) ------------------------------------------------------------
+void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_row_elems = c->Kp * planes; }
+
+// Does a call of this shape run coarse + repair?  The repair pass needs the list mode of k_stft_phat (1024-sample frames,
+// more than two microphones) and has a fixed cost of a few small launches, so small batches -- which are latency bound
+// whatever the precision -- and gated streams (the rows a frame's energy depends on are then the last VOICED ones) run as
+// plain FP16X3, which is what the repair pass reproduces.
+bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames)
+{
+    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->cfg.use_power_floor && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 &&
+           (long long)n_arrays * n_frames >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
+}
+
+// rows of one repair pass (the two-plane A rows of all listed groups may not fit the workspace budget at once)
+long long repair_pass_rows(const mca_hip_ctx *c, int n_arrays, int n_frames)
+{
+    const long long gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
+    const long long all = (long long)n_arrays * gpa * REPAIR_GROUP;
+    long long cap = ws_max_bytes() / ((long long)2 * c->Kp * 2) / 128 * 128;
+    if (cap < 128) cap = 128;
+    return std::min(all, cap);
+}
+
+int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chunks)
+{
+    const size_t nf = (size_t)n_arrays * n_frames, nc = (size_t)n_arrays * n_chunks;
+    const size_t ng = (size_t)n_arrays * ((n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP);
+    if (nf > c->adapt_frames) {
+        if (c->d_flags) (void)hipFree(c->d_flags);
+        c->d_flags = nullptr; c->adapt_frames = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_flags, nf));
+        c->adapt_frames = nf; ++c->ws_gen;
+    }
+    if (nc > c->adapt_chunks) {
+        if (c->d_chunk_flag) (void)hipFree(c->d_chunk_flag);
+        c->d_chunk_flag = nullptr; c->adapt_chunks = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_chunk_flag, nc * 4));
+        c->adapt_chunks = nc; ++c->ws_gen;
+    }
+    if (ng > c->adapt_groups) {
+        if (c->d_list) (void)hipFree(c->d_list);
+        c->d_list = nullptr; c->adapt_groups = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_list, ng * 4));
+        c->adapt_groups = ng; ++c->ws_gen;
+    }
+    const long long rows = repair_pass_rows(c, n_arrays, n_frames);
+    const int planes = c->a_planes;
+    set_call_planes(c, 2);
+    const int rc = ensure_a(c, rows);
+    set_call_planes(c, planes);
+    if (rc) return rc;
+    const size_t need_cx = (size_t)repair_cx_rows(rows) * c->Dp * sizeof(float);
+    if (need_cx > c->cx_bytes) {
+        if (c->d_Cx) (void)hipFree(c->d_Cx);
+        c->d_Cx = nullptr; c->cx_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_Cx, need_cx));
+        c->cx_bytes = need_cx; ++c->ws_gen;
+    }
+    return MCA_HIP_OK;
 }
 
 template <typename OutT>
@@ -388,7 +473,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     if (cfg->fft_size < 16 || (cfg->fft_size & 1) || cfg->fft_size > 8192) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "fft_size must be even, 16..8192");
     if (cfg->sample_rate <= 0) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "sample_rate <= 0");
     if (!(cfg->doa_step_deg > 0) || cfg->doa_step_deg > 45) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_step_deg must be in (0,45]");
-    if (cfg->srp_precision < 0 || cfg->srp_precision > 2) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "bad srp_precision");
+    if (cfg->srp_precision < 0 || cfg->srp_precision > 3) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "bad srp_precision");
     if (cfg->max_arrays < 1) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "max_arrays < 1");
 
     int ndev = 0;
@@ -456,9 +541,25 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     }
     c->G = c->ula ? c->M - 1 : c->P;
     c->Kp = round_up(c->G * c->K * 2, 32);     // K == KG == 513 on the tuned path
-    c->a_planes = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
+    c->tab_planes = (c->prec == MCA_HIP_SRP_FP16X3 || c->prec == MCA_HIP_SRP_ADAPTIVE) ? 2 : 1;
+    c->a_planes = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;          // (ADAPTIVE: set per call, 1 for the coarse pass, 2 otherwise)
     c->a_elem = c->prec == MCA_HIP_SRP_FP32 ? 4 : 2;
     c->a_row_elems = c->Kp * c->a_planes;
+    {
+        // Error model of the coarse (one fp16 product) map, for the sensitivity test of k_scan_pick: every operand carries
+        // a relative rounding error of rms ~1.8e-4 (11-bit significand), so a term a*b of the contraction is off by
+        // ~2.5e-4 rms and C[d] by sigma_C = 2.5e-4 sqrt(sum_k a_k^2 b_k^2) <= 2.5e-4 sqrt(K/2 sum_g n_g^2) (n_g = pairs per
+        // delay group, |PHAT sum of a group| <= n_g; b = cos / sin).  For a static source the error repeats from frame to
+        // frame, so the 0.8 recursion does not average it: sigma_E = sigma_C.  A difference of two energies is decided at
+        // 8 sigma: tau = 8 sqrt(2) sigma_C, in units of the normalised energy En = (E + 15 P) / (30 P).
+        double sum_n2 = 0;
+        if (c->ula) for (int g = 0; g < c->G; ++g) sum_n2 += (double)(c->M - 1 - g) * (c->M - 1 - g);
+        else sum_n2 = c->P;
+        const double sigma_c = 2.5e-4 * std::sqrt(0.5 * c->K * sum_n2);
+        const double scale = std::getenv("MCA_HIP_ADAPT_TAU_SCALE") ? std::atof(std::getenv("MCA_HIP_ADAPT_TAU_SCALE")) : 1.0;
+        c->tau_en = (float)(scale * 8.0 * std::sqrt(2.0) * sigma_c / (30.0 * c->P));
+        if (std::getenv("MCA_HIP_ADAPT_MIN_ROWS")) c->adapt_min_rows = std::atoll(std::getenv("MCA_HIP_ADAPT_MIN_ROWS"));
+    }
 
     int rc = MCA_HIP_OK;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
@@ -488,6 +589,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
         (rc = zalloc((void **)&c->d_vdone[0], na * 8)) || (rc = zalloc((void **)&c->d_vdone[1], na * 8)) ||
         (rc = zalloc((void **)&c->d_silence, na * 4)) || (rc = zalloc((void **)&c->d_g2_post0, na * 4)) ||
+        (rc = zalloc((void **)&c->d_nlist, 4)) || (rc = zalloc((void **)&c->d_rstats, 16)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
@@ -627,10 +729,17 @@ int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     if (!c || n_arrays < 1 || n_frames < 1) return MCA_HIP_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    int rc;
+    if (c->prec == MCA_HIP_SRP_ADAPTIVE) {
+        const bool adaptive = adaptive_applies(c, n_arrays, n_frames);
+        set_call_planes(c, adaptive ? 1 : 2);
+        if (adaptive && (rc = ensure_adapt_workspace(c, n_arrays, n_frames, n_chunks))) return rc;
+    }
     long long fc = chunk_frames_for(c, n_arrays, n_frames);
-    int rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames);
+    rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames);
     if (rc) return rc;
-    return ensure_scan_workspace(c, n_arrays, n_frames, (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    return ensure_scan_workspace(c, n_arrays, n_frames, n_chunks);
 }
 
 // STFT + PHAT + steering contraction for every frame: fills c->d_C [arrays][n_frames][Dp]
@@ -651,7 +760,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         sa.fpb = 8;
         while (sa.fpb > 1 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 256) sa.fpb >>= 1;
         sa.power = c->cfg.use_power_floor ? c->d_power : nullptr; sa.total_frames = n_frames;
-        sa.window = c->d_window; sa.A = c->d_A; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
+        sa.window = c->d_window; sa.A = a_buf(c); sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         if (c->n512) {
@@ -711,7 +820,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         if (rc) return rc;
 
         GemmArgs ga{};
-        ga.A = c->d_A; ga.B = c->d_B; ga.C = c->d_C; ga.Bt = c->d_Bt;
+        ga.A = a_buf(c); ga.B = c->d_B; ga.C = c->d_C; ga.Bt = c->d_Bt;
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
         ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
         ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
@@ -722,7 +831,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         c->c_planes = ksplit; c->c_plane = ga.c_plane_elems;
         time_begin(c, MCA_HIP_K_SRP_GEMM, st);
         if (v2) {
-            const int np = c->prec == MCA_HIP_SRP_FP16X3 ? 2 : 1;
+            const int np = c->a_planes;
             const size_t smem = (size_t)2 * np * (256 + 384) * 64;        // two 32-deep stages: all 160 KiB with hi + lo planes
             dim3 gv((ga.rows + 255) / 256, ksplit);
 #define V2_LAUNCH(K)                                                                                                      \
@@ -730,15 +839,15 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
                 hipLaunchKernelGGL(K, gv, dim3(512), smem, st, ga);                                                       \
             } while (0)
-            if (c->prec == MCA_HIP_SRP_FP16X3) V2_LAUNCH((k_srp_gemm_f16_v2<true>));
+            if (c->a_planes == 2) V2_LAUNCH((k_srp_gemm_f16_v2<true>));
             else V2_LAUNCH((k_srp_gemm_f16_v2<false>));
 #undef V2_LAUNCH
         } else {
             dim3 g2((ga.rows + 127) / 128, c->Dp == 64 ? 1 : c->Dp / 192, ksplit);
             if (c->prec == MCA_HIP_SRP_FP32) hipLaunchKernelGGL(k_srp_gemm_f32, g2, dim3(256), 0, st, ga);
-            else if (c->Dp == 64 && c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL((k_srp_gemm_f16<true, 64>), g2, dim3(256), 0, st, ga);
+            else if (c->Dp == 64 && c->a_planes == 2) hipLaunchKernelGGL((k_srp_gemm_f16<true, 64>), g2, dim3(256), 0, st, ga);
             else if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_f16<false, 64>), g2, dim3(256), 0, st, ga);
-            else if (c->prec == MCA_HIP_SRP_FP16X3) hipLaunchKernelGGL((k_srp_gemm_f16<true, 192>), g2, dim3(256), 0, st, ga);
+            else if (c->a_planes == 2) hipLaunchKernelGGL((k_srp_gemm_f16<true, 192>), g2, dim3(256), 0, st, ga);
             else hipLaunchKernelGGL((k_srp_gemm_f16<false, 192>), g2, dim3(256), 0, st, ga);
         }
         time_end(c, st);
@@ -764,6 +873,10 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     if (rc) return rc;
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
     hipStream_t st = (hipStream_t)stream;
+    const bool adaptive = adaptive_applies(c, n_arrays, n_frames);
+    if (c->prec == MCA_HIP_SRP_ADAPTIVE) set_call_planes(c, adaptive ? 1 : 2);
+    const int n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (adaptive && (rc = ensure_adapt_workspace(c, n_arrays, n_frames, n_chunks))) return rc;
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
 
     const bool gate = c->cfg.use_power_floor != 0;
@@ -778,11 +891,12 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     }
     ScanPickArgs pa{};
     pa.C = c->d_C; pa.c_planes = c->c_planes; pa.c_plane_stride = c->c_plane; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
-    pa.chunk = SCAN_CHUNK; pa.n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    pa.chunk = SCAN_CHUNK; pa.n_chunks = n_chunks;
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
     pa.state_in = c->d_E[c->e_cur]; pa.state_out = c->d_E[c->e_cur ^ 1];
     pa.part = c->d_part; pa.nvoiced = c->d_nv; pa.e_start = c->d_estart; pa.voiced = gate ? c->d_voiced : nullptr;
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
+    if (adaptive) { pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->d_flags; pa.zero_word = c->d_nlist; }
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
     hipLaunchKernelGGL(k_scan_partial, g3, dim3(nthr), 0, st, pa);
@@ -800,8 +914,69 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     }
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
+    if (adaptive) {
+        // exact repair: list the row groups the flagged frames depend on, recompute them with the hi + lo operand planes and
+        // the three-product contraction, patch them into the map, pick the flagged chunks again (k_scan_pick, mode 2).
+        // Every launch is sized for the worst case (all rows) and exits at the device-side count.
+        time_begin(c, MCA_HIP_K_REPAIR, st);
+        const int gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
+        RepairPlanArgs rp{};
+        rp.flags = c->d_flags; rp.n_frames = n_frames; rp.n_chunks = n_chunks; rp.chunk = SCAN_CHUNK; rp.groups_per_array = gpa;
+        rp.list = c->d_list; rp.n_list = c->d_nlist; rp.chunk_flag = c->d_chunk_flag; rp.stats = c->d_rstats;
+        hipLaunchKernelGGL(k_repair_plan, dim3(n_arrays), dim3(256), 0, st, rp);
+        const long long pass_rows = repair_pass_rows(c, n_arrays, n_frames);
+        const int pass_groups = (int)(pass_rows / REPAIR_GROUP);
+        const long long all_groups = (long long)n_arrays * gpa;
+        set_call_planes(c, 2);
+        for (long long g0 = 0; g0 < all_groups; g0 += pass_groups) {
+            StftPhatArgs sa{};
+            sa.pcm = pcm; sa.array_stride = array_stride; sa.mic_stride = mic_stride;
+            sa.M = c->M; sa.n_frames = n_frames; sa.frame0 = 0; sa.fpb = REPAIR_GROUP; sa.total_frames = n_frames;
+            sa.window = c->d_window; sa.A = c->d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
+            sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
+            sa.list = c->d_list; sa.n_list = c->d_nlist; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = gpa;
+            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
+            // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
+            if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, 512), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
+            GemmArgs ga{};
+            ga.A = c->d_Ax; ga.B = c->d_B; ga.C = c->d_Cx; ga.Bt = c->d_Bt;
+            ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
+            ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
+            ga.n_list = c->d_nlist; ga.list0 = (int)g0;
+            const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
+            const long long max_work = (pass_rows + 127) / 128 * col_tiles * REPAIR_KSPLIT_MAX;
+            dim3 gg((unsigned)std::min<long long>(max_work, 768));
+            if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
+            else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
+            RepairPatchArgs pp{};
+            pp.Cx = c->d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles;
+            pp.list = c->d_list; pp.n_list = c->d_nlist; pp.list0 = (int)g0; pp.groups_per_array = gpa;
+            pp.C = c->d_C; pp.c_planes = c->c_planes; pp.c_plane_stride = c->c_plane; pp.n_frames = n_frames; pp.Dp = c->Dp;
+            hipLaunchKernelGGL(k_repair_patch, dim3(std::min(pass_groups, 1024)), dim3(256), 0, st, pp);
+        }
+        set_call_planes(c, 1);
+        pa.mode = 2; pa.chunk_flag = c->d_chunk_flag;
+        hipLaunchKernelGGL(k_scan_pick, g3, dim3(std::max(nthr, 512)), smem3, st, pa);
+        time_end(c, st);
+        HIP_TRY(c, hipGetLastError());
+        c->adapt_frames_total += (unsigned long long)n_arrays * n_frames;
+    }
     c->last_arrays = n_arrays; c->last_frames = n_frames;
     c->e_cur ^= 1;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_get_repair_stats(mca_hip_ctx *c, unsigned long long *frames, unsigned long long *flagged_frames,
+                             unsigned long long *recomputed_frames)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    unsigned long long st[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(st, c->d_rstats, sizeof(st), hipMemcpyDeviceToHost));
+    if (frames) *frames = c->adapt_frames_total;
+    if (flagged_frames) *flagged_frames = st[0];
+    if (recomputed_frames) *recomputed_frames = st[1] * REPAIR_GROUP;
     return MCA_HIP_OK;
 }
 
@@ -1077,6 +1252,7 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     if (c->Dp > 192) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "the 2-microphone GCC path supports up to 192 steering delays");
     if (!argmax) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "argmax_dev is NULL");
     hipStream_t st = (hipStream_t)stream;
+    if (c->prec == MCA_HIP_SRP_ADAPTIVE) set_call_planes(c, 2);      // the 2-microphone path always runs the exact split
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
     Gcc2ScanArgs ga{};
     ga.C = c->d_C; ga.c_planes = c->c_planes; ga.c_plane_stride = c->c_plane; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D;
@@ -1310,6 +1486,8 @@ int mca_hip_reset_timing(mca_hip_ctx *c)
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
     int rc = drain_events(c);
     for (int i = 0; i < MCA_HIP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_launches[i] = 0; }
+    if (c->d_rstats) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipMemset(c->d_rstats, 0, 16)); }
+    c->adapt_frames_total = 0;
     return rc;
 }
 

@@ -10,6 +10,8 @@ __global__ void k_sum_planes(float *C, long long n4, int planes, long long strid
 __global__ void k_scan_partial(ScanPickArgs p);
 __global__ void k_scan_carry(ScanPickArgs p);
 __global__ void k_scan_pick(ScanPickArgs p);
+__global__ void k_repair_plan(RepairPlanArgs p);
+__global__ void k_repair_patch(RepairPatchArgs p);
 __global__ void k_gate(GateArgs p);
 __global__ void k_doa_fill(DoaFillArgs p);
 template <int CPW, int OCC> __global__ void k_beamform_ola(BeamformArgs p);
@@ -22,6 +24,7 @@ __global__ void k_beamform_gen(BeamformArgs p);
 __global__ void k_srp_gemm_f32(GemmArgs p);
 template <bool SPLIT, int BN> __global__ void k_srp_gemm_f16(GemmArgs p);
 template <bool SPLIT> __global__ void k_srp_gemm_f16_v2(GemmArgs p);
+template <int BN> __global__ void k_srp_gemm_repair(GemmArgs p);
 
 template <typename T> struct C2;
 template <typename T>

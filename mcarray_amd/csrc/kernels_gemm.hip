@@ -118,18 +118,17 @@ constexpr int G16_BM = 128, G16_BK = 32, G16_LD = 40;   // LD in halves (80 B)
 // BN = 192: 4 waves as 2 x 2, wave tile 64 x 96.  BN = 64 (grids of up to 64 angles: the reference's own 37 and
 // the 2-microphone 61): 4 waves as 4 x 1, wave tile 32 x 64 -- a third of the B traffic, LDS and MFMA work of a
 // 192-wide tile whose columns would mostly be padding.
+// one output tile (128 rows x BN columns) over the K range of split z out of ksplit; As / Bs: the workgroup's LDS tiles
 template <bool SPLIT, int BN>
-__global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
+__device__ __forceinline__ void gemm_f16_tile(const GemmArgs &p, int row0, int col0, int z, int ksplit, int n_rows, long long plane_elems,
+                                              _Float16 (*As)[G16_BM][G16_LD], _Float16 (*Bs)[BN][G16_LD])
 {
     constexpr int NP = SPLIT ? 2 : 1;
     constexpr int WN = BN == 192 ? 2 : 1, WM = 4 / WN;            // waves across columns / rows
     constexpr int NI = G16_BM / WM / 32, NJ = BN / WN / 32;       // 32 x 32 MFMA tiles per wave
     constexpr int NBL = BN * 4 / 256;                             // 16-byte B chunks per thread and plane
-    __shared__ __attribute__((aligned(16))) _Float16 As[NP][G16_BM][G16_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[NP][BN][G16_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int row0 = blockIdx.x * G16_BM, col0 = blockIdx.y * BN;
     const _Float16 *A = reinterpret_cast<const _Float16 *>(p.A);
     const _Float16 *B = reinterpret_cast<const _Float16 *>(p.B);
 
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
     // A tile: 128 rows x 4 chunks = 512 chunks -> 2 per thread; B tile: BN x 4 chunks -> NBL per thread.
     const int lr = tid >> 2, lc = tid & 3;
     f16x8 ra[NP][2], rb[NP][NBL];
-    const int ar0 = min(row0 + lr, p.rows - 1), ar1 = min(row0 + lr + 64, p.rows - 1);
+    const int ar0 = min(row0 + lr, n_rows - 1), ar1 = min(row0 + lr + 64, n_rows - 1);
 #define G16_GLOAD(k0)                                                                                                          \
     _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                                                        \
         ra[pl][0] = *reinterpret_cast<const f16x8 *>(A + (long long)ar0 * p.a_row_elems + pl * p.Kp + (k0) + lc * 8);          \
@@ -153,8 +152,8 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
         _Pragma("unroll") for (int i = 0; i < NBL; ++i)                                                                        \
             rb[pl][i] = *reinterpret_cast<const f16x8 *>(B + ((long long)pl * p.Dp + col0 + lr + 64 * i) * p.Kp + (k0) + lc * 8); \
     }
-    const int nk_all = p.Kp / G16_BK, per = (nk_all + gridDim.z - 1) / gridDim.z;   // split-K over blockIdx.z
-    const int kt0 = blockIdx.z * per, nk = min(kt0 + per, nk_all);
+    const int nk_all = p.Kp / G16_BK, per = (nk_all + ksplit - 1) / ksplit;   // split-K over blockIdx.z
+    const int kt0 = z * per, nk = min(kt0 + per, nk_all);
     G16_GLOAD(kt0 * G16_BK)
     for (int kt = kt0; kt < nk; ++kt) {
 #pragma unroll
@@ -197,14 +196,49 @@ __global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int frow = row0 + wm * (32 * NI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (frow < p.rows) {
+            if (frow < n_rows) {
                 const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
-                float *crow = p.C + (long long)blockIdx.z * p.c_plane_elems + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * (32 * NJ) + (lane & 31);
+                float *crow = p.C + (long long)z * plane_elems + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + col0 + wn * (32 * NJ) + (lane & 31);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) crow[j * 32] = acc[i][j][r];
             }
         }
 }
+
+
+template <bool SPLIT, int BN>
+__global__ __launch_bounds__(256) void k_srp_gemm_f16(GemmArgs p)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 As[SPLIT ? 2 : 1][G16_BM][G16_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[SPLIT ? 2 : 1][BN][G16_LD];
+    gemm_f16_tile<SPLIT, BN>(p, blockIdx.x * G16_BM, blockIdx.y * BN, blockIdx.z, gridDim.z, p.rows, p.c_plane_elems, As, Bs);
+}
+
+// The repair contraction of the adaptive SRP precision: the three-product kernel above on however many rows the plan listed.
+// The row count lives on the device, so the launch cannot be sized for it; a fixed, moderate grid walks the work items
+// (row tile, column tile, K split) instead -- a grid sized for the worst case would spend ~90 us retiring empty
+// workgroups.  Partial maps: [repair_ksplit][repair_plane_stride] (mca_internal.h), summed by k_repair_patch.
+template <int BN>
+__global__ __launch_bounds__(256) void k_srp_gemm_repair(GemmArgs p)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][G16_BM][G16_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BN][G16_LD];
+    const int n_rows = min(p.rows, (*p.n_list - p.list0) * REPAIR_GROUP);
+    if (n_rows <= 0) return;
+    const int col_tiles = p.Dp / BN, row_tiles = (n_rows + G16_BM - 1) / G16_BM;
+    const int ksplit = repair_ksplit(n_rows, col_tiles);
+    const long long plane_elems = repair_plane_stride(n_rows, p.Dp);
+    const int n_work = row_tiles * col_tiles * ksplit;
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        // K split fastest: the workgroups that share an output tile (and its A rows) run at the same time
+        const int z = w % ksplit, t = w / ksplit;
+        const int ct = t % col_tiles, rt = t / col_tiles;
+        gemm_f16_tile<true, BN>(p, rt * G16_BM, ct * BN, z, ksplit, n_rows, plane_elems, As, Bs);
+    }
+}
+
+template __global__ void k_srp_gemm_repair<192>(GemmArgs);
+template __global__ void k_srp_gemm_repair<64>(GemmArgs);
 
 template __global__ void k_srp_gemm_f16<false, 192>(GemmArgs);
 template __global__ void k_srp_gemm_f16<true, 192>(GemmArgs);

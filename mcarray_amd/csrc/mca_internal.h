@@ -15,6 +15,8 @@ constexpr int SCAN_WARM = 96;     // frames of IIR warm-up per scan chunk (0.8^9
 constexpr int KG = 513;            // complex K-slots per delay group in the A / B contraction index (g * KG + k)
 constexpr int SCAN_CHUNK = 64;    // frames per chunk of the exact chunked scan
 constexpr int SCAN_SUB = 32;      // frames per LDS sub-batch of k_scan_pick
+constexpr int REPAIR_WARM = 40;   // exact rows recomputed BEFORE a flagged frame (adaptive SRP precision): 0.8^41 = 1e-4 of the coarse error remains
+constexpr int REPAIR_GROUP = 8;   // frames per repair unit = frames per workgroup of k_stft_phat
 
 struct StftPhatArgs {
     const float *pcm;
@@ -30,6 +32,9 @@ struct StftPhatArgs {
     // any-N kernels only (kernels_generic.hip)
     int N, logH, kg, ula;    // frame length, log2(N/2), K-slots per delay group (= N/2 + 1), delay-group merging on/off
     const float2 *tw;        // [N/2] exp(-j 2 pi i / N)
+    // list mode (k_stft_phat only; the repair pass of the adaptive SRP precision): workgroup b takes the REPAIR_GROUP frames of
+    // list[list0 + b] = array * groups_per_array + group and writes A rows b * REPAIR_GROUP ...; b >= *n_list - list0 exits
+    const int *list; const int *n_list; int list0, list_cap, groups_per_array;   // list_cap: groups of this pass at most
 };
 
 __device__ __forceinline__ void store_a(float *row, const StftPhatArgs &, int cidx, float2 v)
@@ -64,6 +69,8 @@ struct GemmArgs {
     int Kp, Dp, a_row_elems;
     long long c_plane_elems;  // elements between the partial maps of a split-K launch
     const void *Bt;          // fp16 steering table tiled for the 256 x 384 kernel: [plane][Kp/32][Dp][32] (a K stage of all columns is contiguous)
+    // device-side row count (repair pass): rows = min(rows, (*n_list - list0) * REPAIR_GROUP); workgroups beyond it exit
+    const int *n_list; int list0;
 };
 
 struct ScanPickArgs {
@@ -79,6 +86,44 @@ struct ScanPickArgs {
     const unsigned char *voiced;   // [arrays][n_frames] 1 = frame passed the power gate; NULL = ungated (all frames)
     const float *grid;       // [D] doaIdx2angle
     int *doa_bin; float *doa_rad; float *prob; float *energy;
+    // adaptive SRP precision (fp16 coarse scan + exact repair of the frames whose pick is sensitive to the fp16 error)
+    int mode;                // 0: plain; 1: coarse pass, writes flags; 2: repair pass over the chunks with chunk_flag set
+    float tau;               // two normalised energies closer than this cannot be ordered from the coarse map
+    unsigned char *flags;    // [arrays][n_frames] 1 = the frame's pick must be repeated on exact rows
+    const int *chunk_flag;   // [arrays][n_chunks] (mode 2) 1 + position of the chunk's first flagged frame, 0 = none
+    int *zero_word;          // (mode 1) the repair list's length, reset by k_scan_carry on its way
+};
+
+constexpr int REPAIR_KSPLIT_MAX = 32;
+// The repair contraction runs on however many rows the plan listed (a device-side count): few rows -> the K range is what
+// parallelises.  Split factor and partial-map stride as a function of the row count, shared by the contraction
+// (k_srp_gemm_f16 with n_list) and k_repair_patch: ~1024 workgroups, at most REPAIR_KSPLIT_MAX partial maps.
+__host__ __device__ inline int repair_ksplit(int n_rows, int col_tiles)
+{
+    const int tiles = (n_rows + 127) / 128 * col_tiles;
+    int k = 1024 / (tiles > 0 ? tiles : 1);
+    return k < 1 ? 1 : (k > REPAIR_KSPLIT_MAX ? REPAIR_KSPLIT_MAX : k);
+}
+__host__ __device__ inline long long repair_plane_stride(int n_rows, int Dp) { return (long long)((n_rows + 127) / 128 * 128) * Dp; }
+// rows x partial maps never exceeds this many rows of Cx (1024 workgroups x 128 rows / 2 column tiles, or one map of all rows)
+__host__ __device__ inline long long repair_cx_rows(long long pass_rows) { return (pass_rows > 131072 ? pass_rows : 131072) + 128 * REPAIR_KSPLIT_MAX; }
+
+struct RepairPlanArgs {
+    const unsigned char *flags;   // [arrays][n_frames]
+    int n_frames, n_chunks, chunk, groups_per_array;
+    int *list;               // [arrays * groups_per_array] groups (REPAIR_GROUP frames) whose rows are recomputed
+    int *n_list;             // [1] their number (zeroed before the launch)
+    int *chunk_flag;         // [arrays][n_chunks] 1 + position of the chunk's first flagged frame, 0 = none
+    unsigned long long *stats;    // [2] running totals: flagged frames, recomputed groups
+};
+
+struct RepairPatchArgs {
+    const float *Cx;         // [repair_ksplit][repair_plane_stride] exact rows, split-K partial maps
+    int pass_rows, col_tiles;
+    const int *list; const int *n_list; int list0, groups_per_array;
+    float *C;                // [c_planes][arrays][n_frames][Dp]: plane 0 takes the exact row, the others zeros
+    int c_planes; long long c_plane_stride;
+    int n_frames, Dp;
 };
 
 struct GateArgs {

@@ -1,0 +1,111 @@
+"""MCA_HIP_SRP_ADAPTIVE: one fp16 MFMA product per k-step for every frame, then an exact repair (hi + lo operand planes,
+three products) of the frames whose peak pick is sensitive to the fp16 error and of the rows their smoothed energy depends
+on (replaces the all-pairs, all-delays double-precision loop nest of SteeringBeamforming.cpp:104-130 + :132-195 at about the
+cost of the plain fp16 mode).  The DOA bins must be those of the exact paths: against the CPU oracle on sizes it can reach
+(adaptive forced onto small batches), and against MCA_HIP_SRP_FP16X3 / MCA_HIP_SRP_FP32 on the GPU at full size."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from mcarray_amd import api, synth
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture
+def force_small(monkeypatch):
+    monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "256")       # read by mca_hip_create: adaptive also for small batches
+
+
+def _assert_bins(gpu_bins, ora_bins, ora_energy, n_pairs, max_ties):
+    """bins equal except numerical ties of the fp32-level paths against the fp64 oracle (as tests/test_gpu_parity.py)"""
+    ties = 0
+    for idx in np.argwhere(gpu_bins != ora_bins):
+        t = idx[0]
+        g, o = int(gpu_bins[tuple(idx)]), int(ora_bins[tuple(idx)])
+        En = (ora_energy[t] + 15.0 * n_pairs) / (30.0 * n_pairs)
+        assert abs(En[g] - En[o]) < 1e-5, "DOA bin mismatch that is not a tie: frame %d gpu %d oracle %d" % (t, g, o)
+        ties += 1
+    assert ties <= max_ties
+    return ties
+
+
+@pytest.mark.parametrize("xs,step,S,thetas", [(synth.ULA8, 0.5, 1, (23.0, -61.5, 79.0)), (synth.REEM_C, 5.0, 2, (-40.0, 10.0, 55.0)),
+                                               (synth.ULA16, 1.0, 1, (5.0, -20.0, 70.0))])
+def test_adaptive_matches_oracle(force_small, xs, step, S, thetas):
+    fs, N, F = 48000, 1024, 330
+    A = len(thetas)
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(th), fs, (F + 1) * N // 2, 900 + i, snr_db=20.0 - 8 * i) for i, th in enumerate(thetas)])
+    ctx = api.Context(fs, xs, N, step, S, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+    ctx.reset_timing()
+    cut = 150                                                   # two calls: the state handed over must be exact as well
+    ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * 512], want_energy=True)
+    rb = ctx.process_frames_host(pcm[:, :, cut * 512:], want_energy=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out", "prob")}
+    st = ctx.repair_stats()
+    assert st["frames"] == A * F and st["flagged"] >= 2 * A and st["recomputed"] >= st["flagged"]
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), S, step, want_map=True)
+        ties = _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=3)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= 2e-4 * np.abs(o["energy"]).max()      # fp16-level map on unrepaired frames
+        if not ties:
+            assert np.abs(r["out"][a] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+
+
+def test_adaptive_context_runs_small_and_gated_calls_as_fp16x3():
+    """below the batch-size threshold and with the power gate an ADAPTIVE context IS the FP16X3 path: bit-identical outputs"""
+    fs, N, F, A = 48000, 1024, 70, 2
+    xs = synth.ULA8
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-30.0 + 50 * a), fs, (F + 1) * N // 2, 40 + a) for a in range(A)])
+    for gate in (False, True):
+        ra = api.Context(fs, xs, N, 0.5, 1, use_power_floor=gate, srp_precision=api.SRP_ADAPTIVE, max_arrays=A).process_frames_host(pcm, want_energy=True)
+        rx = api.Context(fs, xs, N, 0.5, 1, use_power_floor=gate, srp_precision=api.SRP_FP16X3, max_arrays=A).process_frames_host(pcm, want_energy=True)
+        for k in ("bin", "doa", "prob", "energy", "out"):
+            assert np.array_equal(ra[k], rx[k]), (gate, k)
+
+
+@pytest.mark.parametrize("kind,M,S,step", [("static", 8, 1, 0.5), ("noise", 8, 1, 0.5), ("two", 5, 2, 1.0), ("moving", 4, 3, 3.0)])
+def test_adaptive_equals_exact_paths_at_full_size(kind, M, S, step):
+    """GPU only (the oracle cannot reach these sizes): bins of ADAPTIVE == bins of FP16X3, except frames on which the two
+    exact-level paths FP16X3 and FP32 themselves disagree (fp32-level ties); the plain fp16 mode flips on the same data."""
+    import adaptive_check as ac
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1234 + M + S)
+    xs = (0.04 * np.arange(M)).tolist() if M == 8 else np.sort(rng.uniform(0, 0.05 * M, M)).tolist()
+    A, F, cut = 8, 2304, 1031            # two calls of >= 8192 rows each: both run coarse + repair
+    pcm = ac.synth(xs, A, F, kind, rng, dev)
+    from oracle import np_twin as tw
+    res, en = {}, None
+    for name, prec in (("x3", api.SRP_FP16X3), ("fp32", api.SRP_FP32), ("adaptive", api.SRP_ADAPTIVE)):
+        ctx = api.Context(ac.FS, xs, ac.N, step, S, srp_precision=prec, max_arrays=A)
+        ctx.reset_timing()
+        out = ac.run(ctx, pcm, F, S, cut)
+        res[name] = out[0]
+        if name == "x3":
+            en, P = out[2], ctx.P
+        if name == "adaptive":
+            st = ctx.repair_stats()
+        ctx.close()
+    assert st["frames"] == A * F
+    tie = (res["x3"] != res["fp32"]).any(dim=2)                # frames the exact-level paths do not agree on
+    flips = ((res["adaptive"] != res["x3"]).any(dim=2) & ~tie).nonzero().tolist()
+    assert len(flips) <= 4, (len(flips), int(tie.sum()), st)
+    # a remaining difference must be a tie at the exact paths' own error level (FP16X3 vs the fp64 oracle: 2e-6 of the
+    # map's peak): selectDOA of the FP16X3 energy row changes under perturbations of that size
+    prng = np.random.default_rng(5)
+    for a_, t_ in flips:
+        E = en[a_, t_].double().cpu().numpy()
+        base = tw.select_doa(E, P, tw.doa_step(step), S)[2]
+        unstable = any(not np.array_equal(tw.select_doa(E + prng.standard_normal(E.shape) * 2e-6 * np.abs(E).max(), P, tw.doa_step(step), S)[2], base)
+                       for _ in range(32))
+        assert unstable, (a_, t_, res["adaptive"][a_, t_].tolist(), res["x3"][a_, t_].tolist())
+    if kind == "static":
+        assert st["flagged"] < 0.05 * A * F                    # a clear source: few frames need the exact rows

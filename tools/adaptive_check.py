@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""MCA_HIP_SRP_ADAPTIVE against MCA_HIP_SRP_FP16X3 on the GPU, at sizes the CPU oracle cannot reach: the DOA bins must be
+IDENTICAL (the adaptive mode recomputes exactly the frames whose pick is sensitive to the fp16 error); reports the flips of
+the plain fp16 mode on the same data, the flagged / recomputed fractions, and how the measured fp16 error of the normalised
+energy compares with the decision margin tau the sensitivity test assumes.
+usage (GPU box): python tools/adaptive_check.py [cases] [seed] > profiles/rNN_adaptive_check.json"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcarray_amd import api  # noqa: E402
+
+FS, N, HOP = 48000, 1024, 512
+
+
+def synth(xs, n_arrays, n_frames, kind, rng, dev):
+    """[A][M][(F+1)*hop] float32 on the GPU.  kind: 'static' (one far-field white source per array + sensor noise at a random
+    SNR), 'two' (two sources), 'noise' (sensor noise only), 'moving' (the source sweeps ~20 degrees over the call)"""
+    M, L = len(xs), (n_frames + 1) * HOP
+    x_t = torch.tensor(xs, device=dev, dtype=torch.float64)
+    f = torch.fft.rfftfreq(L, d=1.0 / FS).to(device=dev, dtype=torch.float64)
+    out = torch.empty(n_arrays, M, L, device=dev, dtype=torch.float32)
+    for a in range(n_arrays):
+        gen = torch.Generator(device=dev).manual_seed(int(rng.integers(1, 1 << 40)))
+        acc = torch.zeros(M, L, device=dev, dtype=torch.float64)
+        n_src = {"static": 1, "two": 2, "noise": 0, "moving": 1}[kind]
+        for _ in range(n_src):
+            th = np.deg2rad(rng.uniform(-85, 85))
+            s = torch.randn(L, device=dev, dtype=torch.float64, generator=gen) * 0.1 * rng.uniform(0.3, 1.0)
+            if kind == "moving":
+                # piecewise: 16 segments with slightly different angles, cross-faded by construction (each segment delayed on its own)
+                seg = L // 16
+                for i in range(16):
+                    thi = th + np.deg2rad(20.0) * i / 16
+                    si = torch.zeros_like(s)
+                    si[i * seg:(i + 1) * seg if i < 15 else L] = s[i * seg:(i + 1) * seg if i < 15 else L]
+                    adv = x_t * float(np.sin(thi)) / 346.1
+                    acc += torch.fft.irfft(torch.fft.rfft(si)[None, :] * torch.exp(2j * np.pi * f[None, :] * adv[:, None]), n=L, dim=1)
+            else:
+                adv = x_t * float(np.sin(th)) / 346.1
+                acc += torch.fft.irfft(torch.fft.rfft(s)[None, :] * torch.exp(2j * np.pi * f[None, :] * adv[:, None]), n=L, dim=1)
+        snr = rng.uniform(0, 40)
+        acc += torch.randn(M, L, device=dev, dtype=torch.float64, generator=gen) * (0.1 * 10 ** (-snr / 20) if n_src else 0.05)
+        out[a] = acc.clamp_(-1.0, 1.0).to(torch.float32)
+    return out
+
+
+def run(ctx, pcm, F, S, cut):
+    A = pcm.shape[0]
+    dev = pcm.device
+    b = torch.empty(A, F, S, dtype=torch.int32, device=dev)
+    r = torch.empty(A, F, S, dtype=torch.float32, device=dev)
+    p = torch.empty(A, F, S, dtype=torch.float32, device=dev)
+    e = torch.empty(A, F, ctx.D, dtype=torch.float32, device=dev)
+    if cut:
+        # two calls: the state carried between them must be exact as well
+        pa = pcm[:, :, :(cut + 1) * HOP].contiguous()
+        pb = pcm[:, :, cut * HOP:].contiguous()
+        b1, r1, p1, e1 = (torch.empty_like(t[:, :cut]).contiguous() for t in (b, r, p, e))
+        b2, r2, p2, e2 = (torch.empty_like(t[:, cut:]).contiguous() for t in (b, r, p, e))
+        ctx.process_frames_dev(pa, cut, b1, r1, p1, e1, None)
+        ctx.process_frames_dev(pb, F - cut, b2, r2, p2, e2, None)
+        torch.cuda.synchronize()
+        return torch.cat([b1, b2], 1), torch.cat([p1, p2], 1), torch.cat([e1, e2], 1)
+    ctx.process_frames_dev(pcm, F, b, r, p, e, None)
+    torch.cuda.synchronize()
+    return b, p, e
+
+
+def main(cases, seed):
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    rows = []
+    tot = dict(frames=0, adaptive_flips=0, fp16_flips=0, flagged=0, recomputed=0)
+    worst_margin = 0.0
+    for case in range(cases):
+        M = int(rng.choice([3, 4, 5, 8, 8, 8, 16]))
+        ula = bool(rng.integers(0, 2))
+        xs = ((0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))).tolist()
+        step = float(rng.choice([0.5, 0.5, 1.0, 3.0, 5.0]))
+        S = int(rng.choice([1, 1, 2, 3, 4]))
+        A = int(rng.choice([4, 8]))
+        F = int(rng.choice([2048, 2304, 4096]))
+        kind = str(rng.choice(["static", "static", "two", "noise", "moving"]))
+        cut = int(rng.integers(200, F - 200)) if rng.integers(0, 2) else 0
+        pcm = synth(xs, A, F, kind, rng, dev)
+        res = {}
+        for name, prec in (("x3", api.SRP_FP16X3), ("adaptive", api.SRP_ADAPTIVE), ("fp16", api.SRP_FP16)):
+            ctx = api.Context(FS, xs, N, step, S, srp_precision=prec, max_arrays=A)
+            ctx.reset_timing()
+            res[name] = run(ctx, pcm, F, S, cut)
+            if name == "adaptive":
+                st = ctx.repair_stats()
+            P, D = ctx.P, ctx.D
+            ctx.close()
+        fl_a = int((res["adaptive"][0] != res["x3"][0]).sum())
+        fl_16 = int((res["fp16"][0] != res["x3"][0]).sum())
+        # how close a call each adaptive flip was on the FP16X3 map: |En[adaptive's bin] - En[x3's bin]| (normalised energy; the
+        # parity tests call a difference below 1e-5 a numerical tie of the fp32-level paths against the fp64 oracle)
+        gap = 0.0
+        if fl_a:
+            idx = (res["adaptive"][0] != res["x3"][0]).nonzero()
+            En = (res["x3"][2] + 15.0 * P) / (30.0 * P)
+            for a_, t_, s_ in idx.tolist():
+                ba, bx = int(res["adaptive"][0][a_, t_, s_]), int(res["x3"][0][a_, t_, s_])
+                gap = max(gap, abs(float(En[a_, t_, ba]) - float(En[a_, t_, bx])))
+        # measured coarse error of the normalised energy vs the margin: tau decides DIFFERENCES of two energies, so the
+        # per-value budget is tau / 2
+        en_err = float((res["fp16"][2] - res["x3"][2]).abs().max()) / (30.0 * P)
+        sum_n2 = sum((M - 1 - g) ** 2 for g in range(M - 1)) if ula and M > 2 else P
+        tau = 8.0 * np.sqrt(2.0) * 2.5e-4 * np.sqrt(0.5 * 513 * sum_n2) / (30.0 * P)
+        worst_margin = max(worst_margin, en_err / (tau / 2))
+        detail = None
+        if fl_a and os.environ.get("MCA_ADAPT_DEBUG"):
+            # classify: with every frame flagged (tau -> infinity) the result is the repair path alone
+            os.environ["MCA_HIP_ADAPT_TAU_SCALE"] = "1e9"
+            ctx = api.Context(FS, xs, N, step, S, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+            r_all = run(ctx, pcm, F, S, cut)
+            ctx.close()
+            os.environ.pop("MCA_HIP_ADAPT_TAU_SCALE")
+            idx = (res["adaptive"][0] != res["x3"][0]).nonzero().tolist()
+            En = (res["x3"][2] + 15.0 * P) / (30.0 * P)
+            Ec = (res["fp16"][2] + 15.0 * P) / (30.0 * P)
+            detail = dict(flips_with_everything_flagged=int((r_all[0] != res["x3"][0]).sum()), tau=tau, flips=[])
+            for a_, t_, s_ in idx[:8]:
+                ba, bx = int(res["adaptive"][0][a_, t_, s_]), int(res["x3"][0][a_, t_, s_])
+                detail["flips"].append(dict(a=a_, t=t_, s=s_, adaptive=res["adaptive"][0][a_, t_].tolist(), x3=res["x3"][0][a_, t_].tolist(),
+                                            fp16=res["fp16"][0][a_, t_].tolist(), all=r_all[0][a_, t_].tolist(),
+                                            en_x3=[float(En[a_, t_, b_]) for b_ in range(max(0, min(ba, bx) - 3), min(D, max(ba, bx) + 4))][:24],
+                                            en_c=[float(Ec[a_, t_, b_]) for b_ in range(max(0, min(ba, bx) - 3), min(D, max(ba, bx) + 4))][:24]))
+        row = dict(case=case, detail=detail, M=M, ula=ula, step=step, S=S, A=A, F=F, kind=kind, cut=cut, adaptive_flips=fl_a, fp16_flips=fl_16,
+                   flagged=st["flagged"], recomputed=st["recomputed"], adaptive_frames=st["frames"], worst_flip_gap_en=gap,
+                   fp16_en_err_over_half_tau=en_err / (tau / 2))
+        rows.append(row)
+        print(json.dumps(row), file=sys.stderr)
+        tot["frames"] += A * F
+        tot["adaptive_flips"] += fl_a
+        tot["fp16_flips"] += fl_16
+        tot["flagged"] += st["flagged"]
+        tot["recomputed"] += st["recomputed"]
+    out = {"cases": cases, "seed": seed, "totals": tot, "worst_fp16_error_over_half_tau": worst_margin, "rows": rows}
+    print(json.dumps(out, indent=1))
+    return tot["adaptive_flips"]
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
