@@ -27,6 +27,35 @@ struct TimedEvent { int id; hipEvent_t a, b; };
 
 struct mca_hip_graph;
 
+#define MCA_MAX_LANES 4
+
+// Per-call workspace of one LANE.  A large call is split by arrays into up to MCA_MAX_LANES lanes that run on their own
+// HIP streams between a fork and a join on the caller's stream: arrays never interact, so the lanes are independent, and
+// the short latency-bound kernels of one lane (scan carry, repair plan / patch / second pick, launch gaps) run under the
+// long throughput-bound ones (STFT, contraction, beamformer) of another.  State is per array and lives in the context.
+struct Workspace {
+    void *d_A = nullptr; size_t a_bytes = 0;          // A operand: [rows][a_row_elems]
+    void *d_Ax = nullptr; size_t ax_bytes = 0;        // ADAPTIVE: the two-plane A rows (repair pass, FP16X3 calls)
+    float *d_C = nullptr; size_t c_bytes = 0;         // correlation map
+    int c_planes = 1;                                 // partial maps (split-K) the last contraction left in d_C
+    long long c_plane = 0;
+    float *d_Cx = nullptr; size_t cx_bytes = 0;       // ADAPTIVE: partial maps of the repair contraction
+    // exact chunked scan + power gate
+    float *d_part = nullptr, *d_estart = nullptr; int *d_nv = nullptr; size_t scan_ws_chunks = 0;
+    float *d_power = nullptr; unsigned char *d_voiced = nullptr; float *d_power_out = nullptr; size_t gate_frames = 0;
+    // ADAPTIVE: flags, repair list
+    unsigned char *d_flags = nullptr; int *d_chunk_first = nullptr, *d_list = nullptr, *d_need = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
+    int *d_nlist = nullptr;
+    int last_a0 = 0, last_arrays = 0;                 // the arrays this lane ran in the last call (mca_hip_copy_gate)
+    void release()
+    {
+        auto F = [](void *q) { if (q) (void)hipFree(q); };
+        F(d_A); F(d_Ax); F(d_C); F(d_Cx); F(d_part); F(d_estart); F(d_nv); F(d_power); F(d_voiced); F(d_power_out);
+        F(d_flags); F(d_chunk_first); F(d_list); F(d_need); F(d_nlist);
+        *this = Workspace();
+    }
+};
+
 struct mca_hip_ctx {
     mca_hip_config cfg{};
     std::vector<double> xyz;
@@ -34,7 +63,7 @@ struct mca_hip_ctx {
     bool ula = false, stream_ok = false, generic = false, force_v1 = false;
     bool n512 = false;             // 512-sample frames with <= 8 microphones: k_stft_phat_512 / k_beamform_512 instead of the any-length kernels
     std::string stream_why;       // why the stream API is unavailable for this configuration
-    int v2_min_rows = 32768;
+    int v2_min_rows = 16384;       // (a lane of the bench shape: 4 arrays x 4096 frames)
     float step = 0.f;
     std::vector<float> delays, grid;
     std::vector<int2> pairs;
@@ -48,9 +77,13 @@ struct mca_hip_ctx {
     float *d_E[2] = {nullptr, nullptr};
     float *d_tail[2] = {nullptr, nullptr};
     int e_cur = 0, tail_cur = 0;
-    // exact chunked scan + power gate
-    float *d_part = nullptr, *d_estart = nullptr; int *d_nv = nullptr; size_t scan_ws_chunks = 0;
-    float *d_power = nullptr; unsigned char *d_voiced = nullptr; float *d_power_out = nullptr; size_t gate_frames = 0;
+    // lanes (see Workspace)
+    Workspace lanes[MCA_MAX_LANES];
+    int cur_lane = 0, a0 = 0;              // the lane being enqueued and its first array (host side, sequential)
+    int max_lanes = 1, n_lanes_last = 1;   // lanes are off by default: measured 7 % SLOWER with two on the bench shape; MCA_HIP_LANES=n enables them
+    long long lane_min_rows = 8192;
+    hipStream_t lane_stream[MCA_MAX_LANES] = {}; hipEvent_t lane_ev[MCA_MAX_LANES] = {}; hipEvent_t fork_ev = nullptr;
+    Workspace &ws() { return lanes[cur_lane]; }
     double *d_gate_state = nullptr;
     int *d_last_bin = nullptr; float *d_last_rad = nullptr, *d_last_prob = nullptr;
     int last_arrays = 0, last_frames = 0;
@@ -65,20 +98,12 @@ struct mca_hip_ctx {
     // workspace
     unsigned long long ws_gen = 0;          // bumped whenever a workspace buffer is reallocated: recorded graphs hold the old pointers
     std::vector<mca_hip_graph *> graphs;   // live graphs of this context (orphaned by mca_hip_destroy)
-    void *d_A = nullptr; size_t a_bytes = 0;
-    float *d_C = nullptr; size_t c_bytes = 0;
-    // adaptive SRP precision: fp16 coarse scan (d_A, one plane) + exact repair (d_Ax, hi + lo planes; also the A buffer of
-    // the calls of an ADAPTIVE context that run as plain FP16X3)
+    // adaptive SRP precision: fp16 coarse scan (one plane) + exact repair (hi + lo planes)
     int tab_planes = 1;            // planes of the steering tables (2: FP16X3 and ADAPTIVE)
-    void *d_Ax = nullptr; size_t ax_bytes = 0;
-    float *d_Cx = nullptr; size_t cx_bytes = 0;
-    unsigned char *d_flags = nullptr; int *d_chunk_flag = nullptr, *d_list = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
-    int *d_nlist = nullptr; unsigned long long *d_rstats = nullptr;
+    unsigned long long *d_rstats = nullptr;
     unsigned long long adapt_frames_total = 0;
     float tau_en = 0.f;            // normalised energies closer than this cannot be ordered from the coarse map
     long long adapt_min_rows = 8192;
-    int c_planes = 1;              // partial maps (split-K) the last contraction left in d_C
-    long long c_plane = 0;
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
     double *d_fr = nullptr; size_t fr_elems = 0;
@@ -133,10 +158,15 @@ void free_ctx(mca_hip_ctx *c)
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt);
-    F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_A); F(c->d_C); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
+    F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
-    F(c->d_Ax); F(c->d_Cx); F(c->d_flags); F(c->d_chunk_flag); F(c->d_list); F(c->d_nlist); F(c->d_rstats);
-    F(c->d_part); F(c->d_estart); F(c->d_nv); F(c->d_power); F(c->d_voiced); F(c->d_power_out); F(c->d_gate_state);
+    F(c->d_rstats); F(c->d_gate_state);
+    for (Workspace &w : c->lanes) w.release();
+    for (int i = 0; i < MCA_MAX_LANES; ++i) {
+        if (c->lane_ev[i]) (void)hipEventDestroy(c->lane_ev[i]);
+        if (c->lane_stream[i]) (void)hipStreamDestroy(c->lane_stream[i]);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
     c->stage.release();
@@ -265,8 +295,8 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
 
 // the A buffer of the current call: an ADAPTIVE context keeps its two-plane rows (repair pass, FP16X3 calls) apart from the
 // one-plane rows of the coarse pass, so that a buffer only ever sees one row layout (its Kp padding columns stay zero)
-void *&a_buf(mca_hip_ctx *c) { return (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 2) ? c->d_Ax : c->d_A; }
-size_t &a_buf_bytes(mca_hip_ctx *c) { return (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 2) ? c->ax_bytes : c->a_bytes; }
+void *&a_buf(mca_hip_ctx *c) { return (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 2) ? c->ws().d_Ax : c->ws().d_A; }
+size_t &a_buf_bytes(mca_hip_ctx *c) { return (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 2) ? c->ws().ax_bytes : c->ws().a_bytes; }
 
 int ensure_a(mca_hip_ctx *c, long long rows)
 {
@@ -278,6 +308,7 @@ int ensure_a(mca_hip_ctx *c, long long rows)
         buf = nullptr; bytes = 0;
         HIP_TRY(c, hipMalloc(&buf, need_a));
         HIP_TRY(c, hipMemset(buf, 0, need_a));          // the Kp padding columns stay zero forever
+        HIP_TRY(c, hipDeviceSynchronize());             // (the lanes' streams do not wait for the null stream's memset)
         bytes = need_a; ++c->ws_gen;
     }
     return MCA_HIP_OK;
@@ -289,11 +320,11 @@ int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
     if (rc_a) return rc_a;
     const int planes = std::max(2, plan_gemm(c, rows_chunk).ksplit);
     size_t need_c = (size_t)rows_total * c->Dp * sizeof(float) * planes;   // room for the partial maps of a split-K contraction
-    if (need_c > c->c_bytes) {
-        if (c->d_C) (void)hipFree(c->d_C);
-        c->d_C = nullptr; c->c_bytes = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_C, need_c));
-        c->c_bytes = need_c; ++c->ws_gen;
+    if (need_c > c->ws().c_bytes) {
+        if (c->ws().d_C) (void)hipFree(c->ws().d_C);
+        c->ws().d_C = nullptr; c->ws().c_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_C, need_c));
+        c->ws().c_bytes = need_c; ++c->ws_gen;
     }
     return MCA_HIP_OK;
 }
@@ -301,26 +332,26 @@ int ensure_workspace(mca_hip_ctx *c, long long rows_chunk, long long rows_total)
 int ensure_scan_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chunks)
 {
     const size_t need = (size_t)n_arrays * n_chunks;
-    if (need > c->scan_ws_chunks) {
-        if (c->d_part) (void)hipFree(c->d_part);
-        if (c->d_estart) (void)hipFree(c->d_estart);
-        if (c->d_nv) (void)hipFree(c->d_nv);
-        c->d_part = c->d_estart = nullptr; c->d_nv = nullptr; c->scan_ws_chunks = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_part, need * c->D * 4));
-        HIP_TRY(c, hipMalloc((void **)&c->d_estart, need * c->D * 4));
-        HIP_TRY(c, hipMalloc((void **)&c->d_nv, need * 4));
-        c->scan_ws_chunks = need; ++c->ws_gen;
+    if (need > c->ws().scan_ws_chunks) {
+        if (c->ws().d_part) (void)hipFree(c->ws().d_part);
+        if (c->ws().d_estart) (void)hipFree(c->ws().d_estart);
+        if (c->ws().d_nv) (void)hipFree(c->ws().d_nv);
+        c->ws().d_part = c->ws().d_estart = nullptr; c->ws().d_nv = nullptr; c->ws().scan_ws_chunks = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_part, need * c->D * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_estart, need * c->D * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_nv, need * 4));
+        c->ws().scan_ws_chunks = need; ++c->ws_gen;
     }
     const size_t nf = (size_t)n_arrays * n_frames;
-    if (c->cfg.use_power_floor && nf > c->gate_frames) {
-        if (c->d_power) (void)hipFree(c->d_power);
-        if (c->d_voiced) (void)hipFree(c->d_voiced);
-        if (c->d_power_out) (void)hipFree(c->d_power_out);
-        c->d_power = c->d_power_out = nullptr; c->d_voiced = nullptr; c->gate_frames = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_power, nf * 4));
-        HIP_TRY(c, hipMalloc((void **)&c->d_power_out, nf * 4));
-        HIP_TRY(c, hipMalloc((void **)&c->d_voiced, nf));
-        c->gate_frames = nf; ++c->ws_gen;
+    if (c->cfg.use_power_floor && nf > c->ws().gate_frames) {
+        if (c->ws().d_power) (void)hipFree(c->ws().d_power);
+        if (c->ws().d_voiced) (void)hipFree(c->ws().d_voiced);
+        if (c->ws().d_power_out) (void)hipFree(c->ws().d_power_out);
+        c->ws().d_power = c->ws().d_power_out = nullptr; c->ws().d_voiced = nullptr; c->ws().gate_frames = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_power, nf * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_power_out, nf * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_voiced, nf));
+        c->ws().gate_frames = nf; ++c->ws_gen;
     }
     return MCA_HIP_OK;
 }
@@ -370,23 +401,35 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
 {
     const size_t nf = (size_t)n_arrays * n_frames, nc = (size_t)n_arrays * n_chunks;
     const size_t ng = (size_t)n_arrays * ((n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP);
-    if (nf > c->adapt_frames) {
-        if (c->d_flags) (void)hipFree(c->d_flags);
-        c->d_flags = nullptr; c->adapt_frames = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_flags, nf));
-        c->adapt_frames = nf; ++c->ws_gen;
+    if (nf > c->ws().adapt_frames) {
+        if (c->ws().d_flags) (void)hipFree(c->ws().d_flags);
+        c->ws().d_flags = nullptr; c->ws().adapt_frames = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_flags, nf));
+        c->ws().adapt_frames = nf; ++c->ws_gen;
     }
-    if (nc > c->adapt_chunks) {
-        if (c->d_chunk_flag) (void)hipFree(c->d_chunk_flag);
-        c->d_chunk_flag = nullptr; c->adapt_chunks = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_chunk_flag, nc * 4));
-        c->adapt_chunks = nc; ++c->ws_gen;
+    if (nc > c->ws().adapt_chunks) {
+        if (c->ws().d_chunk_first) (void)hipFree(c->ws().d_chunk_first);
+        c->ws().d_chunk_first = nullptr; c->ws().adapt_chunks = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_chunk_first, nc * 4));
+        HIP_TRY(c, hipMemset(c->ws().d_chunk_first, 0x7f, nc * 4));       // "no flagged frame"; kept so by k_scan_repick
+        HIP_TRY(c, hipDeviceSynchronize());
+        c->ws().adapt_chunks = nc; ++c->ws_gen;
     }
-    if (ng > c->adapt_groups) {
-        if (c->d_list) (void)hipFree(c->d_list);
-        c->d_list = nullptr; c->adapt_groups = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_list, ng * 4));
-        c->adapt_groups = ng; ++c->ws_gen;
+    if (ng > c->ws().adapt_groups) {
+        if (c->ws().d_list) (void)hipFree(c->ws().d_list);
+        if (c->ws().d_need) (void)hipFree(c->ws().d_need);
+        c->ws().d_list = c->ws().d_need = nullptr; c->ws().adapt_groups = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_list, ng * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_need, ng * 4));
+        HIP_TRY(c, hipMemset(c->ws().d_need, 0, ng * 4));                 // test-and-set words; released by k_repair_patch
+        HIP_TRY(c, hipDeviceSynchronize());
+        c->ws().adapt_groups = ng; ++c->ws_gen;
+    }
+    if (!c->ws().d_nlist) {
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_nlist, 4));
+        HIP_TRY(c, hipMemset(c->ws().d_nlist, 0, 4));
+        HIP_TRY(c, hipDeviceSynchronize());
+        ++c->ws_gen;
     }
     const long long rows = repair_pass_rows(c, n_arrays, n_frames);
     const int planes = c->a_planes;
@@ -395,11 +438,11 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
     set_call_planes(c, planes);
     if (rc) return rc;
     const size_t need_cx = (size_t)repair_cx_rows(rows) * c->Dp * sizeof(float);
-    if (need_cx > c->cx_bytes) {
-        if (c->d_Cx) (void)hipFree(c->d_Cx);
-        c->d_Cx = nullptr; c->cx_bytes = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_Cx, need_cx));
-        c->cx_bytes = need_cx; ++c->ws_gen;
+    if (need_cx > c->ws().cx_bytes) {
+        if (c->ws().d_Cx) (void)hipFree(c->ws().d_Cx);
+        c->ws().d_Cx = nullptr; c->ws().cx_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_Cx, need_cx));
+        c->ws().cx_bytes = need_cx; ++c->ws_gen;
     }
     return MCA_HIP_OK;
 }
@@ -512,6 +555,8 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     }
     c->n512 = c->N == 512 && c->M <= 8 && c->stream_ok && std::getenv("MCA_HIP_NO_N512") == nullptr;
     c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switches for measurements
+    if (std::getenv("MCA_HIP_LANES")) c->max_lanes = std::max(1, std::min(MCA_MAX_LANES, std::atoi(std::getenv("MCA_HIP_LANES"))));
+    if (std::getenv("MCA_HIP_LANE_MIN_ROWS")) c->lane_min_rows = std::max(1LL, std::atoll(std::getenv("MCA_HIP_LANE_MIN_ROWS")));
     if (std::getenv("MCA_HIP_V2_MIN_ROWS")) c->v2_min_rows = std::atoi(std::getenv("MCA_HIP_V2_MIN_ROWS"));
 
     // generateLookupTable (SteeringBeamforming.cpp:58-94): pairs i<j lexicographic, float delays
@@ -589,7 +634,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
         (rc = zalloc((void **)&c->d_vdone[0], na * 8)) || (rc = zalloc((void **)&c->d_vdone[1], na * 8)) ||
         (rc = zalloc((void **)&c->d_silence, na * 4)) || (rc = zalloc((void **)&c->d_g2_post0, na * 4)) ||
-        (rc = zalloc((void **)&c->d_nlist, 4)) || (rc = zalloc((void **)&c->d_rstats, 16)) ||
+        (rc = zalloc((void **)&c->d_rstats, 16)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
@@ -725,10 +770,9 @@ int mca_hip_state_load(mca_hip_ctx *c, const void *blob, long long blob_bytes)
     return MCA_HIP_OK;
 }
 
-int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
+// workspace of one lane for a call of n_arrays x n_frames
+static int reserve_lane(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
-    if (!c || n_arrays < 1 || n_frames < 1) return MCA_HIP_ERR_INVALID_ARGUMENT;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
     int rc;
     if (c->prec == MCA_HIP_SRP_ADAPTIVE) {
@@ -742,7 +786,30 @@ int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
     return ensure_scan_workspace(c, n_arrays, n_frames, n_chunks);
 }
 
-// STFT + PHAT + steering contraction for every frame: fills c->d_C [arrays][n_frames][Dp]
+static int reserve_impl(mca_hip_ctx *c, int n_arrays, int n_frames, bool single_lane)
+{
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int nl = 1;
+    if (!single_lane && c->max_lanes > 1 && n_arrays >= 2) {
+        long long n = (long long)n_arrays * n_frames / c->lane_min_rows;
+        nl = (int)std::max<long long>(1, std::min<long long>(n, std::min(c->max_lanes, n_arrays)));
+    }
+    int rc = MCA_HIP_OK;
+    for (int i = 0; i < nl && !rc; ++i) {
+        c->cur_lane = i;
+        rc = reserve_lane(c, n_arrays / nl + (i < n_arrays % nl ? 1 : 0), n_frames);
+    }
+    c->cur_lane = 0;
+    return rc;
+}
+
+int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
+{
+    if (!c || n_arrays < 1 || n_frames < 1) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    return reserve_impl(c, n_arrays, n_frames, false);
+}
+
+// STFT + PHAT + steering contraction for every frame: fills c->ws().d_C [arrays][n_frames][Dp]
 static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
                                int n_arrays, int n_frames, hipStream_t st)
 {
@@ -759,7 +826,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         // so that a few hundred workgroups exist
         sa.fpb = 8;
         while (sa.fpb > 1 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 256) sa.fpb >>= 1;
-        sa.power = c->cfg.use_power_floor ? c->d_power : nullptr; sa.total_frames = n_frames;
+        sa.power = c->cfg.use_power_floor ? c->ws().d_power : nullptr; sa.total_frames = n_frames;
         sa.window = c->d_window; sa.A = a_buf(c); sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
@@ -820,7 +887,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         if (rc) return rc;
 
         GemmArgs ga{};
-        ga.A = a_buf(c); ga.B = c->d_B; ga.C = c->d_C; ga.Bt = c->d_Bt;
+        ga.A = a_buf(c); ga.B = c->d_B; ga.C = c->ws().d_C; ga.Bt = c->d_Bt;
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
         ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
         ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
@@ -828,7 +895,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         // suits the full-size chunks; a shorter last chunk may still fall back to the 128 x 192 kernel
         const bool v2 = plan_gemm(c, ga.rows).v2;
         const int ksplit = plan_gemm(c, (long long)n_arrays * fc).ksplit;
-        c->c_planes = ksplit; c->c_plane = ga.c_plane_elems;
+        c->ws().c_planes = ksplit; c->ws().c_plane = ga.c_plane_elems;
         time_begin(c, MCA_HIP_K_SRP_GEMM, st);
         if (v2) {
             const int np = c->a_planes;
@@ -853,26 +920,25 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
     }
-    if (c->c_planes > 2) {      // deep split-K of a small batch: fold the partial maps once, the scans read one map
-        const long long n4 = c->c_plane / 4;       // Dp is a multiple of 64
+    if (c->ws().c_planes > 2) {      // deep split-K of a small batch: fold the partial maps once, the scans read one map
+        const long long n4 = c->ws().c_plane / 4;       // Dp is a multiple of 64
         time_begin(c, MCA_HIP_K_FOLD, st);
-        hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, c->d_C, n4, c->c_planes, c->c_plane);
+        hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, c->ws().d_C, n4, c->ws().c_planes, c->ws().c_plane);
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
-        c->c_planes = 1;
+        c->ws().c_planes = 1;
     }
 
     return MCA_HIP_OK;
 }
 
-int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
-                                int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
-                                float *energy, void *stream)
+// the localisation stage of the arrays [c->a0, c->a0 + n_arrays) on the workspace of lane c->cur_lane; all pointers already
+// point at the lane's first array
+static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                         int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob, float *energy, hipStream_t st)
 {
-    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
-    if (rc) return rc;
-    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
-    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const size_t a0 = (size_t)c->a0;
     const bool adaptive = adaptive_applies(c, n_arrays, n_frames);
     if (c->prec == MCA_HIP_SRP_ADAPTIVE) set_call_planes(c, adaptive ? 1 : 2);
     const int n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -883,20 +949,24 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     time_begin(c, MCA_HIP_K_SCAN_PICK, st);
     if (gate) {
         GateArgs gg{};
-        gg.power_lin = c->d_power; gg.n_frames = n_frames; gg.fft_n = c->N;
+        gg.power_lin = c->ws().d_power; gg.n_frames = n_frames; gg.fft_n = c->N;
         gg.needed_samples = (int)(3.0 * c->cfg.sample_rate);              // _durationToEstimatePowerFloor (SoundLocalisationImpl.h:77)
         gg.margin_db = 3.f;                                                // _noiseMarginDB (BeamformingSeparationAndLocalistaion.h:52)
-        gg.state = c->d_gate_state; gg.voiced = c->d_voiced; gg.power_out = c->d_power_out;
+        gg.state = c->d_gate_state + a0 * 4; gg.voiced = c->ws().d_voiced; gg.power_out = c->ws().d_power_out;
         hipLaunchKernelGGL(k_gate, dim3(n_arrays), dim3(256), 0, st, gg);
     }
     ScanPickArgs pa{};
-    pa.C = c->d_C; pa.c_planes = c->c_planes; pa.c_plane_stride = c->c_plane; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
+    pa.C = c->ws().d_C; pa.c_planes = c->ws().c_planes; pa.c_plane_stride = c->ws().c_plane; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
     pa.chunk = SCAN_CHUNK; pa.n_chunks = n_chunks;
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
-    pa.state_in = c->d_E[c->e_cur]; pa.state_out = c->d_E[c->e_cur ^ 1];
-    pa.part = c->d_part; pa.nvoiced = c->d_nv; pa.e_start = c->d_estart; pa.voiced = gate ? c->d_voiced : nullptr;
+    pa.state_in = c->d_E[c->e_cur] + a0 * c->D; pa.state_out = c->d_E[c->e_cur ^ 1] + a0 * c->D;
+    pa.part = c->ws().d_part; pa.nvoiced = c->ws().d_nv; pa.e_start = c->ws().d_estart; pa.voiced = gate ? c->ws().d_voiced : nullptr;
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
-    if (adaptive) { pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->d_flags; pa.zero_word = c->d_nlist; }
+    const int gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
+    if (adaptive) {
+        pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
+        pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_first = c->ws().d_chunk_first; pa.stats = c->d_rstats;
+    }
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
     hipLaunchKernelGGL(k_scan_partial, g3, dim3(nthr), 0, st, pa);
@@ -907,9 +977,9 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     hipLaunchKernelGGL(k_scan_pick, g3, dim3(std::max(nthr, 512)), smem3, st, pa);   // 8 waves: the per-frame pick is one wave per frame
     if (gate) {
         DoaFillArgs fa{};
-        fa.voiced = c->d_voiced; fa.n_frames = n_frames; fa.S = c->S;
+        fa.voiced = c->ws().d_voiced; fa.n_frames = n_frames; fa.S = c->S;
         fa.doa_bin = doa_bin; fa.doa_rad = doa_rad; fa.prob = prob;
-        fa.last_bin = c->d_last_bin; fa.last_rad = c->d_last_rad; fa.last_prob = c->d_last_prob;
+        fa.last_bin = c->d_last_bin + a0 * c->S; fa.last_rad = c->d_last_rad + a0 * c->S; fa.last_prob = c->d_last_prob + a0 * c->S;
         hipLaunchKernelGGL(k_doa_fill, dim3(n_arrays), dim3(1024), 0, st, fa);
     }
     time_end(c, st);
@@ -919,11 +989,6 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         // the three-product contraction, patch them into the map, pick the flagged chunks again (k_scan_pick, mode 2).
         // Every launch is sized for the worst case (all rows) and exits at the device-side count.
         time_begin(c, MCA_HIP_K_REPAIR, st);
-        const int gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
-        RepairPlanArgs rp{};
-        rp.flags = c->d_flags; rp.n_frames = n_frames; rp.n_chunks = n_chunks; rp.chunk = SCAN_CHUNK; rp.groups_per_array = gpa;
-        rp.list = c->d_list; rp.n_list = c->d_nlist; rp.chunk_flag = c->d_chunk_flag; rp.stats = c->d_rstats;
-        hipLaunchKernelGGL(k_repair_plan, dim3(n_arrays), dim3(256), 0, st, rp);
         const long long pass_rows = repair_pass_rows(c, n_arrays, n_frames);
         const int pass_groups = (int)(pass_rows / REPAIR_GROUP);
         const long long all_groups = (long long)n_arrays * gpa;
@@ -932,37 +997,35 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
             StftPhatArgs sa{};
             sa.pcm = pcm; sa.array_stride = array_stride; sa.mic_stride = mic_stride;
             sa.M = c->M; sa.n_frames = n_frames; sa.frame0 = 0; sa.fpb = REPAIR_GROUP; sa.total_frames = n_frames;
-            sa.window = c->d_window; sa.A = c->d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
+            sa.window = c->d_window; sa.A = c->ws().d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
             sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
-            sa.list = c->d_list; sa.n_list = c->d_nlist; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = gpa;
+            sa.list = c->ws().d_list; sa.n_list = c->ws().d_nlist; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = gpa;
             const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
             // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
             if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, 512), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
             GemmArgs ga{};
-            ga.A = c->d_Ax; ga.B = c->d_B; ga.C = c->d_Cx; ga.Bt = c->d_Bt;
+            ga.A = c->ws().d_Ax; ga.B = c->d_B; ga.C = c->ws().d_Cx; ga.Bt = c->d_Bt;
             ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
             ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
-            ga.n_list = c->d_nlist; ga.list0 = (int)g0;
+            ga.n_list = c->ws().d_nlist; ga.list0 = (int)g0;
             const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
             const long long max_work = (pass_rows + 127) / 128 * col_tiles * REPAIR_KSPLIT_MAX;
             dim3 gg((unsigned)std::min<long long>(max_work, 768));
             if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
             else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
             RepairPatchArgs pp{};
-            pp.Cx = c->d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles;
-            pp.list = c->d_list; pp.n_list = c->d_nlist; pp.list0 = (int)g0; pp.groups_per_array = gpa;
-            pp.C = c->d_C; pp.c_planes = c->c_planes; pp.c_plane_stride = c->c_plane; pp.n_frames = n_frames; pp.Dp = c->Dp;
-            hipLaunchKernelGGL(k_repair_patch, dim3(std::min(pass_groups, 1024)), dim3(256), 0, st, pp);
+            pp.Cx = c->ws().d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles;
+            pp.list = c->ws().d_list; pp.n_list = c->ws().d_nlist; pp.list0 = (int)g0; pp.groups_per_array = gpa; pp.need = c->ws().d_need;
+            pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames; pp.Dp = c->Dp;
+            hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);
         }
         set_call_planes(c, 1);
-        pa.mode = 2; pa.chunk_flag = c->d_chunk_flag;
-        hipLaunchKernelGGL(k_scan_pick, g3, dim3(std::max(nthr, 512)), smem3, st, pa);
+        hipLaunchKernelGGL(k_scan_repick, g3, dim3(std::max(nthr, 512)), (size_t)32 * (c->Dp + 8) * sizeof(float), st, pa);
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
         c->adapt_frames_total += (unsigned long long)n_arrays * n_frames;
     }
-    c->last_arrays = n_arrays; c->last_frames = n_frames;
-    c->e_cur ^= 1;
+    c->ws().last_a0 = c->a0; c->ws().last_arrays = n_arrays;
     return MCA_HIP_OK;
 }
 
@@ -980,13 +1043,10 @@ int mca_hip_get_repair_stats(mca_hip_ctx *c, unsigned long long *frames, unsigne
     return MCA_HIP_OK;
 }
 
-int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
-                                int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, void *stream)
+static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                         int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, hipStream_t st)
 {
-    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
-    if (rc) return rc;
-    if (!doa_rad || !out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
-    hipStream_t st = (hipStream_t)stream;
+    const size_t a0 = (size_t)c->a0;
     BeamformArgs ba{};
     ba.pcm = pcm; ba.array_stride = array_stride; ba.mic_stride = mic_stride;
     ba.M = c->M; ba.Mpad = c->M; ba.S = c->S; ba.n_frames = n_frames; ba.fs = c->cfg.sample_rate;
@@ -1004,7 +1064,7 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     }
     while (ba.ft > BF_NB && (long long)n_arrays * ((n_frames + ba.ft - 1) / ba.ft) < want_wgs) ba.ft >>= 1;
     ba.window = c->d_window; ba.mic_x = c->d_micx; ba.doa_rad = doa_rad; ba.out = out_pcm;
-    ba.tail_in = c->d_tail[c->tail_cur]; ba.tail_out = c->d_tail[c->tail_cur ^ 1];
+    ba.tail_in = c->d_tail[c->tail_cur] + a0 * c->S * c->H; ba.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->S * c->H;
     ba.N = c->N; ba.logH = c->logH; ba.tw = c->d_tw;
     if (c->n512) {
         const size_t smem = ((size_t)2 * 8 * 258 + 8 * FFT_SCRATCH + TW_WIN + (size_t)2 * c->S * c->M * 41) * sizeof(float2) + (size_t)2 * c->S * sizeof(double);
@@ -1016,7 +1076,6 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         hipLaunchKernelGGL(k_beamform_512, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(512), smem, st, ba);
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
-        c->tail_cur ^= 1;
         return MCA_HIP_OK;
     }
     if (c->generic) {
@@ -1027,7 +1086,6 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
         hipLaunchKernelGGL(k_beamform_gen, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(gen_threads(c, true)), smem, st, ba);
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
-        c->tail_cur ^= 1;
         return MCA_HIP_OK;
     }
     ba.nb = std::max(1, BF_NB / c->S);      // 4 beamformed slots in LDS whatever the number of sources
@@ -1050,6 +1108,93 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
 #undef BF_LAUNCH
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
+    return MCA_HIP_OK;
+}
+
+extern "C++" {
+namespace {
+
+// how many lanes a call of this shape is split into
+int lanes_for(mca_hip_ctx *c, int n_arrays, int n_frames, hipStream_t st)
+{
+    if (c->max_lanes <= 1 || n_arrays < 2) return 1;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 1;   // a recording stays on its stream
+    long long n = (long long)n_arrays * n_frames / c->lane_min_rows;
+    n = std::min<long long>(n, std::min(c->max_lanes, n_arrays));
+    return (int)std::max<long long>(n, 1);
+}
+
+int ensure_lane_streams(mca_hip_ctx *c, int n)
+{
+    if (!c->fork_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < n; ++i) {
+        if (!c->lane_stream[i]) HIP_TRY(c, hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
+        if (!c->lane_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->lane_ev[i], hipEventDisableTiming));
+    }
+    return MCA_HIP_OK;
+}
+
+// Runs body(first array, arrays, stream) once per lane: on the caller's stream if there is one lane, else on the lanes' own
+// streams between a fork (they wait for everything queued on the caller's stream so far) and a join (the caller's stream
+// waits for all of them).  Contiguous blocks of arrays, the first n_arrays % lanes lanes take one more.
+template <typename Body>
+int run_lanes(mca_hip_ctx *c, int n_arrays, int n_frames, hipStream_t st, Body body)
+{
+    const int nl = lanes_for(c, n_arrays, n_frames, st);
+    c->n_lanes_last = nl;
+    if (nl == 1) { c->cur_lane = 0; c->a0 = 0; return body(0, n_arrays, st); }
+    int rc = ensure_lane_streams(c, nl);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->fork_ev, st));
+    const int base = n_arrays / nl, rem = n_arrays % nl;
+    int a0 = 0, started = 0;
+    for (int i = 0; i < nl && !rc; ++i) {
+        const int na = base + (i < rem ? 1 : 0);
+        HIP_TRY(c, hipStreamWaitEvent(c->lane_stream[i], c->fork_ev, 0));
+        c->cur_lane = i; c->a0 = a0;
+        rc = body(a0, na, c->lane_stream[i]);
+        (void)hipEventRecord(c->lane_ev[i], c->lane_stream[i]);
+        ++started;
+        a0 += na;
+    }
+    for (int i = 0; i < started; ++i) (void)hipStreamWaitEvent(st, c->lane_ev[i], 0);
+    c->cur_lane = 0; c->a0 = 0;
+    return rc;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
+                                float *energy, void *stream)
+{
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
+    if (rc) return rc;
+    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
+    const size_t fs_ = (size_t)n_frames * c->S, fd_ = (size_t)n_frames * c->D;
+    rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
+        return localise_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_bin + a0 * fs_,
+                             doa_rad ? doa_rad + a0 * fs_ : nullptr, prob ? prob + a0 * fs_ : nullptr, energy ? energy + a0 * fd_ : nullptr, st);
+    });
+    if (rc) return rc;
+    c->last_arrays = n_arrays; c->last_frames = n_frames;
+    c->e_cur ^= 1;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, void *stream)
+{
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
+    if (rc) return rc;
+    if (!doa_rad || !out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
+    const size_t fs_ = (size_t)n_frames * c->S, fo_ = (size_t)c->S * n_frames * c->H;
+    rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
+        return separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st);
+    });
+    if (rc) return rc;
     c->tail_cur ^= 1;
     return MCA_HIP_OK;
 }
@@ -1060,9 +1205,22 @@ int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array
 {
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
     if (!doa_rad) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev is NULL (the separation stage steers with it)");
-    int rc = mca_hip_localise_frames_dev(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, stream);
+    int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
     if (rc) return rc;
-    return mca_hip_separate_frames_dev(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, stream);
+    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
+    if (!out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
+    const size_t fs_ = (size_t)n_frames * c->S, fd_ = (size_t)n_frames * c->D, fo_ = (size_t)c->S * n_frames * c->H;
+    // both stages of a lane back to back: lane 0 beamforms while lane 1 still localises
+    rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
+        int r = localise_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_bin + a0 * fs_, doa_rad + a0 * fs_,
+                              prob ? prob + a0 * fs_ : nullptr, energy ? energy + a0 * fd_ : nullptr, st);
+        if (!r) r = separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st);
+        return r;
+    });
+    if (rc) return rc;
+    c->last_arrays = n_arrays; c->last_frames = n_frames;
+    c->e_cur ^= 1; c->tail_cur ^= 1;
+    return MCA_HIP_OK;
 }
 
 // ---- real-time mode: the stream call as a HIP graph ------------------------------------------
@@ -1101,7 +1259,7 @@ int mca_hip_graph_create(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
     if (out_pcm && !doa_rad) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev is NULL (the separation stage steers with it)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    if ((rc = mca_hip_reserve(c, n_arrays, n_frames))) return rc;      // recording must not allocate
+    if ((rc = reserve_impl(c, n_arrays, n_frames, true))) return rc;   // recording must not allocate (a recording runs as one lane)
     mca_hip_graph *g = new mca_hip_graph();
     g->c = c; g->pcm = pcm; g->array_stride = array_stride; g->mic_stride = mic_stride; g->n_arrays = n_arrays; g->n_frames = n_frames;
     g->doa_bin = doa_bin; g->doa_rad = doa_rad; g->prob = prob; g->energy = energy; g->out_pcm = out_pcm;
@@ -1145,7 +1303,7 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
         // would run on freed memory.  Make sure the workspace (still) fits this graph's shape, then record afresh.
         HIP_TRY(c, hipDeviceSynchronize());      // launches of the old recordings may still be in flight
         graph_drop_recordings(g);
-        const int rc = mca_hip_reserve(c, g->n_arrays, g->n_frames);
+        const int rc = reserve_impl(c, g->n_arrays, g->n_frames, true);
         if (rc) return rc;
         g->ws_gen = c->ws_gen;
     }
@@ -1158,6 +1316,7 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
     c->e_cur ^= 1;                              // as the eager calls do
     if (g->out_pcm) c->tail_cur ^= 1;
     c->last_arrays = g->n_arrays; c->last_frames = g->n_frames;
+    c->n_lanes_last = 1; c->lanes[0].last_a0 = 0; c->lanes[0].last_arrays = g->n_arrays;
     return MCA_HIP_OK;
 }
 
@@ -1255,7 +1414,7 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     if (c->prec == MCA_HIP_SRP_ADAPTIVE) set_call_planes(c, 2);      // the 2-microphone path always runs the exact split
     if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
     Gcc2ScanArgs ga{};
-    ga.C = c->d_C; ga.c_planes = c->c_planes; ga.c_plane_stride = c->c_plane; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D;
+    ga.C = c->ws().d_C; ga.c_planes = c->ws().c_planes; ga.c_plane_stride = c->ws().c_plane; ga.n_frames = n_frames; ga.Dp = c->Dp; ga.D = c->D;
     // frames per chunk: every chunk re-reads 160 warm-up frames (recursion + DOA smoothing), so long chunks are cheaper;
     // shorter ones for small batches so that a few hundred workgroups exist
     ga.chunk = 128;
@@ -1286,15 +1445,15 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
             c->g2_rows = rows;
         }
         GateArgs gg{};
-        gg.power_lin = c->d_power; gg.n_frames = n_frames; gg.fft_n = c->N;
+        gg.power_lin = c->ws().d_power; gg.n_frames = n_frames; gg.fft_n = c->N;
         gg.needed_samples = (int)(3.0 * c->cfg.sample_rate);              // _durationToEstimatePowerFloor (SoundLocalisationImpl.h:77)
         gg.margin_db = 6.f;                                                // _noiseMarginDB (BinauralLocalisation.h:197)
         gg.eps = 1e-10;                                                    // BinauralLocalisation.cpp:391
-        gg.state = c->d_gate_state; gg.voiced = c->d_voiced; gg.power_out = c->d_power_out; gg.post0 = c->d_g2_post0;
+        gg.state = c->d_gate_state; gg.voiced = c->ws().d_voiced; gg.power_out = c->ws().d_power_out; gg.post0 = c->d_g2_post0;
         hipLaunchKernelGGL(k_gate, dim3(n_arrays), dim3(256), 0, st, gg);
         // the silence rule (:530-560): windowsToDecay = 3 * fs / (analysisLength / 2 - 1), int arithmetic, analysisLength = N + 2
         const int windows_to_decay = 3 * c->cfg.sample_rate / c->H;
-        hipLaunchKernelGGL(k_gcc2_compact, dim3(n_arrays), dim3(256), 0, st, c->d_voiced, n_frames, c->d_g2_vidx, c->d_g2_nv,
+        hipLaunchKernelGGL(k_gcc2_compact, dim3(n_arrays), dim3(256), 0, st, c->ws().d_voiced, n_frames, c->d_g2_vidx, c->d_g2_nv,
                            c->d_g2_post0, c->d_silence, windows_to_decay, c->d_g2_reset);
         ga.vidx = c->d_g2_vidx; ga.nv = c->d_g2_nv; ga.vreset = c->d_g2_reset;
         if (!ga.doa_rad) ga.doa_rad = c->d_g2_rad;                         // the hold-over needs them whatever the caller asked for
@@ -1308,7 +1467,7 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     hipLaunchKernelGGL(k_gcc2_scan, g, dim3(std::max(256, round_up(c->D, 64))), smem, st, ga);   // >= 4 waves: the per-frame argmax / min / sum is one wave per frame
     if (gate) {
         Gcc2FillArgs fa{};
-        fa.voiced = c->d_voiced; fa.n_frames = n_frames; fa.D = c->D;
+        fa.voiced = c->ws().d_voiced; fa.n_frames = n_frames; fa.D = c->D;
         fa.argmax = argmax; fa.doa_rad = ga.doa_rad; fa.prob = ga.prob; fa.corr = corr; fa.corr_state = ga.corr_in;
         fa.last_idx = c->d_last_bin; fa.last_rad = c->d_last_rad; fa.last_prob = c->d_last_prob;
         hipLaunchKernelGGL(k_gcc2_fill, dim3(n_arrays), dim3(1024), 0, st, fa);
@@ -1317,6 +1476,7 @@ int mca_hip_gcc2_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_st
     HIP_TRY(c, hipGetLastError());
     c->e_cur ^= 1; c->doa_cur ^= 1;
     c->last_arrays = n_arrays; c->last_frames = n_frames;
+    c->n_lanes_last = 1; c->lanes[0].last_a0 = 0; c->lanes[0].last_arrays = n_arrays;
     return MCA_HIP_OK;
 }
 
@@ -1351,9 +1511,12 @@ int mca_hip_copy_gate(mca_hip_ctx *c, unsigned char *voiced, float *power)
     if (c->last_frames == 0) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "no stream call has run yet");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipDeviceSynchronize());
-    const size_t n = (size_t)c->last_arrays * c->last_frames;
-    if (voiced) HIP_TRY(c, hipMemcpy(voiced, c->d_voiced, n, hipMemcpyDeviceToHost));
-    if (power) HIP_TRY(c, hipMemcpy(power, c->d_power_out, n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < c->n_lanes_last; ++i) {          // every lane holds the flags of its own block of arrays
+        const Workspace &w = c->lanes[i];
+        const size_t n = (size_t)w.last_arrays * c->last_frames, off = (size_t)w.last_a0 * c->last_frames;
+        if (voiced) HIP_TRY(c, hipMemcpy(voiced + off, w.d_voiced, n, hipMemcpyDeviceToHost));
+        if (power) HIP_TRY(c, hipMemcpy(power + off, w.d_power_out, n * 4, hipMemcpyDeviceToHost));
+    }
     return MCA_HIP_OK;
 }
 

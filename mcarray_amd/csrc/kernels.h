@@ -10,7 +10,7 @@ __global__ void k_sum_planes(float *C, long long n4, int planes, long long strid
 __global__ void k_scan_partial(ScanPickArgs p);
 __global__ void k_scan_carry(ScanPickArgs p);
 __global__ void k_scan_pick(ScanPickArgs p);
-__global__ void k_repair_plan(RepairPlanArgs p);
+__global__ void k_scan_repick(ScanPickArgs p);
 __global__ void k_repair_patch(RepairPatchArgs p);
 __global__ void k_gate(GateArgs p);
 __global__ void k_doa_fill(DoaFillArgs p);

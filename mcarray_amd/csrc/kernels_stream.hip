@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
 {
     __shared__ float spow[SCAN_CHUNK + 1];                          // 0.8f^n
     const int d = threadIdx.x, a = blockIdx.x;
-    if (p.zero_word && a == 0 && d == 0) *p.zero_word = 0;
+    if (p.mode == 1 && a == 0 && d == 0) *p.n_list = 0;              // adaptive SRP precision: the repair list starts empty
     for (int n = d; n <= SCAN_CHUNK; n += blockDim.x) {
         float g = 1.f;
         for (int i = 0; i < n; ++i) g *= p.mu;
@@ -410,29 +410,99 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
     p.state_out[(long long)a * p.D + d] = E;                         // _prevEnergyInDOA (:143)
 }
 
-// Adaptive SRP precision (p.mode): the correlation map comes from ONE fp16 MFMA product per k-step (error sigma ~3e-6 of the
-// largest possible map value instead of ~4e-7 for the three-product split).  Mode 1 (coarse pass) picks as usual and, per
-// frame, decides whether the pick could come out differently on the exact map: with |error| of a normalised energy
-// difference bounded by p.tau,
+// selectDOA of one frame by one wave (SteeringBeamforming.cpp:146-195): En = the frame's normalised energies (LDS), lane
+// evaluates the sign / median-3 / second-derivative chain at the positions lane + 64 i, the S maxima are found by wave
+// shuffles with first-index tie-break and written by lane 0.  SENS (coarse pass of the adaptive SRP precision): also
+// decides whether the picks could come out differently on the exact map; returns that decision (uniform over the wave).
+//
+// Adaptive SRP precision: the correlation map comes from ONE fp16 MFMA product per k-step (error sigma ~3e-6 of the largest
+// possible map value instead of ~4e-7 for the three-product split).  With |error| of a normalised energy difference
+// bounded by tau,
 //   * a position dd is UNCERTAIN if any of the four first differences its second derivative reads (the sign / median-3
 //     chain of selectDOA) lies within +-tau of zero -- its sd could then be -En, 0 or +En[dd+1];
-//   * the frame is flagged if an uncertain position could reach the S-th picked value (En[dd+1] >= v_S - tau; any uncertain
-//     position at all when fewer than S positive peaks exist), or if two of the S+1 largest candidates lie within tau of
-//     each other (their order, or which one is the last pick, is open).
-// Every other frame's picks are the exact map's picks.  The last frame of a call is always flagged, so that the state
-// handed to the next call is exact too.  Mode 2 (repair pass, after the flagged frames' rows and the REPAIR_WARM rows before
-// them were recomputed with the three-product split and patched into C): only the chunks that hold a flagged frame run;
-// the recursion restarts one chunk earlier from that chunk's (coarse) start value and walks the patched map, so that at a
-// flagged frame at most 0.8^(REPAIR_WARM+1) of the coarse error is left; all frames of the chunk are picked again.
+//   * the frame is sensitive if an uncertain position could reach the S-th picked value (En[dd+1] >= v_S - tau; any
+//     uncertain position at all when fewer than S positive peaks exist), or if two of the S+1 largest candidates lie within
+//     tau of each other (their order, or which one is the last pick, is open).
+// Every other frame's picks are the exact map's picks.
+template <bool SENS>
+__device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p, long long out_base, int lane)
+{
+    const int D = p.D;
+    float sdv[8];
+    float umax = -INFINITY;                                     // SENS: largest En[dd+1] over the uncertain positions
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int dd = lane + 64 * i;
+        float sd = -INFINITY;
+        if (dd < D - 2) {
+            // fd(j) = 1 if En[j+1] - En[j] < 0 else 0, j in [0, D-2]; edges replicate (median_filter)
+            const int j0 = max(dd - 1, 0), j3 = min(dd + 2, D - 2);
+            const float e0 = En[j0], e1 = En[j0 + 1];
+            const float ed = En[dd], ed1 = En[dd + 1], ed2 = En[dd + 2];
+            const float e3 = En[j3], e4 = En[j3 + 1];
+            const float dm1 = e1 - e0, d0 = ed1 - ed, d1 = ed2 - ed1, d2 = e4 - e3;
+            const float fm1 = dm1 < 0.f ? 1.f : 0.f;              // fd(d-1) (or fd(0) at the edge)
+            const float f0 = d0 < 0.f ? 1.f : 0.f;                // fd(d)
+            const float f1 = d1 < 0.f ? 1.f : 0.f;                // fd(d+1)
+            const float f2 = d2 < 0.f ? 1.f : 0.f;                // fd(d+2) (or fd(D-2) at the edge)
+            const float m0 = median3f(fm1, f0, f1);               // filtered fd(d)     :164
+            const float m1 = median3f(f0, f1, f2);                // filtered fd(d+1)
+            sd = (m1 - m0) * ed1;                                  // :170-173
+            if (SENS) {
+                const float dmin = fminf(fminf(fabsf(dm1), fabsf(d0)), fminf(fabsf(d1), fabsf(d2)));
+                if (dmin <= p.tau) umax = fmaxf(umax, ed1);
+            }
+        }
+        sdv[i] = sd;
+    }
+    bool sens = false;
+    float prev_bv = 0.f, v_last = 0.f;
+    const int n_pick = SENS ? p.S + 1 : p.S;                      // SENS: one more, the runner-up of the last pick
+    for (int s = 0; s < n_pick; ++s) {                             // :185-194
+        float bv = sdv[0]; int bi = lane;
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (sdv[i] > bv) { bv = sdv[i]; bi = lane + 64 * i; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (bi == lane + 64 * i) sdv[i] = 0.f;                 // _secondDerivative[maxIdx] = 0
+        if (SENS && s > 0 && prev_bv > 0.f && prev_bv - bv <= p.tau) sens = true;
+        prev_bv = bv;
+        if (s < p.S) {
+            v_last = bv;
+            if (lane == 0) {
+                const long long o = out_base + s;
+                p.doa_bin[o] = bi + 1;
+                if (p.doa_rad) p.doa_rad[o] = p.grid[bi + 1];      // doaIdx2angle(maxIdx+1)
+                if (p.prob) p.prob[o] = bv;
+            }
+        }
+    }
+    if (SENS) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) umax = fmaxf(umax, __shfl_xor(umax, off));
+        if (v_last > 0.f ? umax >= v_last - p.tau : umax > -INFINITY) sens = true;
+    }
+    return sens;
+}
+
+// p.mode == 1 (coarse pass of the adaptive SRP precision): a frame whose picks are sensitive to the fp16 error -- and the
+// last frame of the call, so that the state handed to the next call is exact too -- is flagged, and the wave that found it
+// plans its repair on the spot: the groups of REPAIR_GROUP frames that hold its own row and the REPAIR_WARM rows before it
+// (its energy is 0.2 sum_k 0.8^k C_{t-k}) go onto the repair list (once: `need` is a test-and-set per group), and its
+// position becomes the chunk's first flagged one if it is.  need / chunk_first are cleaned by the kernels that consume
+// them (k_repair_patch, k_scan_repick); the list's length is reset by k_scan_carry.
 __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sEn = reinterpret_cast<float *>(smem_raw);                   // [SCAN_SUB][Dl]
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
     const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
-    const int first_flag = p.mode == 2 ? p.chunk_flag[(long long)a * p.n_chunks + blockIdx.x] - 1 : 0;
-    if (first_flag < 0) return;
-    const unsigned char *fl = p.mode == 2 ? p.flags + (long long)a * p.n_frames : nullptr;
     const int t_start = blockIdx.x * p.chunk;
     const int t_end = min(t_start + p.chunk, p.n_frames);
     const bool act = d < D;
@@ -440,20 +510,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
     const float mn = -15.f * (float)p.P;
-    // mode 2: the exact rows start REPAIR_WARM frames before the chunk's first flagged frame; if that is inside this chunk the
-    // recursion starts from this chunk's own (coarse) start value, else one chunk earlier
-    const int c_from = (p.mode == 2 && blockIdx.x > 0 && first_flag < REPAIR_WARM + 1) ? blockIdx.x - 1 : blockIdx.x;
-    float E = act ? p.e_start[((long long)a * p.n_chunks + c_from) * D + d] : 0.f;
-    if (c_from != (int)blockIdx.x && act) {
-        for (int t0 = t_start - p.chunk; t0 < t_start; t0 += 16) {      // the chunk before, on the patched map, no outputs
-            float c16[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c16[i] = csum(C, (long long)(t0 + i) * p.Dp + d, p.c_planes, p.c_plane_stride);
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (!vc || vc[t0 + i]) E = mu * E + omu * c16[i];
-        }
-    }
+    float E = act ? p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d] : 0.f;
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
         if (act) {
@@ -471,159 +528,147 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                     if (t < te) {
                         if (!vc || vc[t]) E = mu * E + omu * c8[i];                 // :134-140
                         if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
-                        if (!fl || fl[t]) sEn[(t - ts) * Dl + d] = (E - mn) / (-2.f * mn);   // :155-156 (mode 2: flagged frames only)
+                        sEn[(t - ts) * Dl + d] = (E - mn) / (-2.f * mn);            // :155-156
                     }
                 }
             }
         }
         __syncthreads();
         for (int tl = wave; tl < te - ts; tl += nwaves) {
-            if (fl && !fl[ts + tl]) continue;                           // mode 2: every other frame keeps its (safe) coarse pick
-            if (vc && !vc[ts + tl]) {                                   // gated out: selectDOA is not reached (:87)
-                if (lane < p.S) p.doa_bin[((long long)a * p.n_frames + ts + tl) * p.S + lane] = -1;
-                if (p.mode == 1 && lane == 0) p.flags[(long long)a * p.n_frames + ts + tl] = (ts + tl == p.n_frames - 1) ? 1 : 0;
-                continue;
-            }
-            const float *En = sEn + tl * Dl;
-            float sdv[8];
-            float umax = -INFINITY;                                     // mode 1: largest En[dd+1] over the uncertain positions
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int dd = lane + 64 * i;
-                float sd = -INFINITY;
-                if (dd < D - 2) {
-                    // fd(j) = 1 if En[j+1] - En[j] < 0 else 0, j in [0, D-2]; edges replicate (median_filter)
-                    const int j0 = max(dd - 1, 0), j3 = min(dd + 2, D - 2);
-                    const float e0 = En[j0], e1 = En[j0 + 1];
-                    const float ed = En[dd], ed1 = En[dd + 1], ed2 = En[dd + 2];
-                    const float e3 = En[j3], e4 = En[j3 + 1];
-                    const float dm1 = e1 - e0, d0 = ed1 - ed, d1 = ed2 - ed1, d2 = e4 - e3;
-                    const float fm1 = dm1 < 0.f ? 1.f : 0.f;              // fd(d-1) (or fd(0) at the edge)
-                    const float f0 = d0 < 0.f ? 1.f : 0.f;                // fd(d)
-                    const float f1 = d1 < 0.f ? 1.f : 0.f;                // fd(d+1)
-                    const float f2 = d2 < 0.f ? 1.f : 0.f;                // fd(d+2) (or fd(D-2) at the edge)
-                    const float m0 = median3f(fm1, f0, f1);               // filtered fd(d)     :164
-                    const float m1 = median3f(f0, f1, f2);                // filtered fd(d+1)
-                    sd = (m1 - m0) * ed1;                                  // :170-173
-                    if (p.mode == 1) {
-                        const float dmin = fminf(fminf(fabsf(dm1), fabsf(d0)), fminf(fabsf(d1), fabsf(d2)));
-                        if (dmin <= p.tau) umax = fmaxf(umax, ed1);
-                    }
-                }
-                sdv[i] = sd;
-            }
-            bool sens = false;
-            float prev_bv = 0.f, v_last = 0.f;
-            const int n_pick = p.mode == 1 ? p.S + 1 : p.S;              // mode 1: one more, the runner-up of the last pick
-            for (int s = 0; s < n_pick; ++s) {                             // :185-194
-                float bv = sdv[0]; int bi = lane;
-#pragma unroll
-                for (int i = 1; i < 8; ++i)
-                    if (sdv[i] > bv) { bv = sdv[i]; bi = lane + 64 * i; }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (bi == lane + 64 * i) sdv[i] = 0.f;                 // _secondDerivative[maxIdx] = 0
-                if (s > 0 && prev_bv > 0.f && prev_bv - bv <= p.tau) sens = true;   // (mode 1 only: tau = 0 and unused otherwise)
-                prev_bv = bv;
-                if (s < p.S) {
-                    v_last = bv;
-                    if (lane == 0) {
-                        const long long o = ((long long)a * p.n_frames + ts + tl) * p.S + s;
-                        p.doa_bin[o] = bi + 1;
-                        if (p.doa_rad) p.doa_rad[o] = p.grid[bi + 1];      // doaIdx2angle(maxIdx+1)
-                        if (p.prob) p.prob[o] = bv;
-                    }
-                }
+            const int t = ts + tl;
+            bool flag = p.mode == 1 && t == p.n_frames - 1;
+            if (vc && !vc[t]) {                                         // gated out: selectDOA is not reached (:87)
+                if (lane < p.S) p.doa_bin[((long long)a * p.n_frames + t) * p.S + lane] = -1;
+            } else if (p.mode == 1) {
+                flag |= wave_pick<true>(sEn + tl * Dl, p, ((long long)a * p.n_frames + t) * p.S, lane);
+            } else {
+                wave_pick<false>(sEn + tl * Dl, p, ((long long)a * p.n_frames + t) * p.S, lane);
             }
             if (p.mode == 1) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) umax = fmaxf(umax, __shfl_xor(umax, off));
-                if (v_last > 0.f ? umax >= v_last - p.tau : umax > -INFINITY) sens = true;
-                if (lane == 0) p.flags[(long long)a * p.n_frames + ts + tl] = (sens || ts + tl == p.n_frames - 1) ? 1 : 0;
+                if (lane == 0) p.flags[(long long)a * p.n_frames + t] = flag ? 1 : 0;
+                if (flag) {
+                    const int q_lo = max(t - REPAIR_WARM, 0) / REPAIR_GROUP, q_hi = t / REPAIR_GROUP;
+                    for (int q = q_lo + lane; q <= q_hi; q += 64) {
+                        const int e = a * p.groups_per_array + q;
+                        if (atomicExch(&p.need[e], 1) == 0) {
+                            p.list[atomicAdd(p.n_list, 1)] = e;
+                            atomicAdd(&p.stats[1], 1ull);
+                        }
+                    }
+                    if (lane == 0) {
+                        atomicMin(&p.chunk_first[(long long)a * p.n_chunks + blockIdx.x], t - t_start);
+                        atomicAdd(&p.stats[0], 1ull);
+                    }
+                }
             }
         }
         __syncthreads();
     }
-    if (p.mode == 2 && act && t_end == p.n_frames) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
 }
 
 // --------------------------------------------------------------------------------------
-// k_repair_plan / k_repair_patch -- adaptive SRP precision: which rows to recompute, and their way back into the map
+// k_scan_repick / k_repair_patch -- adaptive SRP precision: the second pick of the flagged frames on the exact rows
 // --------------------------------------------------------------------------------------
-// k_repair_plan: grid (arrays), 256 threads.  A group of REPAIR_GROUP frames is recomputed if a flagged frame lies in it or
-// within REPAIR_WARM frames after it (the flagged frame's energy is 0.2 sum_k 0.8^k C_{t-k}: its own row and the rows
-// before it).  The groups of all arrays go into one list (order = order of arrival; a row's result does not depend on its
-// place in the list); a chunk is flagged if it holds a flagged frame.
-__global__ __launch_bounds__(256) void k_repair_plan(RepairPlanArgs p)
+// k_scan_repick: grid (chunks, arrays); only the chunks that hold a flagged frame run (chunk_first < chunk).  After the
+// flagged frames' rows and the REPAIR_WARM rows before them were recomputed with the three-product split and patched into C,
+// the recursion restarts from a (coarse) chunk start value -- this chunk's if the first flagged frame lies at least
+// REPAIR_WARM + 1 frames into it, else the one before -- and walks the patched map, so that at a flagged frame at most
+// 0.8^(REPAIR_WARM+1) of the coarse error is left; the flagged frames are picked again (every other frame's coarse pick is
+// safe).  32 rows in flight per thread, the picks of a batch of 32 frames after it.  The last chunk of an array leaves
+// the exact state.
+constexpr int REPICK_B = 32;
+
+__global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
 {
-    __shared__ int s_cnt[4], s_base;
-    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, F = p.n_frames;
-    const unsigned char *fl = p.flags + (long long)a * F;
-    int n_groups = 0;
-    for (int q0 = 0; q0 < p.groups_per_array; q0 += 256) {
-        const int q = q0 + tid;
-        bool need = false;
-        if (q < p.groups_per_array) {
-            const int lo = q * REPAIR_GROUP, hi = min(lo + REPAIR_GROUP - 1 + REPAIR_WARM, F - 1);
-            for (int t = lo; t <= hi; ++t) need |= fl[t] != 0;
-        }
-        const unsigned long long m = __ballot(need);
-        if (lane == 0) s_cnt[wave] = __popcll(m);
-        __syncthreads();
-        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        if (tid == 0) s_base = total ? atomicAdd(p.n_list, total) : 0;
-        __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_cnt[w];
-        if (need) p.list[off + __popcll(m & ((1ull << lane) - 1ull))] = a * p.groups_per_array + q;
-        n_groups += total;
-        __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sEn = reinterpret_cast<float *>(smem_raw);                   // [REPICK_B][Dl]
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
+    const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
+    const long long ci = (long long)a * p.n_chunks + blockIdx.x;
+    const int first_flag = p.chunk_first[ci];
+    if (first_flag >= p.chunk) return;
+    const unsigned char *fl = p.flags + (long long)a * p.n_frames;
+    const int t_start = blockIdx.x * p.chunk;
+    const int t_end = min(t_start + p.chunk, p.n_frames);
+    const bool act = d < D;
+    const float mu = p.mu, omu = p.one_minus_mu;
+    const float *C = p.C + (long long)a * p.n_frames * p.Dp;
+    const float mn = -15.f * (float)p.P;
+    const int c_from = (blockIdx.x > 0 && first_flag < REPAIR_WARM + 1) ? blockIdx.x - 1 : blockIdx.x;
+    float E = act ? p.e_start[((long long)a * p.n_chunks + c_from) * D + d] : 0.f;
+    // the flags of this chunk as one 64-bit mask (p.chunk <= 64): loaded once, not per frame inside the recursion
+    __shared__ unsigned long long s_mask;
+    if (wave == 0) {
+        const unsigned long long m = __ballot(t_start + lane < t_end && fl[t_start + lane] != 0);
+        if (lane == 0) s_mask = m;
     }
-    int n_flag = 0;
-    for (int c = tid; c < p.n_chunks; c += 256) {
-        const int lo = c * p.chunk, hi = min(lo + p.chunk, F);
-        int any = 0, first = 0;
-        for (int t = lo; t < hi; ++t)
-            if (fl[t]) { if (!any) first = t - lo + 1; ++any; }
-        p.chunk_flag[(long long)a * p.n_chunks + c] = first;
-        n_flag += any;
-    }
+    __syncthreads();
+    const unsigned long long mask = s_mask;
+    for (int tb = c_from * p.chunk; tb < t_end; tb += REPICK_B) {
+        const int te = min(tb + REPICK_B, t_end);
+        // flagged frames of this batch (bit i = frame tb + i); none in the chunk before
+        const unsigned bm = tb >= t_start ? (unsigned)((mask >> (tb - t_start)) & 0xffffffffull) : 0u;
+        if (act) {
+            float c16[REPICK_B];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) n_flag += __shfl_down(n_flag, off);
-    if (lane == 0 && n_flag) atomicAdd(&p.stats[0], (unsigned long long)n_flag);
-    if (tid == 0 && n_groups) atomicAdd(&p.stats[1], (unsigned long long)n_groups);
+            for (int i = 0; i < REPICK_B; ++i) c16[i] = csum(C, (long long)min(tb + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+#pragma unroll
+            for (int i = 0; i < REPICK_B; ++i) {
+                const int t = tb + i;
+                if (t < te) {
+                    E = mu * E + omu * c16[i];                          // :134-140
+                    if (t >= t_start && p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
+                    if ((bm >> i) & 1u) sEn[i * Dl + d] = (E - mn) / (-2.f * mn);   // :155-156
+                }
+            }
+        }
+        if (bm) {
+            __syncthreads();
+            for (int i = wave; i < te - tb; i += nwaves)
+                if ((bm >> i) & 1u) wave_pick<false>(sEn + i * Dl, p, ((long long)a * p.n_frames + tb + i) * p.S, lane);
+            __syncthreads();
+        }
+    }
+    if (act && t_end == p.n_frames) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
+    if (d == 0) p.chunk_first[ci] = 0x7f7f7f7f;                              // consumed: no flagged frame
 }
 
-// k_repair_patch: a fixed grid walks the groups of this pass, 256 threads: the exact rows (sum of the repair contraction's split-K partial
-// maps, plane 0 first) replace plane 0 of the map, the other planes of those rows become zero.
-__global__ __launch_bounds__(256) void k_repair_patch(RepairPatchArgs p)
+// k_repair_patch: a fixed grid walks the rows of this pass, 128 threads per row: the exact row (sum of the repair contraction's
+// split-K partial maps, plane 0 first) replaces plane 0 of the map, the other planes of that row become zero; the group's
+// test-and-set word is released.
+__global__ __launch_bounds__(128) void k_repair_patch(RepairPatchArgs p)
 {
     const int n_here = min(*p.n_list - p.list0, p.pass_rows / REPAIR_GROUP);
     const int n_rows = n_here * REPAIR_GROUP;
     const int planes_x = repair_ksplit(n_rows, p.col_tiles);
     const long long plane_x_stride = repair_plane_stride(n_rows, p.Dp);
     const int n4 = p.Dp >> 2;                                            // Dp is a multiple of 64
-    for (int g = blockIdx.x; g < n_here; g += gridDim.x) {
-    const int e = p.list[p.list0 + g];
-    const int a = e / p.groups_per_array, f0 = (e - a * p.groups_per_array) * REPAIR_GROUP;
-    for (int i = threadIdx.x; i < REPAIR_GROUP * n4; i += 256) {
-        const int j = i / n4, c4 = i - j * n4;
-        if (f0 + j >= p.n_frames) break;
-        const float *src = p.Cx + ((long long)g * REPAIR_GROUP + j) * p.Dp + c4 * 4;
+    for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const int g = r / REPAIR_GROUP, j = r - g * REPAIR_GROUP;
+        const int e = p.list[p.list0 + g];
+        const int a = e / p.groups_per_array, f = (e - a * p.groups_per_array) * REPAIR_GROUP + j;
+        if (j == 0 && threadIdx.x == 0) p.need[e] = 0;
+        if (f >= p.n_frames) continue;
+        for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
+        const float *src = p.Cx + (long long)r * p.Dp + c4 * 4;
         float4 v = *reinterpret_cast<const float4 *>(src);
-        for (int z = 1; z < planes_x; ++z) {
+        int z = 1;
+        for (; z + 3 < planes_x; z += 4) {                                // four partial maps in flight, summed in order
+            const float4 w0 = *reinterpret_cast<const float4 *>(src + z * plane_x_stride);
+            const float4 w1 = *reinterpret_cast<const float4 *>(src + (z + 1) * plane_x_stride);
+            const float4 w2 = *reinterpret_cast<const float4 *>(src + (z + 2) * plane_x_stride);
+            const float4 w3 = *reinterpret_cast<const float4 *>(src + (z + 3) * plane_x_stride);
+            v.x = (((v.x + w0.x) + w1.x) + w2.x) + w3.x; v.y = (((v.y + w0.y) + w1.y) + w2.y) + w3.y;
+            v.z = (((v.z + w0.z) + w1.z) + w2.z) + w3.z; v.w = (((v.w + w0.w) + w1.w) + w2.w) + w3.w;
+        }
+        for (; z < planes_x; ++z) {
             const float4 w = *reinterpret_cast<const float4 *>(src + z * plane_x_stride);
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
-        float *dst = p.C + ((long long)a * p.n_frames + f0 + j) * p.Dp + c4 * 4;
+        float *dst = p.C + ((long long)a * p.n_frames + f) * p.Dp + c4 * 4;
         *reinterpret_cast<float4 *>(dst) = v;
         for (int pl = 1; pl < p.c_planes; ++pl) *reinterpret_cast<float4 *>(dst + pl * p.c_plane_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+        }
     }
 }
 

@@ -15,8 +15,9 @@ constexpr int SCAN_WARM = 96;     // frames of IIR warm-up per scan chunk (0.8^9
 constexpr int KG = 513;            // complex K-slots per delay group in the A / B contraction index (g * KG + k)
 constexpr int SCAN_CHUNK = 64;    // frames per chunk of the exact chunked scan
 constexpr int SCAN_SUB = 32;      // frames per LDS sub-batch of k_scan_pick
-constexpr int REPAIR_WARM = 40;   // exact rows recomputed BEFORE a flagged frame (adaptive SRP precision): 0.8^41 = 1e-4 of the coarse error remains
-constexpr int REPAIR_GROUP = 8;   // frames per repair unit = frames per workgroup of k_stft_phat
+constexpr int REPAIR_WARM = 24;   // exact rows recomputed BEFORE a flagged frame (adaptive SRP precision): 0.8^25 = 3.8e-3 of the coarse error
+                                  // remains, i.e. ~6e-8 of the map's peak -- 30 x below the error of the three-product split itself
+constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mode pass of a k_stft_phat workgroup
 
 struct StftPhatArgs {
     const float *pcm;
@@ -87,17 +88,21 @@ struct ScanPickArgs {
     const float *grid;       // [D] doaIdx2angle
     int *doa_bin; float *doa_rad; float *prob; float *energy;
     // adaptive SRP precision (fp16 coarse scan + exact repair of the frames whose pick is sensitive to the fp16 error)
-    int mode;                // 0: plain; 1: coarse pass, writes flags; 2: repair pass over the chunks with chunk_flag set
+    int mode;                // 0: plain; 1: coarse pass, flags the sensitive frames and plans their repair
     float tau;               // two normalised energies closer than this cannot be ordered from the coarse map
     unsigned char *flags;    // [arrays][n_frames] 1 = the frame's pick must be repeated on exact rows
-    const int *chunk_flag;   // [arrays][n_chunks] (mode 2) 1 + position of the chunk's first flagged frame, 0 = none
-    int *zero_word;          // (mode 1) the repair list's length, reset by k_scan_carry on its way
+    int groups_per_array;    // repair units (REPAIR_GROUP frames) per array
+    int *need;               // [arrays * groups_per_array] test-and-set: the group is on the list (cleared by k_repair_patch)
+    int *list;               // [arrays * groups_per_array] groups whose rows are recomputed, in order of arrival
+    int *n_list;             // [1] their number (reset by k_scan_carry)
+    int *chunk_first;        // [arrays][n_chunks] position of the chunk's first flagged frame, >= chunk: none (reset by k_scan_repick)
+    unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
 };
 
 constexpr int REPAIR_KSPLIT_MAX = 32;
-// The repair contraction runs on however many rows the plan listed (a device-side count): few rows -> the K range is what
-// parallelises.  Split factor and partial-map stride as a function of the row count, shared by the contraction
-// (k_srp_gemm_f16 with n_list) and k_repair_patch: ~1024 workgroups, at most REPAIR_KSPLIT_MAX partial maps.
+// The repair contraction runs on however many rows the coarse pass listed (a device-side count): few rows -> the K range is
+// what parallelises.  Split factor and partial-map stride as a function of the row count, shared by the contraction
+// (k_srp_gemm_repair) and k_repair_patch: ~1024 work items, at most REPAIR_KSPLIT_MAX partial maps.
 __host__ __device__ inline int repair_ksplit(int n_rows, int col_tiles)
 {
     const int tiles = (n_rows + 127) / 128 * col_tiles;
@@ -105,22 +110,14 @@ __host__ __device__ inline int repair_ksplit(int n_rows, int col_tiles)
     return k < 1 ? 1 : (k > REPAIR_KSPLIT_MAX ? REPAIR_KSPLIT_MAX : k);
 }
 __host__ __device__ inline long long repair_plane_stride(int n_rows, int Dp) { return (long long)((n_rows + 127) / 128 * 128) * Dp; }
-// rows x partial maps never exceeds this many rows of Cx (1024 workgroups x 128 rows / 2 column tiles, or one map of all rows)
+// rows x partial maps never exceeds this many rows of Cx (1024 work items x 128 rows, or one map of all rows)
 __host__ __device__ inline long long repair_cx_rows(long long pass_rows) { return (pass_rows > 131072 ? pass_rows : 131072) + 128 * REPAIR_KSPLIT_MAX; }
-
-struct RepairPlanArgs {
-    const unsigned char *flags;   // [arrays][n_frames]
-    int n_frames, n_chunks, chunk, groups_per_array;
-    int *list;               // [arrays * groups_per_array] groups (REPAIR_GROUP frames) whose rows are recomputed
-    int *n_list;             // [1] their number (zeroed before the launch)
-    int *chunk_flag;         // [arrays][n_chunks] 1 + position of the chunk's first flagged frame, 0 = none
-    unsigned long long *stats;    // [2] running totals: flagged frames, recomputed groups
-};
 
 struct RepairPatchArgs {
     const float *Cx;         // [repair_ksplit][repair_plane_stride] exact rows, split-K partial maps
     int pass_rows, col_tiles;
     const int *list; const int *n_list; int list0, groups_per_array;
+    int *need;               // the groups' test-and-set words, released here
     float *C;                // [c_planes][arrays][n_frames][Dp]: plane 0 takes the exact row, the others zeros
     int c_planes; long long c_plane_stride;
     int n_frames, Dp;
