@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/s of the 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum path on MI355X.
+"""bench.py -- frames/s of the mcarray hot path on MI355X.
 
-One "step" = one pass of the whole hot path (STFT analysis -> GCC-PHAT over all pairs -> SRP scan
--> IIR + peak pick -> delay-and-sum -> ISTFT/overlap-add) over one batch of synthetic input that
-is already resident in HBM: `--arrays` independent 8-mic arrays x `--frames` STFT frames per GPU
-(BASELINE.json configs[2] geometry: 48 kHz, 1024-pt, hop 512, 361 steering angles; 8 x 4096 frames
-per GPU = the per-GPU frame count of configs[4]).  Arrays are independent units: with N GPUs every
-rank owns its own arrays (weak scaling), no collective inside the compute, one RCCL all_gather of
-the DOA bins + prob per step.
+--config ssl (default): the 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum path.  One "step" = one pass of the whole hot path
+(STFT analysis -> GCC-PHAT over all pairs -> SRP scan -> IIR + peak pick -> delay-and-sum -> ISTFT/overlap-add) over one batch
+of synthetic input that is already resident in HBM: `--arrays` independent 8-mic arrays x `--frames` STFT frames per GPU
+(BASELINE.json configs[2] geometry: 48 kHz, 1024-pt, hop 512, 361 steering angles; 8 x 4096 frames per GPU = the per-GPU frame
+count of configs[4]).  The literal configs[2] reading -- ONE array, 4096 frames per call -- is reported next to it as
+config.single_stream_4096.
+--config mvdr: BASELINE.json configs[3], the 16-mic frequency-domain beamformer with a per-bin spatial covariance, 256 concurrent
+streams x 64 frames per step.
 
-Prints ONE JSON line (rank 0).  `value` = frames of all ranks / max-over-ranks time of K steps.
-`roofline` is for the dominant kernel, timed with HIP events recorded by the library on the
-launch stream inside the timed region.  `cpu_baseline` = the CPU oracle (a scalar double-precision
-restatement of the reference, oracle/) on a bounded sample of the same input, rank 0, N=1 only.
+Arrays / streams are independent units: with N GPUs every rank owns its own block (weak scaling), no collective inside the
+compute, one RCCL all_gather of the DOA bins + prob per step (mcarray_amd/dist.py; --gather-audio adds the beamformed audio, to
+rank 0).  `python bench.py --gpus N` without a launcher starts its own N ranks (or refuses if fewer GPUs are visible).
+
+Prints ONE JSON line (rank 0).  `value` = frames of all ranks / max-over-ranks time of K steps.  `roofline` is for the dominant
+kernel, timed with HIP events recorded by the library on the launch stream inside the timed region.  `cpu_baseline` = the CPU
+oracle (a scalar double-precision restatement of the reference, oracle/) on a bounded sample of the same input, rank 0, N=1 only.
 """
 import argparse
 import json
@@ -32,26 +36,26 @@ BYTES_PER_FRAME = M * HOP * 4 + HOP * 4 + 8          # 18 440 B (PCM 
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0 TB/s spec
 PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0, "adaptive": 2500.0}   # dense MFMA peaks, same guide
 PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2, "adaptive": 3}
+PROFILE_TAG = "r02"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
 
 
-def synth_batch(seeds, n_frames, device):
+def synth_batch(xs, seeds, n_frames, device, noise=0.01):
     """Far-field white source per array + 20 dB sensor noise, generated on the GPU.
     One seed per array, derived from the array's GLOBAL index, so its data does not depend on the rank count."""
-    from mcarray_amd import synth
-    n_arrays = len(seeds)
+    n_arrays, n_mics = len(seeds), len(xs)
     L = (n_frames + 1) * HOP
-    xs = torch.tensor(synth.ULA8, device=device, dtype=torch.float64)
+    xs_t = torch.tensor(xs, device=device, dtype=torch.float64)
     theta = torch.empty(n_arrays, device=device, dtype=torch.float64)
-    out = torch.empty(n_arrays, M, L, device=device, dtype=torch.float32)
+    out = torch.empty(n_arrays, n_mics, L, device=device, dtype=torch.float32)
     f = torch.fft.rfftfreq(L, d=1.0 / FS).to(device=device, dtype=torch.float64)
     for a in range(n_arrays):   # one array at a time keeps the fp64 temporaries small
         gen = torch.Generator(device=device).manual_seed(seeds[a])
         theta[a] = (torch.rand(1, device=device, dtype=torch.float64, generator=gen)[0] * 160.0 - 80.0) * (np.pi / 180.0)
         s = torch.randn(L, device=device, dtype=torch.float64, generator=gen) * 0.1
         S = torch.fft.rfft(s)
-        adv = xs * torch.sin(theta[a]) / 346.1
+        adv = xs_t * torch.sin(theta[a]) / 346.1
         x = torch.fft.irfft(S[None, :] * torch.exp(2j * np.pi * f[None, :] * adv[:, None]), n=L, dim=1)
-        x = x + torch.randn(M, L, device=device, dtype=torch.float64, generator=gen) * 0.01
+        x = x + torch.randn(n_mics, L, device=device, dtype=torch.float64, generator=gen) * noise
         out[a] = x.clamp_(-1.0, 1.0).to(torch.float32)
     return out, theta
 
@@ -81,20 +85,268 @@ def cpu_baseline_all_cores(pcm_host_arrays, n_frames):
     return cores * n_frames / dt, dt, cores
 
 
+def timed_loop(step, drain, steps, warmup, use_dist, dist, dev, before_timed=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    if before_timed:
+        before_timed()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def traffic_from_profiles(roof, dom, precision, shape_matches):
+    """HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh): NOT measured in this
+    run -- a --pmc pass serialises the kernels and cannot share a process with the timed loop."""
+    tj = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_TAG, precision))
+    if os.path.exists(tj) and shape_matches:
+        kk = json.load(open(tj))["kernels"].get(dom)
+        if kk:   # gfx950 correction: FETCH_SIZE reports half of a wide coalesced read stream
+            roof["traffic"] = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0
+            roof["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)"
+            roof["traffic_source"] = "profiles/%s_pmc_traffic_%s.json (committed PMC passes of the same command on an MI355X; not this run)" % (PROFILE_TAG, precision)
+
+
+def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
+    from mcarray_amd import api, synth
+    from mcarray_amd import dist as mdist
+    A, F = args.arrays, args.frames
+    mine = mdist.local_range(A * world, rank, world)          # this rank's block of the global array list
+    # context first (host-side table building, the GPU idles), input synthesis on the GPU right before the warm-up
+    ctx = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=A, device=local_rank)
+    assert ctx.D == D and ctx.P == P
+    ctx.reserve(A, F)
+    pcm, theta = synth_batch(synth.ULA8, [mdist.array_seed(0x5EED0000, g) for g in mine], F, dev)
+    # the only exchange of the path (mcarray_amd/dist.py, StepGather): ONE all_gather of the packed DOA bin + probability
+    # buffers per step (RCCL over xGMI, asynchronous, double buffered: it overlaps the next step's kernels), plus, with
+    # --gather-audio, a gather of the beamformed audio to rank 0
+    xg = mdist.StepGather(A, F, 1, dev, audio_samples=F * HOP if args.gather_audio else 0)
+    doa_rad = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+    out_local = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    state = {"last": 0}
+
+    def step():
+        b = xg.begin_step()
+        doa_bin, prob = xg.doa_buffers(b)
+        out = xg.audio_buffer(b) if args.gather_audio else out_local
+        ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=stream)
+        xg.end_step(b)
+        state["last"] = b
+
+    def arm():
+        ctx.set_timing(not args.no_kernel_timing)
+        ctx.reset_timing()
+
+    elapsed = timed_loop(step, xg.drain, args.steps, args.warmup, use_dist, dist, dev, arm)
+    ctx.set_timing(False)
+    last = state["last"]
+    last_bin = xg.doa_buffers(last)[0]
+    value = A * F * world * args.steps / elapsed
+    if args.no_kernel_timing:
+        if rank == 0:
+            print(json.dumps({"value": value, "ms_per_step": elapsed / args.steps * 1e3, "note": "A/B run without kernel timing"}))
+        return None
+
+    # per-kernel times recorded by the library with hipEvents on the launch stream
+    kt = {}
+    for kid, name in api.KERNEL_NAMES.items():
+        n, ms = ctx.get_timing(kid)
+        kt[name] = {"launches": n, "avg_ms": (ms / n if n else 0.0), "total_ms": ms}
+    dom = max(kt, key=lambda k: kt[k]["total_ms"])
+    # (a large call can run as several lanes: every kernel is then launched once per lane on its share of the arrays)
+    frames_per_launch = A * F * args.steps / max(1, kt[dom]["launches"])
+    if dom == "k_srp_gemm":
+        # algorithmic flops of this kernel per frame: real contraction [G*2K] x D, G = 7 delay groups of the ULA
+        flops = 2.0 * ctx.G * 2 * K * D * frames_per_launch
+        ach = flops / (kt[dom]["avg_ms"] * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None}
+    else:
+        per_frame = {"k_stft_phat": M * HOP * 4, "k_beamform_ola": M * HOP * 4 + HOP * 4, "k_scan_pick": D * 4 + 8}.get(dom, D * 4 + 8)
+        ach = per_frame * frames_per_launch / (kt[dom]["avg_ms"] * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_frame": per_frame}
+    traffic_from_profiles(roof, dom, args.precision, A == 8 and F == 4096)
+    repair = None
+    if args.precision == "adaptive":
+        rs = ctx.repair_stats()
+        repair = dict(rs, flagged_fraction=rs["flagged"] / max(1, rs["frames"]), recomputed_fraction=rs["recomputed"] / max(1, rs["frames"]),
+                      note="frames whose peak pick was repeated on exactly recomputed rows / rows recomputed (includes the last frame of every array and call)")
+
+    line = None
+    if rank == 0:
+        cpu = single = None
+        if world == 1 and args.cpu_frames > 0:
+            nf = min(args.cpu_frames, F)
+            fps, dt, ref = cpu_baseline(pcm[0].cpu().numpy(), nf)
+            gb = last_bin[0, :nf, 0].cpu().numpy()
+            mism = int((gb != ref["bin"][:, 0]).sum())
+            cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "array 0, first %d frames of the same input, %.1f s, double-precision scalar C restatement "
+                             "(oracle/mca_oracle.c, -O3); GPU/oracle DOA-bin mismatches on the sample: %d" % (nf, dt, mism)}
+            if args.cpu_all_cores:
+                # the reference is single threaded (faithful baseline above); this is what its host could do with one
+                # independent array per core
+                nfa = min(nf, 2048)
+                ncpu = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores whatever nproc says
+                host = [pcm[i % A].cpu().numpy() for i in range(ncpu)]
+                fps_all, dt_all, cores = cpu_baseline_all_cores(host, nfa)
+                cpu["all_cores"] = {"value": fps_all, "unit": "frames/s", "cores": cores,
+                                    "sample": "one array per thread, %d frames each, %.1f s wall" % (nfa, dt_all)}
+        if world == 1 and args.single_stream:
+            # the literal BASELINE configs[2]: ONE 8-mic array, 4096 frames batched per call (a batch this small is bound by the
+            # dependent chain of its kernels, not by throughput; an ADAPTIVE context runs it as plain FP16X3)
+            c1 = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=1, device=local_rank)
+            F1 = 4096
+            c1.reserve(1, F1)
+            p1 = pcm[:1, :, :(F1 + 1) * HOP].contiguous() if F >= F1 else synth_batch(synth.ULA8, [0x5EED0000], F1, dev)[0]
+            b1 = torch.empty(1, F1, 1, dtype=torch.int32, device=dev)
+            r1 = torch.empty(1, F1, 1, dtype=torch.float32, device=dev)
+            q1 = torch.empty(1, F1, 1, dtype=torch.float32, device=dev)
+            o1 = torch.empty(1, 1, F1 * HOP, dtype=torch.float32, device=dev)
+            n1 = max(10, min(args.steps, 100))
+            e1 = timed_loop(lambda: c1.process_frames_dev(p1, F1, b1, r1, q1, None, o1, stream=stream), lambda: None, n1, 5, False, None, dev)
+            single = {"value": F1 * n1 / e1, "unit": "frames/s", "ms_per_call": e1 / n1 * 1e3, "calls": n1,
+                      "workload": "1 array x 4096 frames per call (BASELINE configs[2] as written)"}
+            c1.close()
+        line = {
+            "metric": "STFT frames/sec, 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum beamform @48kHz/1024-pt",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (SRP operands %s)" % args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] geometry (8-mic ULA 0.04 m, 48 kHz, N=1024, hop 512, 361 angles, "
+                                   "1 source, no power floor), %d arrays x %d frames per GPU per step" % (A, F),
+                       "arrays_per_gpu": A, "frames_per_array": F, "srp_precision": args.precision,
+                       "parallelism": "arrays sharded over %d GPU(s), all_gather of DOA bins+prob%s" % (world, " + gather of the beamformed audio to rank 0" if args.gather_audio else ""),
+                       "single_stream_4096": single},
+            "algorithmic_GBps": value * BYTES_PER_FRAME / 1e9,
+            "hbm_roofline_frac": value * BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world),
+            "kernels": kt, "roofline": roof, "cpu_baseline": cpu, "repair": repair,
+            "exchange": {"backend": dist.get_backend() if use_dist else None, "gather_audio": bool(args.gather_audio),
+                         "bytes_per_step_per_rank": 8 * A * F + (4 * A * F * HOP if args.gather_audio else 0)},
+        }
+    if use_dist:
+        # the gathered buffers hold every rank's block at its global position
+        all_bin, all_prob = xg.gathered_doa(last)
+        mine_bin, mine_prob = xg.doa_buffers(last)
+        ok = torch.equal(all_bin[rank * A:(rank + 1) * A], mine_bin) and torch.equal(all_prob[rank * A:(rank + 1) * A], mine_prob)
+        if args.gather_audio and rank == 0:
+            ok = ok and torch.equal(xg.gathered_audio(last)[:A], xg.audio_buffer(last))
+        if not ok:
+            print("rank %d: gathered buffers do not contain this rank's block" % rank, file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
+    return line
+
+
+def run_mvdr(args, world, rank, local_rank, dev, use_dist, dist):
+    """BASELINE configs[3]: 16-mic frequency-domain beamformer with a per-bin spatial covariance (MVDR-style), 256 concurrent
+    streams.  No reference counterpart; the CPU baseline is the build's own fp64 oracle of the same algorithm."""
+    from mcarray_amd import api, synth
+    from mcarray_amd import dist as mdist
+    S_, F, Mm = args.streams, args.mvdr_frames, 16
+    xs = synth.ULA16
+    mine = mdist.local_range(S_ * world, rank, world)
+    bf = api.MvdrBeamformer(FS, xs, NFFT, max_streams=S_, device=local_rank)
+    pcm, theta = synth_batch(xs, [mdist.array_seed(0x3D500000, g) for g in mine], F, dev)
+    doa = theta.to(torch.float32)[:, None].expand(S_, F).contiguous()        # look direction = the stream's source
+    out = torch.empty(S_, F * HOP, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    bytes_per_frame = Mm * HOP * 4 + HOP * 4                                    # PCM in once, audio out
+
+    def step():
+        bf.process_dev(pcm, F, doa, out_pcm=out, stream=stream)
+
+    def arm():
+        bf.set_timing(True)
+
+    elapsed = timed_loop(step, lambda: None, args.steps, args.warmup, use_dist, dist, dev, arm)
+    bf.set_timing(False)
+    value = S_ * F * world * args.steps / elapsed
+    kt = {}
+    for kid, name in ((0, "k_mvdr_analyse"), (1, "k_mvdr_solve"), (2, "k_mvdr_synth")):
+        n, ms = bf.get_timing(kid)
+        kt[name] = {"launches": n, "avg_ms": (ms / n if n else 0.0), "total_ms": ms}
+    dom = max(kt, key=lambda k: kt[k]["total_ms"])
+    # every kernel of this path is bounded below by the bytes it must move; the solve also by its VALU work (DESIGN.md section 4)
+    per_frame = {"k_mvdr_analyse": Mm * HOP * 4, "k_mvdr_solve": K * Mm * 8 + K * 8, "k_mvdr_synth": K * 8 + HOP * 4}[dom]
+    ach = per_frame * S_ * F / (kt[dom]["avg_ms"] * 1e-3) / 1e9
+    roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+            "algorithmic_bytes_per_frame": per_frame,
+            "note": "k_mvdr_solve reads the [bin][mic] spectra and writes one beamformed bin per (stream, frame, bin); it is VALU-issue bound (K Cholesky "
+                    "factorisations of order 16 per frame), which the HBM fraction makes visible"}
+    line = None
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            from oracle import pyoracle as po
+            po.lib()
+            n_cpu = max(1, min(S_, args.cpu_frames // F, 48))                    # ~1 000 frames/s on one core: ~3 s
+            bf.reset()                                                           # the oracle starts from a fresh state: so does this replay
+            step()
+            torch.cuda.synchronize()
+            first = out[:n_cpu].cpu().numpy()
+            host_pcm = pcm[:n_cpu].cpu().numpy().astype(np.float64)
+            host_doa = doa[:n_cpu].cpu().numpy().astype(np.float64)
+            worst = 0.0
+            t0 = time.perf_counter()
+            outs = [po.MVDR(FS, NFFT, xs).stream(host_pcm[s_], host_doa[s_])["out"] for s_ in range(n_cpu)]
+            dt = time.perf_counter() - t0
+            for s_ in range(n_cpu):
+                worst = max(worst, float(np.abs(first[s_] - outs[s_]).max() / np.abs(outs[s_]).max()))
+            cpu = {"value": n_cpu * F / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "streams 0..%d, %d frames each of the same input, %.1f s, double-precision scalar C restatement of the same algorithm "
+                             "(oracle/mca_oracle.c mca_or_mvdr_*, -O3); GPU/oracle audio error on the sample (first call of a fresh state): %.1e of the peak"
+                             % (n_cpu - 1, F, dt, worst)}
+        line = {
+            "metric": "STFT frames/sec, 16-mic frequency-domain beamformer with per-bin spatial covariance (MVDR) @48kHz/1024-pt",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: 16-mic ULA 0.02 m, 48 kHz, N=1024, hop 512, covariance memory 0.95, loading 1e-3, "
+                                   "%d concurrent streams x %d frames per GPU per step" % (S_, F),
+                       "streams_per_gpu": S_, "frames_per_stream": F, "parallelism": "streams sharded over %d GPU(s), no exchange" % world},
+            "algorithmic_GBps": value * bytes_per_frame / 1e9, "hbm_roofline_frac": value * bytes_per_frame / 1e9 / (HBM_PEAK_GBPS * world),
+            "kernels": kt, "roofline": roof, "cpu_baseline": cpu,
+        }
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # 20 untimed steps: the GPU needs ~25 ms of load before its clocks settle (3 warm-up steps read ~6 % lower)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=["ssl", "mvdr"], default="ssl", help="ssl: BASELINE configs[2] / [4] (the headline metric); mvdr: configs[3]")
     ap.add_argument("--arrays", type=int, default=8, help="independent 8-mic arrays per GPU")
     ap.add_argument("--frames", type=int, default=4096, help="STFT frames per array per step")
+    ap.add_argument("--streams", type=int, default=256, help="--config mvdr: concurrent 16-mic streams per GPU")
+    ap.add_argument("--mvdr-frames", type=int, default=64, help="--config mvdr: frames per stream per step")
     ap.add_argument("--precision", choices=list(PREC), default=os.environ.get("MCA_SRP_PRECISION", "adaptive"))
-    ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of array 0 timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=4096, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle on all host cores, one array per process (0 = skip)")
+    ap.add_argument("--single-stream", type=int, default=1, help="also time the literal configs[2] call: 1 array x 4096 frames (0 = skip)")
     ap.add_argument("--gather-audio", action="store_true",
                     help="N > 1: also gather the beamformed audio (2 KB per frame) to rank 0 every step (BASELINE configs[4]: 'RCCL gather of DOA/output')")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the kernels with HIP events (A/B: the events serialise nothing, but cost ~1 us each)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the kernels with HIP events (A/B of the event overhead)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -126,140 +378,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from mcarray_amd import api, synth
-    from mcarray_amd import dist as mdist
-    A, F = args.arrays, args.frames
-    mine = mdist.local_range(A * world, rank, world)          # this rank's block of the global array list
-    # context first (host-side table building, the GPU idles), input synthesis on the GPU right before the warm-up
-    ctx = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=A, device=local_rank)
-    assert ctx.D == D and ctx.P == P
-    ctx.reserve(A, F)
-    pcm, theta = synth_batch([mdist.array_seed(0x5EED0000, g) for g in mine], F, dev)
-    # the only exchange of the path (mcarray_amd/dist.py, StepGather): ONE all_gather of the packed DOA bin + probability
-    # buffers per step (RCCL over xGMI, asynchronous, double buffered: it overlaps the next step's kernels), plus, with
-    # --gather-audio, a gather of the beamformed audio to rank 0
-    xg = mdist.StepGather(A, F, 1, dev, audio_samples=F * HOP if args.gather_audio else 0)
-    doa_rad = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
-    out_local = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    state = {"last": 0}
-
-    def step():
-        b = xg.begin_step()
-        doa_bin, prob = xg.doa_buffers(b)
-        out = xg.audio_buffer(b) if args.gather_audio else out_local
-        ctx.process_frames_dev(pcm, F, doa_bin, doa_rad, prob, None, out, stream=stream)
-        xg.end_step(b)
-        state["last"] = b
-
-    drain = xg.drain
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    ctx.set_timing(not args.no_kernel_timing)
-    ctx.reset_timing()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.set_timing(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    last = state["last"]
-    last_bin = xg.doa_buffers(last)[0]
-    frames_per_step = A * F * world
-    value = frames_per_step * args.steps / elapsed
-
-    # per-kernel times recorded by the library with hipEvents on the launch stream
-    kt = {}
-    for kid, name in api.KERNEL_NAMES.items():
-        n, ms = ctx.get_timing(kid)
-        kt[name] = {"launches": n, "avg_ms": (ms / n if n else 0.0), "total_ms": ms}
-    dom = max(kt, key=lambda k: kt[k]["total_ms"])
-    if args.no_kernel_timing:
-        print(json.dumps({"value": value, "ms_per_step": elapsed / args.steps * 1e3, "note": "A/B run without kernel timing"}))
-        return
-    # (a large call runs as several lanes: every kernel is launched once per lane on its share of the arrays)
-    frames_per_launch = A * F * args.steps / max(1, kt[dom]["launches"])
-    if dom == "k_srp_gemm":
-        # algorithmic flops of this kernel per frame: real contraction [G*2K] x D, G = 7 delay groups of the ULA
-        flops = 2.0 * ctx.G * 2 * K * D * frames_per_launch
-        ach = flops / (kt[dom]["avg_ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None}
-    else:
-        per_frame = {"k_stft_phat": M * HOP * 4, "k_beamform_ola": M * HOP * 4 + HOP * 4, "k_scan_pick": D * 4 + 8}.get(dom, D * 4 + 8)
-        ach = per_frame * frames_per_launch / (kt[dom]["avg_ms"] * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": None}
-
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh), if present
-    tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.precision)
-    if os.path.exists(tj) and A == 8 and F == 4096:
-        kk = json.load(open(tj))["kernels"].get(dom)
-        if kk:   # gfx950 correction: FETCH_SIZE reports half of a wide coalesced read stream
-            roof["traffic"] = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0
-            roof["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)"
-
-    if rank == 0:
-        cpu = None
-        if world == 1 and args.cpu_frames > 0:
-            nf = min(args.cpu_frames, F)
-            fps, dt, ref = cpu_baseline(pcm[0].cpu().numpy(), nf)
-            gb = last_bin[0, :nf, 0].cpu().numpy()
-            mism = int((gb != ref["bin"][:, 0]).sum())
-            cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "array 0, first %d frames of the same input, %.1f s, double-precision scalar C restatement "
-                             "(oracle/mca_oracle.c, -O3); GPU/oracle DOA-bin mismatches on the sample: %d" % (nf, dt, mism)}
-            if args.cpu_all_cores:
-                # the reference is single threaded (faithful baseline above); this is what its host could do with one
-                # independent array per core
-                nfa = min(nf, 2048)
-                ncpu = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores whatever nproc says
-                host = [pcm[i % A].cpu().numpy() for i in range(ncpu)]
-                fps_all, dt_all, cores = cpu_baseline_all_cores(host, nfa)
-                cpu["all_cores"] = {"value": fps_all, "unit": "frames/s", "cores": cores,
-                                    "sample": "one array per thread, %d frames each, %.1f s wall" % (nfa, dt_all)}
-        line = {
-            "metric": "STFT frames/sec, 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum beamform @48kHz/1024-pt",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (SRP operands %s)" % args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] geometry (8-mic ULA 0.04 m, 48 kHz, N=1024, hop 512, 361 angles, "
-                                   "1 source, no power floor), %d arrays x %d frames per GPU per step" % (A, F),
-                       "arrays_per_gpu": A, "frames_per_array": F, "srp_precision": args.precision,
-                       "parallelism": "arrays sharded over %d GPU(s), all_gather of DOA bins+prob%s" % (world, " + gather of the beamformed audio to rank 0" if args.gather_audio else "")},
-            "algorithmic_GBps": value * BYTES_PER_FRAME / 1e9,
-            "hbm_roofline_frac": value * BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world),
-            "kernels": kt, "roofline": roof, "cpu_baseline": cpu,
-            "repair": ctx.repair_stats() if args.precision == "adaptive" else None,
-            "exchange": {"backend": dist.get_backend() if use_dist else None, "gather_audio": bool(args.gather_audio),
-                         "bytes_per_step_per_rank": 8 * A * F + (4 * A * F * HOP if args.gather_audio else 0)},
-        }
+    line = (run_mvdr if args.config == "mvdr" else run_ssl)(args, world, rank, local_rank, dev, use_dist, dist)
+    if rank == 0 and line is not None:
         print(json.dumps(line))
     if use_dist:
-        # the gathered buffers hold every rank's block at its global position
-        all_bin, all_prob = xg.gathered_doa(last)
-        mine_bin, mine_prob = xg.doa_buffers(last)
-        ok = torch.equal(all_bin[rank * A:(rank + 1) * A], mine_bin) and torch.equal(all_prob[rank * A:(rank + 1) * A], mine_prob)
-        if args.gather_audio and rank == 0:
-            ok = ok and torch.equal(xg.gathered_audio(last)[:A], xg.audio_buffer(last))
-        if not ok:
-            print("rank %d: gathered buffers do not contain this rank's block" % rank, file=sys.stderr)
-            dist.destroy_process_group()
-            raise SystemExit(3)
         dist.destroy_process_group()
 
 

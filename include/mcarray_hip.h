@@ -80,6 +80,15 @@ typedef struct {
     int max_arrays;            /* number of independent arrays whose state the context holds (>= 1) */
 } mca_hip_config;
 
+/* ---- page-locked host memory ---------------------------------------------- */
+/* Thin wrappers over hipHostMalloc / hipHostFree / hipHostRegister / hipHostUnregister so that a caller of the host-pointer
+ * entry points need not link HIP.  A registered range must stay allocated until it is unregistered.  The reference has no
+ * counterpart (its SignalVector buffers are plain new[] arrays, mcadefs.h:86-88). */
+void *mca_hip_host_alloc(long long bytes);
+void mca_hip_host_free(void *p);
+int mca_hip_host_register(void *p, long long bytes);
+int mca_hip_host_unregister(void *p);
+
 /* ---- lifetime ------------------------------------------------------------ */
 /* Replaces the constructors SteeringBeamforming::SteeringBeamforming + generateLookupTable
  * (SteeringBeamforming.cpp:34-94), Beamformer::Beamformer (Beamformer.cpp:33-49) and
@@ -156,7 +165,11 @@ int mca_hip_process_frames_host_i16(mca_hip_ctx *ctx, const short *pcm, int n_ar
 int mca_hip_copy_gate(mca_hip_ctx *ctx, unsigned char *voiced, float *power);
 
 /* Host-buffer variant of mca_hip_process_frames_dev (copies in, runs, copies out, synchronises);
- * pcm is [A][M][(F+1)*hop] contiguous; outputs as above, any of doa_rad/prob/energy/out_pcm may be NULL. */
+ * pcm is [A][M][(F+1)*hop] contiguous; outputs as above, any of doa_rad/prob/energy/out_pcm may be NULL.
+ * This is what a drop-in process() caller hits (src/programs/mcabeamf.cpp:101-112, test/test_mcarray.cpp:869,937).
+ * If pcm is page-locked (mca_hip_host_alloc / mca_hip_host_register below, or hipHostMalloc / hipHostRegister), the arrays
+ * go up in up to four chunks and the upload of chunk i+1, the kernels of chunk i and the download of chunk i-1 (into
+ * page-locked result buffers) overlap; pageable buffers take one synchronous copy each way.  Same results either way. */
 int mca_hip_process_frames_host(mca_hip_ctx *ctx, const float *pcm, int n_arrays, int n_frames,
                                 int *doa_bin, float *doa_rad, float *prob, float *energy, float *out_pcm);
 

@@ -159,6 +159,10 @@ SYMBOLS = [
     ("mca_hip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("mca_hip_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
     ("mca_hip_reset_timing", C.c_int, [C.c_void_p]),
+    ("mca_hip_host_alloc", C.c_void_p, [C.c_longlong]),
+    ("mca_hip_host_free", None, [C.c_void_p]),
+    ("mca_hip_host_register", C.c_int, [C.c_void_p, C.c_longlong]),
+    ("mca_hip_host_unregister", C.c_int, [C.c_void_p]),
     ("mca_hip_get_repair_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     ("mca_hip_version", C.c_char_p, []),
 ]

@@ -19,6 +19,29 @@ KERNEL_NAMES = {K_STFT_PHAT: "k_stft_phat", K_SRP_GEMM: "k_srp_gemm", K_SCAN_PIC
                 K_FOLD: "k_sum_planes", K_REPAIR: "repair"}
 
 
+class PinnedBuffer:
+    """numpy view of page-locked host memory (mca_hip_host_alloc): buffers of this kind make the host-pointer entry points
+    overlap upload, kernels and download at the rate of the PCIe link.  Keep the object alive while `.array` is in use."""
+
+    def __init__(self, shape, dtype):
+        self._lib = _lib.load()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self._lib.mca_hip_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise MCArrayHipError("mca_hip_host_alloc(%d) failed" % self.nbytes)
+        raw = (C.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._lib.mca_hip_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
 def _xyz(x):
     a = np.asarray(x, dtype=np.float64)
     if a.ndim == 1:   # ArrayDescription::make_linear_array_description (ArrayDescription.cpp:41-49)
@@ -100,8 +123,9 @@ class Context:
         self._check(self._lib.mca_hip_state_load(self.h, blob, len(blob)))
 
     # ---- stream API, host buffers ----
-    def process_frames_host(self, pcm, want_energy=False, want_audio=True):
-        """pcm float32 [A][M][(F+1)*hop] -> dict(bin [A][F][S], doa, prob, energy [A][F][D], out [A][S][F*hop])"""
+    def process_frames_host(self, pcm, want_energy=False, want_audio=True, into=None):
+        """pcm float32 [A][M][(F+1)*hop] -> dict(bin [A][F][S], doa, prob, energy [A][F][D], out [A][S][F*hop]).
+        into: optional dict of preallocated result arrays (e.g. PinnedBuffer(...).array) for bin / doa / prob / energy / out."""
         i16 = isinstance(pcm, np.ndarray) and pcm.dtype == np.int16       # 16-bit PCM goes up as it is (half the PCIe bytes)
         pcm = np.ascontiguousarray(pcm, dtype=np.int16 if i16 else np.float32)
         if pcm.ndim == 2:
@@ -113,11 +137,20 @@ class Context:
         if F < 1 or (F + 1) * self.hop != L:
             raise MCArrayHipError("pcm length must be (F+1)*hop samples")
         S, D = self.S, self.D
-        bins = np.empty((A, F, S), dtype=np.int32)
-        doa = np.empty((A, F, S), dtype=np.float32)
-        prob = np.empty((A, F, S), dtype=np.float32)
-        energy = np.empty((A, F, D), dtype=np.float32) if want_energy else None
-        out = np.empty((A, S, F * self.hop), dtype=np.float32) if want_audio else None
+        into = into or {}
+
+        def buf(key, shape, dtype):
+            b = into.get(key)
+            if b is None:
+                return np.empty(shape, dtype=dtype)
+            if b.shape != shape or b.dtype != dtype or not b.flags["C_CONTIGUOUS"]:
+                raise MCArrayHipError("into[%r] must be a contiguous %s array of shape %s" % (key, np.dtype(dtype).name, shape))
+            return b
+        bins = buf("bin", (A, F, S), np.int32)
+        doa = buf("doa", (A, F, S), np.float32)
+        prob = buf("prob", (A, F, S), np.float32)
+        energy = buf("energy", (A, F, D), np.float32) if want_energy else None
+        out = buf("out", (A, S, F * self.hop), np.float32) if want_audio else None
         fp = _lib.c_fp
         entry = self._lib.mca_hip_process_frames_host_i16 if i16 else self._lib.mca_hip_process_frames_host
         self._check(entry(

@@ -80,9 +80,11 @@ struct mca_hip_ctx {
     // lanes (see Workspace)
     Workspace lanes[MCA_MAX_LANES];
     int cur_lane = 0, a0 = 0;              // the lane being enqueued and its first array (host side, sequential)
+    long long plan_rows = 0;               // > 0: rows of the whole call while it is worked off in pieces (plan_gemm)
     int max_lanes = 1, n_lanes_last = 1;   // lanes are off by default: measured 7 % SLOWER with two on the bench shape; MCA_HIP_LANES=n enables them
     long long lane_min_rows = 8192;
     hipStream_t lane_stream[MCA_MAX_LANES] = {}; hipEvent_t lane_ev[MCA_MAX_LANES] = {}; hipEvent_t fork_ev = nullptr;
+    hipStream_t io_stream[3] = {}; hipEvent_t io_ev[8] = {};   // host-pointer entry points with page-locked buffers: copy in / run / copy out
     Workspace &ws() { return lanes[cur_lane]; }
     double *d_gate_state = nullptr;
     int *d_last_bin = nullptr; float *d_last_rad = nullptr, *d_last_prob = nullptr;
@@ -167,6 +169,8 @@ void free_ctx(mca_hip_ctx *c)
         if (c->lane_stream[i]) (void)hipStreamDestroy(c->lane_stream[i]);
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    for (auto &e : c->io_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &q : c->io_stream) if (q) (void)hipStreamDestroy(q);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
     F(c->d_fr); F(c->d_E64[0]); F(c->d_E64[1]); F(c->d_res); F(c->d_bins); F(c->d_out64);
     c->stage.release();
@@ -274,6 +278,9 @@ struct GemmPlan { bool v2; int ksplit; };
 GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
 {
     GemmPlan g;
+    // a call that is worked off in pieces (chunks of the host-pointer path, lanes) plans every piece as the whole call would
+    // be planned: a row's result then does not depend on how the call was cut (same kernel, same K segments, same order)
+    if (c->plan_rows > 0) rows = c->plan_rows;
     g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= c->v2_min_rows && !c->force_v1;
     if (g.v2) {
         g.ksplit = rows >= 65536 ? 1 : 2;   // 256 x 384 tiles need >= ~256 workgroups to fill the chip
@@ -383,8 +390,9 @@ void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_ro
 // plain FP16X3, which is what the repair pass reproduces.
 bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
+    const long long rows = c->plan_rows > 0 ? c->plan_rows : (long long)n_arrays * n_frames;     // (see plan_gemm)
     return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->cfg.use_power_floor && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 &&
-           (long long)n_arrays * n_frames >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
+           rows >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
 }
 
 // rows of one repair pass (the two-plane A rows of all listed groups may not fit the workspace budget at once)
@@ -393,8 +401,10 @@ long long repair_pass_rows(const mca_hip_ctx *c, int n_arrays, int n_frames)
     const long long gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
     const long long all = (long long)n_arrays * gpa * REPAIR_GROUP;
     long long cap = ws_max_bytes() / ((long long)2 * c->Kp * 2) / 128 * 128;
+    // (the repair contraction always leaves REPAIR_KSPLIT partial maps: Cx is sized for the worst case, all rows listed --
+    // 1.6 GB next to the 1.9 GB of two-plane A rows on the bench shape; one pass in the common case, so no empty launches)
     if (cap < 128) cap = 128;
-    return std::min(all, cap);
+    return std::min((all + 127) / 128 * 128, cap);
 }
 
 int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chunks)
@@ -592,15 +602,17 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     c->a_row_elems = c->Kp * c->a_planes;
     {
         // Error model of the coarse (one fp16 product) map, for the sensitivity test of k_scan_pick: every operand carries
-        // a relative rounding error of rms ~1.8e-4 (11-bit significand), so a term a*b of the contraction is off by
-        // ~2.5e-4 rms and C[d] by sigma_C = 2.5e-4 sqrt(sum_k a_k^2 b_k^2) <= 2.5e-4 sqrt(K/2 sum_g n_g^2) (n_g = pairs per
-        // delay group, |PHAT sum of a group| <= n_g; b = cos / sin).  For a static source the error repeats from frame to
-        // frame, so the 0.8 recursion does not average it: sigma_E = sigma_C.  A difference of two energies is decided at
-        // 8 sigma: tau = 8 sqrt(2) sigma_C, in units of the normalised energy En = (E + 15 P) / (30 P).
+        // a relative rounding error of rms ~2-3e-4 (11-bit significand), so a term a*b of the contraction is off by
+        // ~4e-4 rms and C[d] by sigma_C = 4e-4 sqrt(sum_k a_k^2 b_k^2) <= 4e-4 sqrt(K/2 sum_g n_g^2) (n_g = pairs per delay
+        // group, |PHAT sum of a group| <= n_g; b = cos / sin).  For a static source the error repeats from frame to frame,
+        // so the 0.8 recursion does not average it: sigma_E = sigma_C.  A difference of two energies is decided at
+        // 8 sigma plus head room: tau = 8 sqrt(2) 1.25 sigma_C, in units of the normalised energy En = (E + 15 P) / (30 P).
+        // Calibration (tools/adaptive_check.py, 60 random configurations, 1e9 map values): the largest |E_fp16 - E_fp16x3|
+        // seen is 0.42 tau (16-microphone ULA, static source), typically 0.2 tau.
         double sum_n2 = 0;
         if (c->ula) for (int g = 0; g < c->G; ++g) sum_n2 += (double)(c->M - 1 - g) * (c->M - 1 - g);
         else sum_n2 = c->P;
-        const double sigma_c = 2.5e-4 * std::sqrt(0.5 * c->K * sum_n2);
+        const double sigma_c = 5.0e-4 * std::sqrt(0.5 * c->K * sum_n2);
         const double scale = std::getenv("MCA_HIP_ADAPT_TAU_SCALE") ? std::atof(std::getenv("MCA_HIP_ADAPT_TAU_SCALE")) : 1.0;
         c->tau_en = (float)(scale * 8.0 * std::sqrt(2.0) * sigma_c / (30.0 * c->P));
         if (std::getenv("MCA_HIP_ADAPT_MIN_ROWS")) c->adapt_min_rows = std::atoll(std::getenv("MCA_HIP_ADAPT_MIN_ROWS"));
@@ -1009,7 +1021,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
             ga.n_list = c->ws().d_nlist; ga.list0 = (int)g0;
             const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
-            const long long max_work = (pass_rows + 127) / 128 * col_tiles * REPAIR_KSPLIT_MAX;
+            const long long max_work = (pass_rows + 127) / 128 * col_tiles * REPAIR_KSPLIT;
             dim3 gg((unsigned)std::min<long long>(max_work, 768));
             if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
             else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
@@ -1147,6 +1159,7 @@ int run_lanes(mca_hip_ctx *c, int n_arrays, int n_frames, hipStream_t st, Body b
     int rc = ensure_lane_streams(c, nl);
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->fork_ev, st));
+    c->plan_rows = (long long)n_arrays * n_frames;
     const int base = n_arrays / nl, rem = n_arrays % nl;
     int a0 = 0, started = 0;
     for (int i = 0; i < nl && !rc; ++i) {
@@ -1159,7 +1172,7 @@ int run_lanes(mca_hip_ctx *c, int n_arrays, int n_frames, hipStream_t st, Body b
         a0 += na;
     }
     for (int i = 0; i < started; ++i) (void)hipStreamWaitEvent(st, c->lane_ev[i], 0);
-    c->cur_lane = 0; c->a0 = 0;
+    c->cur_lane = 0; c->a0 = 0; c->plan_rows = 0;
     return rc;
 }
 
@@ -1334,34 +1347,6 @@ void mca_hip_graph_destroy(mca_hip_graph *g)
     delete g;
 }
 
-int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int n_frames, int *doa_bin,
-                                float *doa_rad, float *prob, float *energy, float *out_pcm)
-{
-    if (!c || !pcm || !doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const long long ms = (long long)(n_frames + 1) * c->H, as = ms * c->M;
-    const size_t n_pcm = (size_t)as * n_arrays, n_fs = (size_t)n_arrays * n_frames * c->S;
-    const size_t n_en = energy ? (size_t)n_arrays * n_frames * c->D : 0, n_out = out_pcm ? (size_t)n_arrays * c->S * n_frames * c->H : 0;
-    float *d_pcm = (float *)c->stage.get(0, n_pcm * 4), *d_rad = (float *)c->stage.get(2, n_fs * 4), *d_prob = (float *)c->stage.get(3, n_fs * 4);
-    float *d_en = (float *)c->stage.get(4, n_en * 4), *d_out = (float *)c->stage.get(5, n_out * 4);
-    int *d_bin = (int *)c->stage.get(1, n_fs * 4);
-    if (!d_pcm || !d_bin || !d_rad || !d_prob || (energy && !d_en) || (out_pcm && !d_out))
-        return fail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
-    HIP_TRY(c, hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
-    int rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
-    if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
-    if (rc) return rc;
-    HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
-    if (doa_rad) HIP_TRY(c, hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
-    if (prob) HIP_TRY(c, hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
-    if (energy) HIP_TRY(c, hipMemcpy(energy, d_en, n_en * 4, hipMemcpyDeviceToHost));
-    if (out_pcm) HIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
-    return MCA_HIP_OK;
-}
-
-
 // 16-bit PCM: upload the shorts (half the PCIe bytes), widen on the GPU
 __global__ void k_i16_to_f32(const short *src, float *dst, long long n4)
 {
@@ -1372,33 +1357,154 @@ __global__ void k_i16_to_f32(const short *src, float *dst, long long n4)
     }
 }
 
-int mca_hip_process_frames_host_i16(mca_hip_ctx *c, const short *pcm, int n_arrays, int n_frames, int *doa_bin,
-                                    float *doa_rad, float *prob, float *energy, float *out_pcm)
+extern "C++" {
+namespace {
+
+// is p page-locked host memory (hipHostMalloc / hipHostRegister, e.g. through mca_hip_host_alloc / _register)?
+bool is_pinned(const void *p)
 {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// The host-pointer stream call.  Pageable buffers: one synchronous copy in, the kernels, synchronous copies out (the
+// driver stages pageable memory through its own bounce buffers at about half the PCIe rate).  Page-locked input: the
+// arrays go up in up to four chunks on a copy stream, each chunk's kernels start when its samples have arrived, and its
+// results leave on a third stream while the next chunk computes -- input, kernels and output of a call overlap, and the
+// rate is that of the PCIe link.  Same kernels on the same per-array state either way: the outputs are bit-identical.
+template <typename SampleT>
+int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
+                             float *energy, float *out_pcm)
+{
+    constexpr bool I16 = sizeof(SampleT) == 2;
     if (!c || !pcm || !doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_arrays < 1 || n_frames < 1) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_arrays/n_frames < 1");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const long long ms = (long long)(n_frames + 1) * c->H, as = ms * c->M;
-    const size_t n_pcm = (size_t)as * n_arrays, n_fs = (size_t)n_arrays * n_frames * c->S;
-    const size_t n_en = energy ? (size_t)n_arrays * n_frames * c->D : 0, n_out = out_pcm ? (size_t)n_arrays * c->S * n_frames * c->H : 0;
+    const size_t n_pcm = (size_t)as * n_arrays, fs_ = (size_t)n_frames * c->S, fd_ = (size_t)n_frames * c->D, fo_ = (size_t)c->S * n_frames * c->H;
+    const size_t n_fs = n_arrays * fs_, n_en = energy ? n_arrays * fd_ : 0, n_out = out_pcm ? n_arrays * fo_ : 0;
     float *d_pcm = (float *)c->stage.get(0, n_pcm * 4), *d_rad = (float *)c->stage.get(2, n_fs * 4), *d_prob = (float *)c->stage.get(3, n_fs * 4);
     float *d_en = (float *)c->stage.get(4, n_en * 4), *d_out = (float *)c->stage.get(5, n_out * 4);
     int *d_bin = (int *)c->stage.get(1, n_fs * 4);
-    short *d_i16 = (short *)c->stage.get(6, n_pcm * 2);
-    if (!d_pcm || !d_i16 || !d_bin || !d_rad || !d_prob || (energy && !d_en) || (out_pcm && !d_out))
+    short *d_i16 = I16 ? (short *)c->stage.get(6, n_pcm * 2) : nullptr;
+    if (!d_pcm || !d_bin || !d_rad || !d_prob || (energy && !d_en) || (out_pcm && !d_out) || (I16 && !d_i16))
         return fail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
-    HIP_TRY(c, hipMemcpy(d_i16, pcm, n_pcm * 2, hipMemcpyHostToDevice));
-    const long long n4 = (long long)(n_pcm / 4);                    // (F+1)*hop is a multiple of 32
-    hipLaunchKernelGGL(k_i16_to_f32, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, nullptr, d_i16, d_pcm, n4);
-    int rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
-    if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
+    int rc = check_stream_args(c, d_pcm, as, ms, n_arrays, n_frames);
     if (rc) return rc;
-    HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
-    if (doa_rad) HIP_TRY(c, hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
-    if (prob) HIP_TRY(c, hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
-    if (energy) HIP_TRY(c, hipMemcpy(energy, d_en, n_en * 4, hipMemcpyDeviceToHost));
-    if (out_pcm) HIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
+
+    if (!is_pinned(pcm)) {
+        if (I16) {
+            HIP_TRY(c, hipMemcpy(d_i16, pcm, n_pcm * 2, hipMemcpyHostToDevice));
+            const long long n4 = (long long)(n_pcm / 4);                    // (F+1)*hop is a multiple of 32
+            hipLaunchKernelGGL(k_i16_to_f32, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, nullptr, d_i16, d_pcm, n4);
+        } else {
+            HIP_TRY(c, hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
+        }
+        rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
+        if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
+        if (rc) return rc;
+        HIP_TRY(c, hipDeviceSynchronize());
+        HIP_TRY(c, hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
+        if (doa_rad) HIP_TRY(c, hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
+        if (prob) HIP_TRY(c, hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
+        if (energy) HIP_TRY(c, hipMemcpy(energy, d_en, n_en * 4, hipMemcpyDeviceToHost));
+        if (out_pcm) HIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
+        return MCA_HIP_OK;
+    }
+
+    // page-locked input: chunks of arrays through three streams
+    for (int i = 0; i < 3; ++i)
+        if (!c->io_stream[i]) HIP_TRY(c, hipStreamCreateWithFlags(&c->io_stream[i], hipStreamNonBlocking));
+    constexpr int MAXC = 4;
+    for (int i = 0; i < 2 * MAXC; ++i)
+        if (!c->io_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->io_ev[i], hipEventDisableTiming));
+    hipStream_t s_in = c->io_stream[0], s_run = c->io_stream[1], s_out = c->io_stream[2];
+    // (with the power gate the call stays one chunk: mca_hip_copy_gate reads the flags of the whole call from one workspace)
+    const int nchunk = c->cfg.use_power_floor ? 1 : std::min(n_arrays, MAXC);
+    const bool out_pinned[5] = {is_pinned(doa_bin), is_pinned(doa_rad), is_pinned(prob), is_pinned(energy), is_pinned(out_pcm)};
+    int a0 = 0;
+    for (int k = 0; k < nchunk; ++k) {                       // all uploads are queued first: the link never waits for a kernel
+        const int na = n_arrays / nchunk + (k < n_arrays % nchunk ? 1 : 0);
+        if (I16) HIP_TRY(c, hipMemcpyAsync(d_i16 + (size_t)a0 * as, pcm + (size_t)a0 * as, (size_t)na * as * 2, hipMemcpyHostToDevice, s_in));
+        else HIP_TRY(c, hipMemcpyAsync(d_pcm + (size_t)a0 * as, pcm + (size_t)a0 * as, (size_t)na * as * 4, hipMemcpyHostToDevice, s_in));
+        HIP_TRY(c, hipEventRecord(c->io_ev[k], s_in));
+        a0 += na;
+    }
+    a0 = 0;
+    c->plan_rows = (long long)n_arrays * n_frames;           // every chunk is planned as the whole call (bit-identical results)
+    for (int k = 0; k < nchunk && !rc; ++k) {
+        const int na = n_arrays / nchunk + (k < n_arrays % nchunk ? 1 : 0);
+        HIP_TRY(c, hipStreamWaitEvent(s_run, c->io_ev[k], 0));
+        if (I16) {
+            const long long n4 = (long long)na * as / 4;
+            hipLaunchKernelGGL(k_i16_to_f32, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s_run, d_i16 + (size_t)a0 * as, d_pcm + (size_t)a0 * as, n4);
+        }
+        c->cur_lane = 0; c->a0 = a0;                          // the chunk's arrays on lane 0's workspace, per-array state at its offset
+        rc = localise_impl(c, d_pcm + (size_t)a0 * as, as, ms, na, n_frames, d_bin + a0 * fs_, d_rad + a0 * fs_, d_prob + a0 * fs_,
+                           energy ? d_en + a0 * fd_ : nullptr, s_run);
+        if (!rc && out_pcm) rc = separate_impl(c, d_pcm + (size_t)a0 * as, as, ms, na, n_frames, d_rad + a0 * fs_, d_out + a0 * fo_, s_run);
+        c->a0 = 0;
+        if (rc) break;
+        HIP_TRY(c, hipEventRecord(c->io_ev[MAXC + k], s_run));
+        HIP_TRY(c, hipStreamWaitEvent(s_out, c->io_ev[MAXC + k], 0));
+        if (out_pinned[0]) HIP_TRY(c, hipMemcpyAsync(doa_bin + a0 * fs_, d_bin + a0 * fs_, na * fs_ * 4, hipMemcpyDeviceToHost, s_out));
+        if (doa_rad && out_pinned[1]) HIP_TRY(c, hipMemcpyAsync(doa_rad + a0 * fs_, d_rad + a0 * fs_, na * fs_ * 4, hipMemcpyDeviceToHost, s_out));
+        if (prob && out_pinned[2]) HIP_TRY(c, hipMemcpyAsync(prob + a0 * fs_, d_prob + a0 * fs_, na * fs_ * 4, hipMemcpyDeviceToHost, s_out));
+        if (energy && out_pinned[3]) HIP_TRY(c, hipMemcpyAsync(energy + a0 * fd_, d_en + a0 * fd_, na * fd_ * 4, hipMemcpyDeviceToHost, s_out));
+        if (out_pcm && out_pinned[4]) HIP_TRY(c, hipMemcpyAsync(out_pcm + a0 * fo_, d_out + a0 * fo_, na * fo_ * 4, hipMemcpyDeviceToHost, s_out));
+        a0 += na;
+    }
+    c->plan_rows = 0;
+    (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(s_run); (void)hipStreamSynchronize(s_out);
+    if (rc) return rc;
+    c->last_arrays = n_arrays; c->last_frames = n_frames;
+    c->n_lanes_last = 1; c->lanes[0].last_a0 = 0; c->lanes[0].last_arrays = n_arrays;
+    c->e_cur ^= 1;
+    if (out_pcm) c->tail_cur ^= 1;
+    // pageable result buffers: plain copies now that everything has finished
+    if (!out_pinned[0]) HIP_TRY(c, hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
+    if (doa_rad && !out_pinned[1]) HIP_TRY(c, hipMemcpy(doa_rad, d_rad, n_fs * 4, hipMemcpyDeviceToHost));
+    if (prob && !out_pinned[2]) HIP_TRY(c, hipMemcpy(prob, d_prob, n_fs * 4, hipMemcpyDeviceToHost));
+    if (energy && !out_pinned[3]) HIP_TRY(c, hipMemcpy(energy, d_en, n_en * 4, hipMemcpyDeviceToHost));
+    if (out_pcm && !out_pinned[4]) HIP_TRY(c, hipMemcpy(out_pcm, d_out, n_out * 4, hipMemcpyDeviceToHost));
+    return MCA_HIP_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int mca_hip_process_frames_host(mca_hip_ctx *c, const float *pcm, int n_arrays, int n_frames, int *doa_bin,
+                                float *doa_rad, float *prob, float *energy, float *out_pcm)
+{
+    return process_frames_host_impl<float>(c, pcm, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, out_pcm);
+}
+
+int mca_hip_process_frames_host_i16(mca_hip_ctx *c, const short *pcm, int n_arrays, int n_frames, int *doa_bin,
+                                    float *doa_rad, float *prob, float *energy, float *out_pcm)
+{
+    return process_frames_host_impl<short>(c, pcm, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, out_pcm);
+}
+
+// page-locked host memory for the host-pointer entry points (thin wrappers, so that a caller need not link HIP)
+void *mca_hip_host_alloc(long long bytes)
+{
+    void *p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void mca_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int mca_hip_host_register(void *p, long long bytes)
+{
+    if (!p || bytes <= 0) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); g_create_error = "hipHostRegister failed"; return MCA_HIP_ERR_HIP; }
+    return MCA_HIP_OK;
+}
+int mca_hip_host_unregister(void *p)
+{
+    if (!p) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); g_create_error = "hipHostUnregister failed"; return MCA_HIP_ERR_HIP; }
     return MCA_HIP_OK;
 }
 

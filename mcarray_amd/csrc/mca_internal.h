@@ -99,19 +99,14 @@ struct ScanPickArgs {
     unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
 };
 
-constexpr int REPAIR_KSPLIT_MAX = 32;
-// The repair contraction runs on however many rows the coarse pass listed (a device-side count): few rows -> the K range is
-// what parallelises.  Split factor and partial-map stride as a function of the row count, shared by the contraction
-// (k_srp_gemm_repair) and k_repair_patch: ~1024 work items, at most REPAIR_KSPLIT_MAX partial maps.
-__host__ __device__ inline int repair_ksplit(int n_rows, int col_tiles)
-{
-    const int tiles = (n_rows + 127) / 128 * col_tiles;
-    int k = 1024 / (tiles > 0 ? tiles : 1);
-    return k < 1 ? 1 : (k > REPAIR_KSPLIT_MAX ? REPAIR_KSPLIT_MAX : k);
-}
+constexpr int REPAIR_KSPLIT = 32;
+// The repair contraction runs on however many rows the coarse pass listed (a device-side count, usually a few hundred): the
+// K range is what parallelises.  It is always cut into the same REPAIR_KSPLIT segments, whatever the row count, so that an
+// exact row's value does not depend on how many other rows were listed with it (a call worked off in chunks or lanes
+// returns the same bits).  Partial maps: [REPAIR_KSPLIT][repair_plane_stride], summed in order by k_repair_patch.
+__host__ __device__ inline int repair_ksplit(int, int) { return REPAIR_KSPLIT; }
 __host__ __device__ inline long long repair_plane_stride(int n_rows, int Dp) { return (long long)((n_rows + 127) / 128 * 128) * Dp; }
-// rows x partial maps never exceeds this many rows of Cx (1024 work items x 128 rows, or one map of all rows)
-__host__ __device__ inline long long repair_cx_rows(long long pass_rows) { return (pass_rows > 131072 ? pass_rows : 131072) + 128 * REPAIR_KSPLIT_MAX; }
+__host__ __device__ inline long long repair_cx_rows(long long pass_rows) { return ((pass_rows + 127) / 128 * 128) * REPAIR_KSPLIT; }
 
 struct RepairPatchArgs {
     const float *Cx;         // [repair_ksplit][repair_plane_stride] exact rows, split-K partial maps

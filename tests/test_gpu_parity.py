@@ -739,3 +739,47 @@ def test_state_save_and_load_resume_a_stream():
         other.state_load(blob)
     with pytest.raises(api.MCArrayHipError):
         b.state_load(blob[:100])
+
+
+def test_page_locked_host_buffers_equal_pageable_ones():
+    """The host-pointer entry point with page-locked buffers (mca_hip_host_alloc: arrays uploaded in chunks, upload / kernels /
+    download overlapped on three streams) returns bit-for-bit what the synchronous pageable path returns: fp32 and 16-bit
+    PCM, several arrays (chunked), one array, with the power gate (single chunk) and with state carried over two calls."""
+    fs, N = 48000, 1024
+    hop = N // 2
+    xs = synth.ULA8
+    for A, F, gate, prec in ((5, 70, False, api.SRP_FP16X3), (1, 40, False, api.SRP_FP32), (3, 200, True, api.SRP_FP16X3), (6, 1400, False, api.SRP_ADAPTIVE)):
+        pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-50.0 + 30 * a), fs, (F + 1) * hop, 300 + a) for a in range(A)])
+        if gate:
+            pcm[:, :, :150 * hop] *= 0.01
+        i16 = np.round(pcm * 20000).astype(np.int16)
+        for src in (pcm, i16):
+            pin = api.PinnedBuffer(src.shape, src.dtype)
+            pin.array[...] = src
+            outs = []
+            for buf, pinned in ((src, False), (pin.array, True)):
+                ctx = api.Context(fs, xs, N, 0.5, 1, use_power_floor=gate, srp_precision=prec, max_arrays=A)
+                into = None
+                keep = []
+                h = F // 2
+                parts = []
+                for sl in (slice(0, (h + 1) * hop), slice(h * hop, None)):
+                    part = np.ascontiguousarray(buf[:, :, sl])
+                    if pinned:
+                        pp = api.PinnedBuffer(part.shape, part.dtype)
+                        pp.array[...] = part
+                        nf = part.shape[2] // hop - 1
+                        ob = {"bin": api.PinnedBuffer((A, nf, 1), np.int32), "out": api.PinnedBuffer((A, 1, nf * hop), np.float32)}
+                        keep += [pp] + list(ob.values())
+                        r = ctx.process_frames_host(pp.array, want_energy=True, into={k: v.array for k, v in ob.items()})
+                    else:
+                        r = ctx.process_frames_host(part, want_energy=True)
+                    parts.append({k: np.array(v) for k, v in r.items() if v is not None})
+                outs.append({k: np.concatenate([q[k] for q in parts], axis=2 if k == "out" else 1) for k in parts[0]})
+                ctx.close()
+            for k in outs[0]:
+                if k == "power":        # the frame power is summed over the 8 waves with LDS float atomics: the order, hence the last bit, varies
+                    np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=1e-6)
+                    continue
+                assert np.array_equal(outs[0][k], outs[1][k]), (A, F, gate, prec, src.dtype, k)
+            pin.close()
