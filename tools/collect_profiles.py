@@ -10,17 +10,19 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
 def short(name):
     m = re.search(r"(k_[a-z0-9_]+?)(?:_f16_v2|_f16|_f32|IL|<|\(|E)", name)
     base = m.group(1) if m else name
+    if base.startswith("k_srp_gemm_repair"):
+        return "k_srp_gemm_repair"
     return "k_srp_gemm" if base.startswith("k_srp_gemm") else base
 
 
-for prec in ("fp16x3", "fp16", "fp32"):
+for prec in ("adaptive", "fp16x3", "fp16", "fp32"):
     log = os.path.join(G, "final", "bench_%s.log" % prec)
     if os.path.exists(log):
         lines = [l for l in open(log) if l.startswith("{")]
@@ -36,11 +38,19 @@ for prec in ("fp16x3", "fp16", "fp32"):
                          "--steps 3 --warmup 1 --cpu-frames 0 --precision %s` (tools/pmc_traffic.sh), MI355X" % prec,
                "correction": "gfx950: FETCH_SIZE counts exactly half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM "
                              "section): hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
-               "workload": "8 arrays x 4096 frames per launch", "kernels": {}}
+               "workload": "8 arrays x 4096 frames per step; values are per STEP (a kernel that runs twice per step -- k_stft_phat in "
+                           "the adaptive mode: all frames, then the listed repair groups -- has both launches added up)", "kernels": {}}
+        steps = {c: max(1, min(v[c]["dispatches"] for v in raw.values() if c in v)) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+        tot = 0.0
         for k, v in raw.items():
-            out["kernels"][short(k)] = {"kernel": k,
-                                        "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"]["sum"] / v["FETCH_SIZE"]["dispatches"],
-                                        "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"]["sum"] / v["WRITE_SIZE"]["dispatches"]}
+            e = {"kernel": k, "dispatches_per_step": v["FETCH_SIZE"]["dispatches"] / steps["FETCH_SIZE"],
+                 "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"]["sum"] / steps["FETCH_SIZE"],
+                 "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"]["sum"] / steps["WRITE_SIZE"]}
+            e["hbm_bytes_per_step"] = (2.0 * e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"]) * 1024.0
+            tot += e["hbm_bytes_per_step"]
+            out["kernels"][short(k)] = e
+        out["total_hbm_bytes_per_step"] = tot
+        out["algorithmic_bytes_per_step"] = 18440 * 32768
         json.dump(out, open(os.path.join(P, "%s_pmc_traffic_%s.json" % (tag, prec)), "w"), indent=1)
 ks = os.path.join(G, "final", "kernel_stats_mvdr.csv")
 if os.path.exists(ks):
@@ -50,12 +60,16 @@ if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
     if lines:
         open(os.path.join(P, "%s_bench_mvdr.json" % tag), "w").write(lines[-1])
-sq = os.path.join(G, "pmc_sq", "sq_fp16x3.json")
+for name in ("adaptive_check.json", "precision_report.json", "host_path.log"):
+    src = os.path.join(G, "final", name)
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copy(src, os.path.join(P, "%s_%s" % (tag, name)))
+sq = os.path.join(G, "pmc_sq", "sq_adaptive.json")
 if os.path.exists(sq):
     raw = json.load(open(sq))
     out = {"source": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, tools/pmc_sq.sh) of `python3 bench.py --steps 2 "
-                     "--warmup 1 --cpu-frames 0 --precision fp16x3`, MI355X, values per dispatch (8 arrays x 4096 frames)",
+                     "--warmup 1 --cpu-frames 0 --precision adaptive`, MI355X, values per dispatch (8 arrays x 4096 frames)",
            "notes": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_BUSY_CYCLES is summed over "
                     "the 32 shader engines; SQ_INSTS_* are wave-instructions.", "kernels": raw}
-    json.dump(out, open(os.path.join(P, "%s_pmc_sq_fp16x3.json" % tag), "w"), indent=1)
+    json.dump(out, open(os.path.join(P, "%s_pmc_sq_adaptive.json" % tag), "w"), indent=1)
 print(sorted(os.listdir(P)))

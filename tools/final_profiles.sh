@@ -1,15 +1,22 @@
+# Round profiles: bench lines, rocprofv3 kernel stats, PMC traffic / SQ counters, adaptive-precision check, host path.
+# usage (GPU box, from the repo root): bash tools/final_profiles.sh ; then python tools/collect_profiles.py r02 here
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
-for p in fp16x3 fp16 fp32; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_$p -- python3 bench.py --steps 100 --warmup 20 --cpu-frames 0 --precision $p > gpurun_out/final/rocprof_$p.log 2>&1
+for p in adaptive fp16x3; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_$p -- python3 bench.py --steps 100 --warmup 20 --cpu-frames 0 --single-stream 0 --precision $p > gpurun_out/final/rocprof_$p.log 2>&1
   python3 tools/summarize_rocprof.py gpurun_out/final/rocprof_$p gpurun_out/final/kernel_stats_$p.csv > /dev/null
 done
-timeout 900 python bench.py > gpurun_out/final/bench_fp16x3.log 2>&1
+timeout 900 python bench.py > gpurun_out/final/bench_adaptive.log 2>&1
+timeout 900 python bench.py --precision fp16x3 --cpu-frames 0 > gpurun_out/final/bench_fp16x3.log 2>&1
 timeout 900 python bench.py --precision fp16 --cpu-frames 0 > gpurun_out/final/bench_fp16.log 2>&1
-timeout 900 python bench.py --precision fp32 --cpu-frames 0 > gpurun_out/final/bench_fp32.log 2>&1
 # BASELINE configs[3]: the MVDR path (256 streams x 64 frames, 16 microphones)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_mvdr -- python3 tools/bench_mvdr_dev.py --check 0 --steps 10 > gpurun_out/final/rocprof_mvdr.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_mvdr -- python3 bench.py --config mvdr --steps 20 --warmup 5 --cpu-frames 0 > gpurun_out/final/rocprof_mvdr.log 2>&1
 python3 tools/summarize_rocprof.py gpurun_out/final/rocprof_mvdr gpurun_out/final/kernel_stats_mvdr.csv > /dev/null
-timeout 300 python tools/bench_mvdr_dev.py > gpurun_out/final/bench_mvdr.log 2>&1
-tail -c 600 gpurun_out/final/bench_fp16x3.log
-cat gpurun_out/final/kernel_stats_fp16x3.csv
+timeout 300 python bench.py --config mvdr > gpurun_out/final/bench_mvdr.log 2>&1
+bash tools/pmc_traffic.sh adaptive gpurun_out/pmc_traffic_adaptive > gpurun_out/final/pmc_traffic.log 2>&1
+bash tools/pmc_sq.sh adaptive gpurun_out/pmc_sq > gpurun_out/final/pmc_sq.log 2>&1
+timeout 600 python tools/adaptive_check.py 40 2026 > gpurun_out/final/adaptive_check.json 2> gpurun_out/final/adaptive_check.log
+timeout 600 python tools/precision_report.py > gpurun_out/final/precision_report.json 2> gpurun_out/final/precision_report.log
+timeout 300 python tools/host_path_rate.py > gpurun_out/final/host_path.log 2>&1
+tail -c 400 gpurun_out/final/bench_adaptive.log
+cat gpurun_out/final/kernel_stats_adaptive.csv
