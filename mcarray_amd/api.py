@@ -176,6 +176,10 @@ class Context:
         if not pcm.is_contiguous():
             raise MCArrayHipError("pcm must be contiguous")
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        if localise and separate and out_pcm is not None and doa_rad is not None:
+            self._check(self._lib.mca_hip_process_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_bin), ptr(doa_rad), ptr(prob),
+                                                             ptr(energy), ptr(out_pcm), stream))
+            return
         if localise:
             self._check(self._lib.mca_hip_localise_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_bin),
                                                               ptr(doa_rad), ptr(prob), ptr(energy), stream))

@@ -1126,12 +1126,20 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
 extern "C++" {
 namespace {
 
+// is `st` being recorded into a graph?  (the null stream cannot be captured; asking about it is an error on some runtimes)
+bool stream_is_capturing(hipStream_t st)
+{
+    if (!st) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 // how many lanes a call of this shape is split into
 int lanes_for(mca_hip_ctx *c, int n_arrays, int n_frames, hipStream_t st)
 {
     if (c->max_lanes <= 1 || n_arrays < 2) return 1;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 1;   // a recording stays on its stream
+    if (stream_is_capturing(st)) return 1;               // a recording stays on its stream
     long long n = (long long)n_arrays * n_frames / c->lane_min_rows;
     n = std::min<long long>(n, std::min(c->max_lanes, n_arrays));
     return (int)std::max<long long>(n, 1);

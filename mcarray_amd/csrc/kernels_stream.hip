@@ -396,15 +396,15 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
     const int *nvp = p.nvoiced + (long long)a * p.n_chunks;
     const float *pp = p.part + (long long)a * p.n_chunks * p.D + d;
     float *ep = p.e_start + (long long)a * p.n_chunks * p.D + d;
-    for (int c0 = 0; c0 < p.n_chunks; c0 += 8) {                     // 8 independent loads in flight, then the serial composition
-        int nv8[8]; float b8[8];
+    for (int c0 = 0; c0 < p.n_chunks; c0 += 16) {                    // 16 chunks (32 loads) in flight, then the serial composition
+        int nv8[16]; float b8[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 16; ++i) {
             const int c = min(c0 + i, p.n_chunks - 1);
             nv8[i] = nvp[c]; b8[i] = pp[(long long)c * p.D];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 16; ++i)
             if (c0 + i < p.n_chunks) { ep[(long long)(c0 + i) * p.D] = E; E = spow[nv8[i]] * E + b8[i]; }
     }
     p.state_out[(long long)a * p.D + d] = E;                         // _prevEnergyInDOA (:143)

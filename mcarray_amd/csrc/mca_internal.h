@@ -13,8 +13,14 @@ constexpr int BF_NB = 4;           // frames per inverse-FFT batch of k_beamform
 constexpr int GCC2_DOAWARM = 64;   // frames of DOA-recursion warm-up in k_gcc2_scan (0.6^64 = 6e-15)
 constexpr int SCAN_WARM = 96;     // frames of IIR warm-up per scan chunk (0.8^96 = 5e-10 << fp32 epsilon)
 constexpr int KG = 513;            // complex K-slots per delay group in the A / B contraction index (g * KG + k)
-constexpr int SCAN_CHUNK = 64;    // frames per chunk of the exact chunked scan
-constexpr int SCAN_SUB = 32;      // frames per LDS sub-batch of k_scan_pick
+#ifndef MCA_SCAN_CHUNK
+#define MCA_SCAN_CHUNK 32
+#endif
+#ifndef MCA_SCAN_SUB
+#define MCA_SCAN_SUB 32
+#endif
+constexpr int SCAN_CHUNK = MCA_SCAN_CHUNK;    // frames per chunk of the exact chunked scan (32: 0.928 ms per bench step, 64: 0.965; must exceed REPAIR_WARM)
+constexpr int SCAN_SUB = MCA_SCAN_SUB;      // frames per LDS sub-batch of k_scan_pick
 constexpr int REPAIR_WARM = 24;   // exact rows recomputed BEFORE a flagged frame (adaptive SRP precision): 0.8^25 = 3.8e-3 of the coarse error
                                   // remains, i.e. ~6e-8 of the map's peak -- 30 x below the error of the three-product split itself
 constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mode pass of a k_stft_phat workgroup
