@@ -50,8 +50,9 @@ typedef enum {
     MCA_HIP_SRP_ADAPTIVE = 3 /* fp16 coarse scan of every frame + exact repair: the frames whose peak pick is sensitive to the
                                 fp16 error (and the rows their energy depends on) are recomputed with the FP16X3 split and
                                 picked again, so the DOA bins are those of FP16X3 at about the cost of FP16.  Applies to large
-                                batches on the 1024-sample / 361-angle path without the power gate; every other call of such a
-                                context runs as FP16X3.  The optional energy map keeps fp16 accuracy on unrepaired frames. */
+                                batches (>= 8192 frames per call) on the 1024-sample path with more than two microphones, with
+                                or without the power gate; every other call of such a context runs as FP16X3.  The optional
+                                energy map keeps fp16 accuracy on unrepaired frames. */
 } mca_hip_srp_precision;
 
 typedef struct mca_hip_ctx mca_hip_ctx;
@@ -253,6 +254,8 @@ int mca_hip_mask_get_thresholds(const mca_hip_mask_ctx *ctx, double *thresholds,
 /* STFT + FastBinauralMasking::processParametrisation (FastBinauralMasking.cpp:126-210) + inverse FFT +
  * overlap-add for n_frames frames of n_streams independent 2-channel streams.
  * pcm_dev: sample n of channel c of stream s at pcm[s*stream_stride + c*ch_stride + n], (F+1)*hop samples;
+ * The streams of a context start and advance together (the module's first-frame behaviour, FastBinauralMasking.cpp:186-197,
+ * is tracked once per context): every call after create / reset must pass the same n_streams, else INVALID_ARGUMENT.
  * out_pcm_dev [streams][2][F*hop]; decisions_dev (may be NULL) [streams][F][45] int32:
  * 0 enhance, 1 temporal mask, 2 spatial mask. */
 int mca_hip_mask_frames_dev(mca_hip_mask_ctx *ctx, const float *pcm_dev, long long stream_stride, long long ch_stride,

@@ -44,14 +44,14 @@ struct Workspace {
     float *d_part = nullptr, *d_estart = nullptr; int *d_nv = nullptr; size_t scan_ws_chunks = 0;
     float *d_power = nullptr; unsigned char *d_voiced = nullptr; float *d_power_out = nullptr; size_t gate_frames = 0;
     // ADAPTIVE: flags, repair list
-    unsigned char *d_flags = nullptr; int *d_chunk_first = nullptr, *d_list = nullptr, *d_need = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
-    int *d_nlist = nullptr;
+    unsigned char *d_flags = nullptr; int *d_chunk_from = nullptr, *d_list = nullptr, *d_need = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
+    int *d_nlist = nullptr, *d_last_vchunk = nullptr; size_t lastv_arrays = 0;
     int last_a0 = 0, last_arrays = 0;                 // the arrays this lane ran in the last call (mca_hip_copy_gate)
     void release()
     {
         auto F = [](void *q) { if (q) (void)hipFree(q); };
         F(d_A); F(d_Ax); F(d_C); F(d_Cx); F(d_part); F(d_estart); F(d_nv); F(d_power); F(d_voiced); F(d_power_out);
-        F(d_flags); F(d_chunk_first); F(d_list); F(d_need); F(d_nlist);
+        F(d_flags); F(d_chunk_from); F(d_list); F(d_need); F(d_nlist); F(d_last_vchunk);
         *this = Workspace();
     }
 };
@@ -391,7 +391,7 @@ void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_ro
 bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     const long long rows = c->plan_rows > 0 ? c->plan_rows : (long long)n_arrays * n_frames;     // (see plan_gemm)
-    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->cfg.use_power_floor && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 &&
+    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 &&
            rows >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
 }
 
@@ -418,10 +418,10 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
         c->ws().adapt_frames = nf; ++c->ws_gen;
     }
     if (nc > c->ws().adapt_chunks) {
-        if (c->ws().d_chunk_first) (void)hipFree(c->ws().d_chunk_first);
-        c->ws().d_chunk_first = nullptr; c->ws().adapt_chunks = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->ws().d_chunk_first, nc * 4));
-        HIP_TRY(c, hipMemset(c->ws().d_chunk_first, 0x7f, nc * 4));       // "no flagged frame"; kept so by k_scan_repick
+        if (c->ws().d_chunk_from) (void)hipFree(c->ws().d_chunk_from);
+        c->ws().d_chunk_from = nullptr; c->ws().adapt_chunks = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_chunk_from, nc * 4));
+        HIP_TRY(c, hipMemset(c->ws().d_chunk_from, 0x7f, nc * 4));       // "no flagged frame"; kept so by k_scan_repick
         HIP_TRY(c, hipDeviceSynchronize());
         c->ws().adapt_chunks = nc; ++c->ws_gen;
     }
@@ -434,6 +434,12 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
         HIP_TRY(c, hipMemset(c->ws().d_need, 0, ng * 4));                 // test-and-set words; released by k_repair_patch
         HIP_TRY(c, hipDeviceSynchronize());
         c->ws().adapt_groups = ng; ++c->ws_gen;
+    }
+    if ((size_t)n_arrays > c->ws().lastv_arrays) {
+        if (c->ws().d_last_vchunk) (void)hipFree(c->ws().d_last_vchunk);
+        c->ws().d_last_vchunk = nullptr; c->ws().lastv_arrays = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_last_vchunk, (size_t)n_arrays * 4));
+        c->ws().lastv_arrays = n_arrays; ++c->ws_gen;
     }
     if (!c->ws().d_nlist) {
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_nlist, 4));
@@ -977,7 +983,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     const int gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
     if (adaptive) {
         pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
-        pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_first = c->ws().d_chunk_first; pa.stats = c->d_rstats;
+        pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_from = c->ws().d_chunk_from; pa.last_vchunk = c->ws().d_last_vchunk; pa.stats = c->d_rstats;
     }
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
@@ -987,13 +993,11 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (smem3 > 64 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
     hipLaunchKernelGGL(k_scan_pick, g3, dim3(std::max(nthr, 512)), smem3, st, pa);   // 8 waves: the per-frame pick is one wave per frame
-    if (gate) {
-        DoaFillArgs fa{};
-        fa.voiced = c->ws().d_voiced; fa.n_frames = n_frames; fa.S = c->S;
-        fa.doa_bin = doa_bin; fa.doa_rad = doa_rad; fa.prob = prob;
-        fa.last_bin = c->d_last_bin + a0 * c->S; fa.last_rad = c->d_last_rad + a0 * c->S; fa.last_prob = c->d_last_prob + a0 * c->S;
-        hipLaunchKernelGGL(k_doa_fill, dim3(n_arrays), dim3(1024), 0, st, fa);
-    }
+    DoaFillArgs fa{};
+    fa.voiced = c->ws().d_voiced; fa.n_frames = n_frames; fa.S = c->S;
+    fa.doa_bin = doa_bin; fa.doa_rad = doa_rad; fa.prob = prob;
+    fa.last_bin = c->d_last_bin + a0 * c->S; fa.last_rad = c->d_last_rad + a0 * c->S; fa.last_prob = c->d_last_prob + a0 * c->S;
+    if (gate && !adaptive) hipLaunchKernelGGL(k_doa_fill, dim3(n_arrays), dim3(1024), 0, st, fa);   // (ADAPTIVE: after the second pick)
     time_end(c, st);
     HIP_TRY(c, hipGetLastError());
     if (adaptive) {
@@ -1033,6 +1037,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         }
         set_call_planes(c, 1);
         hipLaunchKernelGGL(k_scan_repick, g3, dim3(std::max(nthr, 512)), (size_t)32 * (c->Dp + 8) * sizeof(float), st, pa);
+        if (gate) hipLaunchKernelGGL(k_doa_fill, dim3(n_arrays), dim3(1024), 0, st, fa);   // gated-out frames repeat the last FINAL pick
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
         c->adapt_frames_total += (unsigned long long)n_arrays * n_frames;

@@ -28,6 +28,7 @@ struct mca_hip_mask_ctx {
     float *d_Q[2] = {nullptr, nullptr}, *d_noise = nullptr, *d_tail[2] = {nullptr, nullptr};
     int q_cur = 0, tail_cur = 0;
     long long frames_done = 0;
+    int streams_in_use = 0;           // n_streams of the first stream call after create / reset: the context counts frames once for all streams
     // frame API (double)
     double *d_H = nullptr, *d_thr = nullptr, *d_Q64 = nullptr, *d_noise64 = nullptr, *d_io = nullptr;   // d_io: L, R, outL, outR
     int *d_dec = nullptr;
@@ -192,7 +193,7 @@ int mca_hip_mask_reset(mca_hip_mask_ctx *c)
     for (int i = 0; i < 2; ++i) { MHIP_TRY(c, hipMemset(c->d_Q[i], 0, ns * 45 * 4)); MHIP_TRY(c, hipMemset(c->d_tail[i], 0, ns * 2 * c->hop * 4)); }
     MHIP_TRY(c, hipMemset(c->d_noise, 0, ns * 45 * 4));
     MHIP_TRY(c, hipMemset(c->d_Q64, 0, 45 * 8)); MHIP_TRY(c, hipMemset(c->d_noise64, 0, 45 * 8));
-    c->frames_done = 0; c->first_call = 0;
+    c->frames_done = 0; c->first_call = 0; c->streams_in_use = 0;
     return MCA_HIP_OK;
 }
 
@@ -212,6 +213,11 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
     if (!pcm || !out_pcm) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev/out_pcm_dev is NULL");
     if (n_streams < 1 || n_streams > c->cfg.max_streams) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_streams outside [1, max_streams]");
     if (n_frames < 1) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_frames < 1");
+    // frames_done (first-frame behaviour of the Q recursion, NOISY's noise capture: FastBinauralMasking.cpp:186-197) is kept once
+    // per context, so all streams of a context start together and advance together: a call with another number of streams
+    // would give the late or missing slots the not-first-frame path
+    if (c->streams_in_use && n_streams != c->streams_in_use)
+        return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "n_streams differs from the first call after create / reset: the streams of a masking context advance together (mca_hip_mask_reset starts over)");
     const long long need = (long long)(n_frames + 1) * c->hop;
     if (ch_stride < need || (n_streams > 1 && stream_stride < ch_stride + need)) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "strides shorter than (n_frames+1)*hop samples");
     if ((ch_stride & 1) || (stream_stride & 1) || (reinterpret_cast<uintptr_t>(pcm) & 7)) return mfail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "pcm_dev must be 8-byte aligned with even strides");
@@ -268,7 +274,7 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
     }
     MHIP_TRY(c, hipGetLastError());
     c->q_cur ^= 1; c->tail_cur ^= 1;
-    c->frames_done += n_frames;
+    c->frames_done += n_frames; c->streams_in_use = n_streams;
     return MCA_HIP_OK;
 }
 
@@ -320,7 +326,7 @@ int mca_hip_mask_state_save(mca_hip_mask_ctx *c, void *blob, long long bytes)
 {
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
     MHIP_TRY(c, hipSetDevice(c->cfg.device));
-    BlobHeader h{MASK_MAGIC, 1, mask_cfg_hash(c), 0, {c->frames_done, (long long)c->first_call, 0, 0}};
+    BlobHeader h{MASK_MAGIC, 1, mask_cfg_hash(c), 0, {c->frames_done, (long long)c->first_call, (long long)c->streams_in_use, 0}};
     const int rc = blob_save(mask_parts(c), h, blob, bytes);
     return rc ? mfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc)) : MCA_HIP_OK;
 }
@@ -332,7 +338,7 @@ int mca_hip_mask_state_load(mca_hip_mask_ctx *c, const void *blob, long long byt
     BlobHeader h;
     const int rc = blob_load(mask_parts(c), MASK_MAGIC, mask_cfg_hash(c), blob, bytes, &h);
     if (rc) return mfail(c, rc == 2 ? MCA_HIP_ERR_HIP : MCA_HIP_ERR_INVALID_ARGUMENT, blob_error(rc));
-    c->frames_done = h.host[0]; c->first_call = (int)h.host[1];
+    c->frames_done = h.host[0]; c->first_call = (int)h.host[1]; c->streams_in_use = (int)h.host[2];
     return MCA_HIP_OK;
 }
 

@@ -385,6 +385,17 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
     __shared__ float spow[SCAN_CHUNK + 1];                          // 0.8f^n
     const int d = threadIdx.x, a = blockIdx.x;
     if (p.mode == 1 && a == 0 && d == 0) *p.n_list = 0;              // adaptive SRP precision: the repair list starts empty
+    __shared__ int s_lv;
+    if (d == 0) s_lv = -1;
+    __syncthreads();
+    if (p.mode == 1) {
+        // the chunk that holds the array's last frame whose energy advanced (= its last frame without the gate): that frame is
+        // always repaired, so that the state handed to the next call is exact
+        for (int c = d; c < p.n_chunks; c += blockDim.x)
+            if (p.nvoiced[(long long)a * p.n_chunks + c] > 0) atomicMax(&s_lv, c);
+        __syncthreads();
+        if (d == 0) p.last_vchunk[a] = s_lv;
+    }
     for (int n = d; n <= SCAN_CHUNK; n += blockDim.x) {
         float g = 1.f;
         for (int i = 0; i < n; ++i) g *= p.mu;
@@ -420,7 +431,7 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
 // bounded by tau,
 //   * a position dd is UNCERTAIN if any of the four first differences its second derivative reads (the sign / median-3
 //     chain of selectDOA) lies within +-tau of zero -- its sd could then be -En, 0 or +En[dd+1];
-//   * the frame is sensitive if an uncertain position could reach the S-th picked value (En[dd+1] >= v_S - tau; any
+//   * the frame is sensitive if an uncertain position could reach the S-th picked value (|En[dd+1]| >= v_S - tau; any
 //     uncertain position at all when fewer than S positive peaks exist), or if two of the S+1 largest candidates lie within
 //     tau of each other (their order, or which one is the last pick, is open).
 // Every other frame's picks are the exact map's picks.
@@ -429,7 +440,7 @@ __device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p
 {
     const int D = p.D;
     float sdv[8];
-    float umax = -INFINITY;                                     // SENS: largest En[dd+1] over the uncertain positions
+    float umax = -INFINITY;                                     // SENS: largest |En[dd+1]| over the uncertain positions
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int dd = lane + 64 * i;
@@ -450,7 +461,7 @@ __device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p
             sd = (m1 - m0) * ed1;                                  // :170-173
             if (SENS) {
                 const float dmin = fminf(fminf(fabsf(dm1), fabsf(d0)), fminf(fabsf(d1), fabsf(d2)));
-                if (dmin <= p.tau) umax = fmaxf(umax, ed1);
+                if (dmin <= p.tau) umax = fmaxf(umax, fabsf(ed1));       // (a trough of negative energy is a candidate too: sd = -En > 0)
             }
         }
         sdv[i] = sd;
@@ -494,9 +505,10 @@ __device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p
 // p.mode == 1 (coarse pass of the adaptive SRP precision): a frame whose picks are sensitive to the fp16 error -- and the
 // last frame of the call, so that the state handed to the next call is exact too -- is flagged, and the wave that found it
 // plans its repair on the spot: the groups of REPAIR_GROUP frames that hold its own row and the REPAIR_WARM rows before it
-// (its energy is 0.2 sum_k 0.8^k C_{t-k}) go onto the repair list (once: `need` is a test-and-set per group), and its
-// position becomes the chunk's first flagged one if it is.  need / chunk_first are cleaned by the kernels that consume
-// them (k_repair_patch, k_scan_repick); the list's length is reset by k_scan_carry.
+// (its energy is 0.2 sum_k 0.8^k C_{t-k} over the frames that advanced the recursion: with the power gate only the voiced ones,
+// BeamformingSeparationAndLocalisation.cpp:87) go onto the repair list (once: `need` is a test-and-set per group), and the chunk
+// learns which chunk its second pick has to restart from.  need / chunk_from are cleaned by the kernels that consume them
+// (k_repair_patch, k_scan_repick); the list's length is reset by k_scan_carry.
 __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -536,9 +548,16 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         __syncthreads();
         for (int tl = wave; tl < te - ts; tl += nwaves) {
             const int t = ts + tl;
-            bool flag = p.mode == 1 && t == p.n_frames - 1;
+            bool flag = false;
+            if (p.mode == 1 && (int)blockIdx.x == p.last_vchunk[a]) {   // the array's last frame that advances the recursion
+                bool later = false;
+                if (vc) for (int u = t + 1; u < t_end; ++u) later |= vc[u] != 0;
+                else later = t + 1 < t_end;
+                flag = !later;
+            }
             if (vc && !vc[t]) {                                         // gated out: selectDOA is not reached (:87)
                 if (lane < p.S) p.doa_bin[((long long)a * p.n_frames + t) * p.S + lane] = -1;
+                flag = false;
             } else if (p.mode == 1) {
                 flag |= wave_pick<true>(sEn + tl * Dl, p, ((long long)a * p.n_frames + t) * p.S, lane);
             } else {
@@ -547,16 +566,29 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
             if (p.mode == 1) {
                 if (lane == 0) p.flags[(long long)a * p.n_frames + t] = flag ? 1 : 0;
                 if (flag) {
-                    const int q_lo = max(t - REPAIR_WARM, 0) / REPAIR_GROUP, q_hi = t / REPAIR_GROUP;
-                    for (int q = q_lo + lane; q <= q_hi; q += 64) {
-                        const int e = a * p.groups_per_array + q;
-                        if (atomicExch(&p.need[e], 1) == 0) {
-                            p.list[atomicAdd(p.n_list, 1)] = e;
-                            atomicAdd(&p.stats[1], 1ull);
+                    // the rows this frame's energy depends on: its own and those of the REPAIR_WARM frames before it that advanced
+                    // the recursion (all of them without the gate, the voiced ones with it), 64 frames per step backwards
+                    int remaining = REPAIR_WARM + 1, u_min = t;
+                    for (int hi = t; hi >= 0 && remaining > 0; hi -= 64) {
+                        const int u = hi - 63 + lane;                        // lane 63 = frame hi
+                        const bool on = u >= 0 && (!vc || vc[u] != 0);
+                        const unsigned long long m = __ballot(on);
+                        const int above = lane < 63 ? __popcll(m >> (lane + 1)) : 0;   // advancing frames after u in this window
+                        const bool take = on && above < remaining;
+                        if (take) {
+                            const int e = a * p.groups_per_array + u / REPAIR_GROUP;
+                            if (atomicExch(&p.need[e], 1) == 0) {
+                                p.list[atomicAdd(p.n_list, 1)] = e;
+                                atomicAdd(&p.stats[1], 1ull);
+                            }
                         }
+                        const unsigned long long mt = __ballot(take);
+                        if (mt) u_min = hi - 63 + (__ffsll((long long)mt) - 1);
+                        remaining -= __popcll(m);
                     }
                     if (lane == 0) {
-                        atomicMin(&p.chunk_first[(long long)a * p.n_chunks + blockIdx.x], t - t_start);
+                        // the second pick of this chunk restarts from the (coarse) start value of the chunk that holds the earliest of those rows
+                        atomicMin(&p.chunk_from[(long long)a * p.n_chunks + blockIdx.x], u_min / p.chunk);
                         atomicAdd(&p.stats[0], 1ull);
                     }
                 }
@@ -569,13 +601,13 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 // --------------------------------------------------------------------------------------
 // k_scan_repick / k_repair_patch -- adaptive SRP precision: the second pick of the flagged frames on the exact rows
 // --------------------------------------------------------------------------------------
-// k_scan_repick: grid (chunks, arrays); only the chunks that hold a flagged frame run (chunk_first < chunk).  After the
-// flagged frames' rows and the REPAIR_WARM rows before them were recomputed with the three-product split and patched into C,
-// the recursion restarts from a (coarse) chunk start value -- this chunk's if the first flagged frame lies at least
-// REPAIR_WARM + 1 frames into it, else the one before -- and walks the patched map, so that at a flagged frame at most
-// 0.8^(REPAIR_WARM+1) of the coarse error is left; the flagged frames are picked again (every other frame's coarse pick is
-// safe).  32 rows in flight per thread, the picks of a batch of 32 frames after it.  The last chunk of an array leaves
-// the exact state.
+// k_scan_repick: grid (chunks, arrays); only the chunks that hold a flagged frame run (chunk_from < n_chunks).  After the
+// flagged frames' rows and the REPAIR_WARM advancing rows before them were recomputed with the three-product split and patched
+// into C, the recursion restarts from the (coarse) start value of the chunk that holds the earliest of those rows -- this
+// chunk or the one before it without the gate, possibly further back across a silence with it -- and walks the patched map,
+// so that at a flagged frame at most 0.8^(REPAIR_WARM+1) of the coarse error is left; the flagged frames are picked again
+// (every other frame's coarse pick is safe).  32 rows in flight per thread, the picks of a batch of 32 frames after it.
+// The chunk with the array's last advancing frame leaves the exact state.
 constexpr int REPICK_B = 32;
 
 __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
@@ -585,38 +617,33 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
     const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
     const long long ci = (long long)a * p.n_chunks + blockIdx.x;
-    const int first_flag = p.chunk_first[ci];
-    if (first_flag >= p.chunk) return;
+    const int c_from = p.chunk_from[ci];
+    if (c_from > (int)blockIdx.x) return;
     const unsigned char *fl = p.flags + (long long)a * p.n_frames;
+    const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
     const int t_start = blockIdx.x * p.chunk;
     const int t_end = min(t_start + p.chunk, p.n_frames);
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     const float mn = -15.f * (float)p.P;
-    const int c_from = (blockIdx.x > 0 && first_flag < REPAIR_WARM + 1) ? blockIdx.x - 1 : blockIdx.x;
     float E = act ? p.e_start[((long long)a * p.n_chunks + c_from) * D + d] : 0.f;
-    // the flags of this chunk as one 64-bit mask (p.chunk <= 64): loaded once, not per frame inside the recursion
-    __shared__ unsigned long long s_mask;
-    if (wave == 0) {
-        const unsigned long long m = __ballot(t_start + lane < t_end && fl[t_start + lane] != 0);
-        if (lane == 0) s_mask = m;
-    }
-    __syncthreads();
-    const unsigned long long mask = s_mask;
     for (int tb = c_from * p.chunk; tb < t_end; tb += REPICK_B) {
         const int te = min(tb + REPICK_B, t_end);
-        // flagged frames of this batch (bit i = frame tb + i); none in the chunk before
-        const unsigned bm = tb >= t_start ? (unsigned)((mask >> (tb - t_start)) & 0xffffffffull) : 0u;
+        // per batch: which frames advance the recursion (all without the gate), which are picked again (flagged, this chunk only);
+        // every wave works the two masks out for itself from one byte per lane
+        const int u = tb + (lane & 31);
+        const unsigned vm = (unsigned)__ballot(lane < 32 && u < te && (!vc || vc[u] != 0));
+        const unsigned bm = tb >= t_start ? (unsigned)__ballot(lane < 32 && u < te && fl[u] != 0) : 0u;
         if (act) {
-            float c16[REPICK_B];
+            float c32[REPICK_B];
 #pragma unroll
-            for (int i = 0; i < REPICK_B; ++i) c16[i] = csum(C, (long long)min(tb + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+            for (int i = 0; i < REPICK_B; ++i) c32[i] = csum(C, (long long)min(tb + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
 #pragma unroll
             for (int i = 0; i < REPICK_B; ++i) {
                 const int t = tb + i;
                 if (t < te) {
-                    E = mu * E + omu * c16[i];                          // :134-140
+                    if ((vm >> i) & 1u) E = mu * E + omu * c32[i];      // :134-140
                     if (t >= t_start && p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
                     if ((bm >> i) & 1u) sEn[i * Dl + d] = (E - mn) / (-2.f * mn);   // :155-156
                 }
@@ -629,8 +656,8 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
             __syncthreads();
         }
     }
-    if (act && t_end == p.n_frames) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
-    if (d == 0) p.chunk_first[ci] = 0x7f7f7f7f;                              // consumed: no flagged frame
+    if (act && (int)blockIdx.x == p.last_vchunk[a]) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
+    if (d == 0) p.chunk_from[ci] = 0x7f7f7f7f;                              // consumed: no flagged frame
 }
 
 // k_repair_patch: a fixed grid walks the rows of this pass, 128 threads per row: the exact row (sum of the repair contraction's

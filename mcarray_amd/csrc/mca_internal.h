@@ -101,7 +101,8 @@ struct ScanPickArgs {
     int *need;               // [arrays * groups_per_array] test-and-set: the group is on the list (cleared by k_repair_patch)
     int *list;               // [arrays * groups_per_array] groups whose rows are recomputed, in order of arrival
     int *n_list;             // [1] their number (reset by k_scan_carry)
-    int *chunk_first;        // [arrays][n_chunks] position of the chunk's first flagged frame, >= chunk: none (reset by k_scan_repick)
+    int *chunk_from;         // [arrays][n_chunks] chunk the second pick of this chunk restarts from, >= n_chunks: no flagged frame (reset by k_scan_repick)
+    int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
     unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
 };
 

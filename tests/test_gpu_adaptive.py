@@ -109,3 +109,82 @@ def test_adaptive_equals_exact_paths_at_full_size(kind, M, S, step):
         assert unstable, (a_, t_, res["adaptive"][a_, t_].tolist(), res["x3"][a_, t_].tolist())
     if kind == "static":
         assert st["flagged"] < 0.05 * A * F                    # a clear source: few frames need the exact rows
+
+
+def _bursty(xs, A, F, seed, dev=None):
+    """[A][M][(F+1)*512] float32: a quiet lead-in (floor estimation: 141 frames at 48 kHz), then loud bursts and quiet gaps"""
+    rng = np.random.default_rng(seed)
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(rng.uniform(-70, 70)), 48000, (F + 1) * 512, seed + 10 + a, snr_db=15.0) for a in range(A)])
+    env = np.full(F + 1, 0.004)
+    t = 150
+    while t < F:
+        b = int(rng.integers(3, 60))
+        env[t:t + b] = 1.0
+        t += b + int(rng.integers(2, 50))
+    return (pcm * np.repeat(env, 512)[None, None, :]).astype(np.float32)
+
+
+def test_adaptive_with_power_gate_matches_oracle(force_small):
+    """usePowerFloor = true (the reference's default): the recursion only advances on voiced frames, so the rows a flagged
+    frame depends on are its last 25 VOICED ones -- possibly far back across a silence -- and gated-out frames repeat the
+    last FINAL pick.  Against the oracle, two calls."""
+    fs, N, F, A, S = 48000, 1024, 420, 3, 2
+    xs = synth.ULA8
+    pcm = _bursty(xs, A, F, 5)
+    ctx = api.Context(fs, xs, N, 0.5, S, use_power_floor=True, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+    ctx.reset_timing()
+    cut = 260
+    ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * 512], want_energy=True)
+    rb = ctx.process_frames_host(pcm[:, :, cut * 512:], want_energy=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out", "prob", "voiced")}
+    st = ctx.repair_stats()
+    assert st["frames"] == A * F and st["flagged"] >= A
+    fired = 0
+    for a in range(A):
+        o = po.ssl_stream_gated(fs, N, xs, pcm[a].astype(np.float64), S, 0.5, True)
+        assert np.array_equal(r["voiced"][a].astype(bool), o["fired"].astype(bool))
+        fired += int(o["fired"].sum())
+        ties = _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=3)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= 2e-4 * np.abs(o["energy"]).max()
+        if not ties:
+            assert np.abs(r["out"][a][:o["out"].shape[0]] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    assert 100 < fired < A * (F - 141)
+    ctx.close()
+
+
+def test_adaptive_with_power_gate_equals_fp16x3_at_full_size():
+    from oracle import np_twin as tw
+    dev = torch.device("cuda:0")
+    fs, N, F, A, S = 48000, 1024, 2304, 8, 1
+    xs = synth.ULA8
+    pcm = torch.from_numpy(_bursty(xs, A, F, 11)).to(dev)
+    res = {}
+    for name, prec in (("x3", api.SRP_FP16X3), ("adaptive", api.SRP_ADAPTIVE)):
+        ctx = api.Context(fs, xs, N, 0.5, S, use_power_floor=True, srp_precision=prec, max_arrays=A)
+        ctx.reset_timing()
+        b = torch.empty(A, F, S, dtype=torch.int32, device=dev)
+        r = torch.empty(A, F, S, dtype=torch.float32, device=dev)
+        p = torch.empty(A, F, S, dtype=torch.float32, device=dev)
+        e = torch.empty(A, F, ctx.D, dtype=torch.float32, device=dev)
+        h = 1100
+        for f0, f1 in ((0, h), (h, F)):
+            part = pcm[:, :, f0 * 512:(f1 + 1) * 512].contiguous()
+            bb, rr, pp, ee = (torch.empty_like(t[:, f0:f1]).contiguous() for t in (b, r, p, e))
+            ctx.process_frames_dev(part, f1 - f0, bb, rr, pp, ee, None)
+            torch.cuda.synchronize()
+            b[:, f0:f1], e[:, f0:f1] = bb, ee
+        if name == "adaptive":
+            st = ctx.repair_stats()
+        res[name] = (b.clone(), e.clone())
+        P = ctx.P
+        ctx.close()
+    assert st["frames"] == A * F and 0 < st["flagged"] < 0.2 * A * F
+    assert int((res["x3"][0] >= 0).sum()) > 2000                       # frames fired
+    diff = (res["adaptive"][0] != res["x3"][0]).any(dim=2).nonzero().tolist()
+    assert len(diff) <= 4, len(diff)
+    prng = np.random.default_rng(5)
+    for a_, t_ in diff:                                                # (a gated-out frame repeats a tie of the frame it copies)
+        E = res["x3"][1][a_, t_].double().cpu().numpy()
+        base = tw.select_doa(E, P, tw.doa_step(0.5), S)[2]
+        assert any(not np.array_equal(tw.select_doa(E + prng.standard_normal(E.shape) * 2e-6 * np.abs(E).max(), P, tw.doa_step(0.5), S)[2], base)
+                   for _ in range(32)), (a_, t_)

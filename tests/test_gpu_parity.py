@@ -783,3 +783,18 @@ def test_page_locked_host_buffers_equal_pageable_ones():
                     continue
                 assert np.array_equal(outs[0][k], outs[1][k]), (A, F, gate, prec, src.dtype, k)
             pin.close()
+
+
+def test_masking_context_rejects_a_changing_stream_count():
+    """the masking context tracks the module's first-frame behaviour once for all its streams (FastBinauralMasking.cpp:186-197):
+    a later call with another n_streams would silently give some slots the wrong path, so it is refused until a reset"""
+    fs, N, F = 16000, 1024, 12
+    rng = np.random.default_rng(3)
+    pcm = (rng.standard_normal((3, 2, (F + 1) * 512)) * 0.1).astype(np.float32)
+    m = api.FastBinauralMasking(fs, 0.086, 500.0, 5000.0, po.FULL, po.BOTH, max_streams=3)
+    m.process(pcm[:2])
+    with pytest.raises(api.MCArrayHipError, match="n_streams differs"):
+        m.process(pcm)
+    m.process(pcm[:2])
+    m.reset()
+    m.process(pcm)

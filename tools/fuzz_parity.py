@@ -10,30 +10,44 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcarray_amd import api, synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
-TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4}
+os.environ.setdefault("MCA_HIP_ADAPT_MIN_ROWS", "128")      # let the adaptive mode run on the small batches the oracle can follow
+TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: 2e-4}
 # a DOA-bin difference is a numerical tie if the ORACLE's normalised energies at the two bins are closer than this
-TIE = {api.SRP_FP32: 1e-5, api.SRP_FP16X3: 1e-5, api.SRP_FP16: 2e-4}
+# (ADAPTIVE: held to the bar of the exact modes -- its bins are those of FP16X3)
+TIE = {api.SRP_FP32: 1e-5, api.SRP_FP16X3: 1e-5, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: 1e-5}
 
 
-def main(cases, seed):
+def main(cases, seed, only_prec=None, adaptive_shapes=False):
     rng = np.random.default_rng(seed)
     bad = 0
+    n_adaptive = n_ties = 0
     for case in range(cases):
         M = int(rng.choice([2, 3, 4, 5, 8, 8, 8, 16]))
         ula = bool(rng.integers(0, 2))
         xs = (0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))
         fs, N = [(8000, 256), (16000, 512), (48000, 1024), (48000, 1024), (48000, 1024), (96000, 2048)][int(rng.integers(0, 6))]
         step = float(rng.choice([5.0, 3.0, 1.0, 0.5]))
-        S = int(rng.integers(1, 3))
+        S = int(rng.integers(1, 5))
         A = int(rng.integers(1, 4))
         F = int(rng.integers(1, 200))
-        prec = [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16][int(rng.integers(0, 3))]
+        prec = [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16, api.SRP_ADAPTIVE, api.SRP_ADAPTIVE][int(rng.integers(0, 5))]
+        if only_prec is not None:
+            prec = only_prec
         gate = bool(rng.integers(0, 4) == 0)
+        if only_prec == api.SRP_ADAPTIVE or adaptive_shapes:        # a sweep of the adaptive path itself: the shapes it applies to
+            M = int(rng.choice([3, 3, 4, 5, 8, 8, 16]))
+            xs = (0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))
+            fs, N, gate, F = 48000, 1024, False, int(rng.integers(64, 200))
         pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(rng.uniform(-80, 80)), fs, (F + 1) * N // 2, int(rng.integers(1, 1 << 30)))
                         for _ in range(A)]).astype(np.float32)
         tag = "case %d: M=%d %s fs=%d N=%d step=%.1f S=%d A=%d F=%d prec=%d gate=%d" % (case, M, "ula" if ula else "irr", fs, N, step, S, A, F, prec, gate)
+        if os.environ.get("MCA_FUZZ_ONLY") and case not in [int(x) for x in os.environ["MCA_FUZZ_ONLY"].split(",")]:
+            if F > 1:
+                rng.integers(0, 2) and rng.integers(0, F)          # (keep the random sequence of the cut in step: approximately)
+            continue
         try:
             ctx = api.Context(fs, xs, N, step, S, use_power_floor=gate, srp_precision=prec, max_arrays=A)
+            ctx.reset_timing()
             cut = int(rng.integers(0, F)) if F > 1 and rng.integers(0, 2) else 0
             hop = N // 2
             if cut:
@@ -56,16 +70,22 @@ def main(cases, seed):
                     ties += 1
                 if len(mism):
                     continue            # a flipped near-tie steers the beamformer elsewhere: the audio is not comparable
-                oe = np.abs(r["out"][a] - o["out"]).max()
+                nout = o["out"].shape[0]         # the oracle (like the reference) writes min(M, S) separated channels
+                oe = np.abs(r["out"][a][:nout] - o["out"]).max()
                 assert oe <= 2e-5 * np.abs(o["out"]).max() + 1e-7, "audio error %.2e" % oe
-            print("ok  ", tag, "ties", ties, "cut", cut)
+            st = ctx.repair_stats() if prec == api.SRP_ADAPTIVE else None
+            if st and st["frames"]:
+                n_adaptive += 1
+            n_ties += ties
+            print("ok  ", tag, "ties", ties, "cut", cut, "repair", st)
             ctx.close()
         except Exception as e:  # noqa: BLE001
             bad += 1
-            print("FAIL", tag, "--", e)
-    print("%d cases, %d failures" % (cases, bad))
+            print("FAIL", tag, "--", e, "| cut", locals().get("cut"), "repair", ctx.repair_stats() if prec == api.SRP_ADAPTIVE else None)
+    print("%d cases, %d failures, %d cases went through the adaptive path, %d oracle-level ties in total" % (cases, bad, n_adaptive, n_ties))
     return bad
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
+    only = {"fp32": api.SRP_FP32, "fp16x3": api.SRP_FP16X3, "fp16": api.SRP_FP16, "adaptive": api.SRP_ADAPTIVE}.get(sys.argv[3]) if len(sys.argv) > 3 else None
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1, only, len(sys.argv) > 4) else 0)
