@@ -433,7 +433,8 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
 //     chain of selectDOA) lies within +-tau of zero -- its sd could then be -En, 0 or +En[dd+1];
 //   * the frame is sensitive if an uncertain position could reach the S-th picked value (|En[dd+1]| >= v_S - tau; any
 //     uncertain position at all when fewer than S positive peaks exist), or if two of the S+1 largest candidates lie within
-//     tau of each other (their order, or which one is the last pick, is open).
+//     tau of each other (their order, or which one is the last pick, is open), or if the last pick is a zero entry (fewer
+//     than S positive candidates) while some candidate's energy lies within tau of zero (it could be on either side).
 // Every other frame's picks are the exact map's picks.
 template <bool SENS>
 __device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p, long long out_base, int lane)
@@ -441,6 +442,7 @@ __device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p
     const int D = p.D;
     float sdv[8];
     float umax = -INFINITY;                                     // SENS: largest |En[dd+1]| over the uncertain positions
+    float zmin = INFINITY;                                      // SENS: smallest |sd| over the positions with a non-zero second derivative
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int dd = lane + 64 * i;
@@ -462,6 +464,7 @@ __device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p
             if (SENS) {
                 const float dmin = fminf(fminf(fabsf(dm1), fabsf(d0)), fminf(fabsf(d1), fabsf(d2)));
                 if (dmin <= p.tau) umax = fmaxf(umax, fabsf(ed1));       // (a trough of negative energy is a candidate too: sd = -En > 0)
+                if (m1 != m0) zmin = fminf(zmin, fabsf(ed1));            // a candidate whose value could be on either side of zero
             }
         }
         sdv[i] = sd;
@@ -496,8 +499,11 @@ __device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p
     }
     if (SENS) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) umax = fmaxf(umax, __shfl_xor(umax, off));
+        for (int off = 32; off > 0; off >>= 1) { umax = fmaxf(umax, __shfl_xor(umax, off)); zmin = fminf(zmin, __shfl_xor(zmin, off)); }
         if (v_last > 0.f ? umax >= v_last - p.tau : umax > -INFINITY) sens = true;
+        // the last pick is (within tau of) one of the zero entries: a candidate whose normalised energy is within tau of zero
+        // could be a positive peak -- picked before every zero -- or a negative one
+        if (v_last <= p.tau && zmin <= p.tau) sens = true;
     }
     return sens;
 }
