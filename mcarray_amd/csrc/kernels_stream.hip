@@ -529,6 +529,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
     const float mn = -15.f * (float)p.P;
     float E = act ? p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d] : 0.f;
+    const bool last_chunk = p.mode == 1 && (int)blockIdx.x == p.last_vchunk[a];   // holds the array's last advancing frame
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
         if (act) {
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         for (int tl = wave; tl < te - ts; tl += nwaves) {
             const int t = ts + tl;
             bool flag = false;
-            if (p.mode == 1 && (int)blockIdx.x == p.last_vchunk[a]) {   // the array's last frame that advances the recursion
+            if (last_chunk) {                                           // the array's last frame that advances the recursion
                 bool later = false;
                 if (vc) for (int u = t + 1; u < t_end; ++u) later |= vc[u] != 0;
                 else later = t + 1 < t_end;
