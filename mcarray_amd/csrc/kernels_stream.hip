@@ -530,8 +530,11 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     const float mn = -15.f * (float)p.P;
     float E = act ? p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d] : 0.f;
     const bool last_chunk = p.mode == 1 && (int)blockIdx.x == p.last_vchunk[a];   // holds the array's last advancing frame
+    __shared__ unsigned s_flagmask;                                     // mode 1: the flags of a batch of SCAN_SUB (<= 32) frames
+    static_assert(SCAN_SUB <= 32, "one 32-bit mask per batch");
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
+        if (d == 0) s_flagmask = 0u;
         if (act) {
             for (int t0 = ts; t0 < te; t0 += 8) {
                 float c8[8];
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 wave_pick<false>(sEn + tl * Dl, p, ((long long)a * p.n_frames + t) * p.S, lane);
             }
             if (p.mode == 1) {
-                if (lane == 0) p.flags[(long long)a * p.n_frames + t] = flag ? 1 : 0;
+                if (lane == 0 && flag) atomicOr(&s_flagmask, 1u << tl);       // (one coalesced store of the batch's flags below)
                 if (flag) {
                     // the rows this frame's energy depends on: its own and those of the REPAIR_WARM frames before it that advanced
                     // the recursion (all of them without the gate, the voiced ones with it), 64 frames per step backwards
@@ -601,6 +604,8 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 }
             }
         }
+        __syncthreads();
+        if (p.mode == 1 && d < te - ts) p.flags[(long long)a * p.n_frames + ts + d] = (s_flagmask >> d) & 1u;
         __syncthreads();
     }
 }
