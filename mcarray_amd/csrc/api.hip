@@ -709,6 +709,11 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
         HIP_TRY(c, hipMemsetAsync(c->d_vdone[i], 0, na * 8, st));
     }
     HIP_TRY(c, hipMemsetAsync(c->d_silence, 0, na * 4, st));
+    // the self-cleaning words of the adaptive path (a call that failed half way may have left some set)
+    for (Workspace &w : c->lanes) {
+        if (w.d_need) HIP_TRY(c, hipMemsetAsync(w.d_need, 0, w.adapt_groups * 4, st));
+        if (w.d_chunk_from) HIP_TRY(c, hipMemsetAsync(w.d_chunk_from, 0x7f, w.adapt_chunks * 4, st));
+    }
     c->gcc2_frames_done = 0;
     return init_last_state(c, st);
 }
