@@ -27,12 +27,12 @@ struct TimedEvent { int id; hipEvent_t a, b; };
 
 struct mca_hip_graph;
 
-#define MCA_MAX_LANES 4
+#define MCA_MAX_LANES 1
 
-// Per-call workspace of one LANE.  A large call is split by arrays into up to MCA_MAX_LANES lanes that run on their own
-// HIP streams between a fork and a join on the caller's stream: arrays never interact, so the lanes are independent, and
-// the short latency-bound kernels of one lane (scan carry, repair plan / patch / second pick, launch gaps) run under the
-// long throughput-bound ones (STFT, contraction, beamformer) of another.  State is per array and lives in the context.
+// Per-call workspace (everything a stream call allocates besides the per-array state, which lives in the context).  A call
+// can be worked off in pieces over a sub-range of its arrays -- the chunks of the host-pointer path -- with the per-array
+// state addressed at c->a0.  (Round 2 also split large device-pointer calls over 2-4 internal streams, "lanes"; measured 7 %
+// slower with two and 57 % slower with three on the bench shape, DESIGN.md section 5, so that code is gone.)
 struct Workspace {
     void *d_A = nullptr; size_t a_bytes = 0;          // A operand: [rows][a_row_elems]
     void *d_Ax = nullptr; size_t ax_bytes = 0;        // ADAPTIVE: the two-plane A rows (repair pass, FP16X3 calls)
@@ -77,13 +77,10 @@ struct mca_hip_ctx {
     float *d_E[2] = {nullptr, nullptr};
     float *d_tail[2] = {nullptr, nullptr};
     int e_cur = 0, tail_cur = 0;
-    // lanes (see Workspace)
     Workspace lanes[MCA_MAX_LANES];
-    int cur_lane = 0, a0 = 0;              // the lane being enqueued and its first array (host side, sequential)
+    int cur_lane = 0, a0 = 0;              // the workspace in use and the first array of the piece being enqueued (host side, sequential)
     long long plan_rows = 0;               // > 0: rows of the whole call while it is worked off in pieces (plan_gemm)
-    int max_lanes = 1, n_lanes_last = 1;   // lanes are off by default: measured 7 % SLOWER with two on the bench shape; MCA_HIP_LANES=n enables them
-    long long lane_min_rows = 8192;
-    hipStream_t lane_stream[MCA_MAX_LANES] = {}; hipEvent_t lane_ev[MCA_MAX_LANES] = {}; hipEvent_t fork_ev = nullptr;
+    int n_lanes_last = 1;
     hipStream_t io_stream[3] = {}; hipEvent_t io_ev[8] = {};   // host-pointer entry points with page-locked buffers: copy in / run / copy out
     Workspace &ws() { return lanes[cur_lane]; }
     double *d_gate_state = nullptr;
@@ -164,11 +161,6 @@ void free_ctx(mca_hip_ctx *c)
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
     F(c->d_rstats); F(c->d_gate_state);
     for (Workspace &w : c->lanes) w.release();
-    for (int i = 0; i < MCA_MAX_LANES; ++i) {
-        if (c->lane_ev[i]) (void)hipEventDestroy(c->lane_ev[i]);
-        if (c->lane_stream[i]) (void)hipStreamDestroy(c->lane_stream[i]);
-    }
-    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     for (auto &e : c->io_ev) if (e) (void)hipEventDestroy(e);
     for (auto &q : c->io_stream) if (q) (void)hipStreamDestroy(q);
     F(c->d_last_bin); F(c->d_last_rad); F(c->d_last_prob);
@@ -278,7 +270,7 @@ struct GemmPlan { bool v2; int ksplit; };
 GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
 {
     GemmPlan g;
-    // a call that is worked off in pieces (chunks of the host-pointer path, lanes) plans every piece as the whole call would
+    // a call that is worked off in pieces (the chunks of the host-pointer path) plans every piece as the whole call would
     // be planned: a row's result then does not depend on how the call was cut (same kernel, same K segments, same order)
     if (c->plan_rows > 0) rows = c->plan_rows;
     g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= c->v2_min_rows && !c->force_v1;
@@ -315,7 +307,7 @@ int ensure_a(mca_hip_ctx *c, long long rows)
         buf = nullptr; bytes = 0;
         HIP_TRY(c, hipMalloc(&buf, need_a));
         HIP_TRY(c, hipMemset(buf, 0, need_a));          // the Kp padding columns stay zero forever
-        HIP_TRY(c, hipDeviceSynchronize());             // (the lanes' streams do not wait for the null stream's memset)
+        HIP_TRY(c, hipDeviceSynchronize());             // (the caller's stream need not wait for the null stream's memset by itself)
         bytes = need_a; ++c->ws_gen;
     }
     return MCA_HIP_OK;
@@ -571,8 +563,6 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     }
     c->n512 = c->N == 512 && c->M <= 8 && c->stream_ok && std::getenv("MCA_HIP_NO_N512") == nullptr;
     c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switches for measurements
-    if (std::getenv("MCA_HIP_LANES")) c->max_lanes = std::max(1, std::min(MCA_MAX_LANES, std::atoi(std::getenv("MCA_HIP_LANES"))));
-    if (std::getenv("MCA_HIP_LANE_MIN_ROWS")) c->lane_min_rows = std::max(1LL, std::atoll(std::getenv("MCA_HIP_LANE_MIN_ROWS")));
     if (std::getenv("MCA_HIP_V2_MIN_ROWS")) c->v2_min_rows = std::atoi(std::getenv("MCA_HIP_V2_MIN_ROWS"));
 
     // generateLookupTable (SteeringBeamforming.cpp:58-94): pairs i<j lexicographic, float delays
@@ -809,21 +799,11 @@ static int reserve_lane(mca_hip_ctx *c, int n_arrays, int n_frames)
     return ensure_scan_workspace(c, n_arrays, n_frames, n_chunks);
 }
 
-static int reserve_impl(mca_hip_ctx *c, int n_arrays, int n_frames, bool single_lane)
+static int reserve_impl(mca_hip_ctx *c, int n_arrays, int n_frames, bool)
 {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    int nl = 1;
-    if (!single_lane && c->max_lanes > 1 && n_arrays >= 2) {
-        long long n = (long long)n_arrays * n_frames / c->lane_min_rows;
-        nl = (int)std::max<long long>(1, std::min<long long>(n, std::min(c->max_lanes, n_arrays)));
-    }
-    int rc = MCA_HIP_OK;
-    for (int i = 0; i < nl && !rc; ++i) {
-        c->cur_lane = i;
-        rc = reserve_lane(c, n_arrays / nl + (i < n_arrays % nl ? 1 : 0), n_frames);
-    }
     c->cur_lane = 0;
-    return rc;
+    return reserve_lane(c, n_arrays, n_frames);
 }
 
 int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
@@ -1136,62 +1116,13 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
 extern "C++" {
 namespace {
 
-// is `st` being recorded into a graph?  (the null stream cannot be captured; asking about it is an error on some runtimes)
-bool stream_is_capturing(hipStream_t st)
-{
-    if (!st) return false;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
-    return cs != hipStreamCaptureStatusNone;
-}
-
-// how many lanes a call of this shape is split into
-int lanes_for(mca_hip_ctx *c, int n_arrays, int n_frames, hipStream_t st)
-{
-    if (c->max_lanes <= 1 || n_arrays < 2) return 1;
-    if (stream_is_capturing(st)) return 1;               // a recording stays on its stream
-    long long n = (long long)n_arrays * n_frames / c->lane_min_rows;
-    n = std::min<long long>(n, std::min(c->max_lanes, n_arrays));
-    return (int)std::max<long long>(n, 1);
-}
-
-int ensure_lane_streams(mca_hip_ctx *c, int n)
-{
-    if (!c->fork_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-    for (int i = 0; i < n; ++i) {
-        if (!c->lane_stream[i]) HIP_TRY(c, hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
-        if (!c->lane_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->lane_ev[i], hipEventDisableTiming));
-    }
-    return MCA_HIP_OK;
-}
-
-// Runs body(first array, arrays, stream) once per lane: on the caller's stream if there is one lane, else on the lanes' own
-// streams between a fork (they wait for everything queued on the caller's stream so far) and a join (the caller's stream
-// waits for all of them).  Contiguous blocks of arrays, the first n_arrays % lanes lanes take one more.
+// Runs body(first array, arrays, stream) for the whole call on the caller's stream.
 template <typename Body>
-int run_lanes(mca_hip_ctx *c, int n_arrays, int n_frames, hipStream_t st, Body body)
+int run_lanes(mca_hip_ctx *c, int n_arrays, int, hipStream_t st, Body body)
 {
-    const int nl = lanes_for(c, n_arrays, n_frames, st);
-    c->n_lanes_last = nl;
-    if (nl == 1) { c->cur_lane = 0; c->a0 = 0; return body(0, n_arrays, st); }
-    int rc = ensure_lane_streams(c, nl);
-    if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->fork_ev, st));
-    c->plan_rows = (long long)n_arrays * n_frames;
-    const int base = n_arrays / nl, rem = n_arrays % nl;
-    int a0 = 0, started = 0;
-    for (int i = 0; i < nl && !rc; ++i) {
-        const int na = base + (i < rem ? 1 : 0);
-        HIP_TRY(c, hipStreamWaitEvent(c->lane_stream[i], c->fork_ev, 0));
-        c->cur_lane = i; c->a0 = a0;
-        rc = body(a0, na, c->lane_stream[i]);
-        (void)hipEventRecord(c->lane_ev[i], c->lane_stream[i]);
-        ++started;
-        a0 += na;
-    }
-    for (int i = 0; i < started; ++i) (void)hipStreamWaitEvent(st, c->lane_ev[i], 0);
-    c->cur_lane = 0; c->a0 = 0; c->plan_rows = 0;
-    return rc;
+    c->n_lanes_last = 1;
+    c->cur_lane = 0; c->a0 = 0;
+    return body(0, n_arrays, st);
 }
 
 }  // namespace
@@ -1241,7 +1172,6 @@ int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
     if (!out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
     const size_t fs_ = (size_t)n_frames * c->S, fd_ = (size_t)n_frames * c->D, fo_ = (size_t)c->S * n_frames * c->H;
-    // both stages of a lane back to back: lane 0 beamforms while lane 1 still localises
     rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
         int r = localise_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_bin + a0 * fs_, doa_rad + a0 * fs_,
                               prob ? prob + a0 * fs_ : nullptr, energy ? energy + a0 * fd_ : nullptr, st);

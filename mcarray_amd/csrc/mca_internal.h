@@ -109,8 +109,8 @@ struct ScanPickArgs {
 constexpr int REPAIR_KSPLIT = 32;
 // The repair contraction runs on however many rows the coarse pass listed (a device-side count, usually a few hundred): the
 // K range is what parallelises.  It is always cut into the same REPAIR_KSPLIT segments, whatever the row count, so that an
-// exact row's value does not depend on how many other rows were listed with it (a call worked off in chunks or lanes
-// returns the same bits).  Partial maps: [REPAIR_KSPLIT][repair_plane_stride], summed in order by k_repair_patch.
+// exact row's value does not depend on how many other rows were listed with it (a call worked off in chunks returns the
+// same bits).  Partial maps: [REPAIR_KSPLIT][repair_plane_stride], summed in order by k_repair_patch.
 __host__ __device__ inline int repair_ksplit(int, int) { return REPAIR_KSPLIT; }
 __host__ __device__ inline long long repair_plane_stride(int n_rows, int Dp) { return (long long)((n_rows + 127) / 128 * 128) * Dp; }
 __host__ __device__ inline long long repair_cx_rows(long long pass_rows) { return ((pass_rows + 127) / 128 * 128) * REPAIR_KSPLIT; }
