@@ -469,7 +469,7 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
     // 2 microphones: four frames per pass so that all eight waves transform (k_stft_phat_few)
 #define LAUNCH_FEW(MT, U)                                                                                    \
     do {                                                                                                     \
-        const size_t smf = ((size_t)8 * FFT_SCRATCH + TW_WORDS + (size_t)a.fpb * MT) * sizeof(float2) + (size_t)a.fpb * sizeof(float); \
+        const size_t smf = ((size_t)8 * FFT_SCRATCH + TW_WORDS + (size_t)a.fpb * MT) * sizeof(float2) + (size_t)a.fpb * 8 * sizeof(float); \
         if (smf > 64 * 1024)                                                                                 \
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_few<MT, U, OutT>),    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smf));           \
@@ -837,7 +837,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             // 512-sample frames: two frames of up to 8 channels per pass on the wave-level transform
             sa.fpb = 8;
             while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
-            const size_t smem5 = ((size_t)2 * 8 * 258 + 8 * FFT_SCRATCH + TW_WIN + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
+            const size_t smem5 = ((size_t)2 * 8 * 258 + 8 * FFT_SCRATCH + TW_WIN + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
             dim3 g5((nf + sa.fpb - 1) / sa.fpb, n_arrays);
 #define L512(MT, U, T)                                                                                                    \
             do {                                                                                                          \
@@ -858,7 +858,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             // two microphones at 2048- / 4096-sample frames (FreqGCC at 32 / 44.1 / 48 kHz): 512-sample sub-sequences per channel
             sa.fpb = 8;
             while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
-            const size_t smem4 = ((size_t)16 * 258 + 8 * FFT_SCRATCH + TW_WIN) * sizeof(float2) + 16;
+            const size_t smem4 = ((size_t)16 * 258 + 8 * FFT_SCRATCH + TW_WIN) * sizeof(float2) + 4 * 8 * sizeof(float);
             dim3 g4((nf + sa.fpb - 1) / sa.fpb, n_arrays);
 #define LSUB(RR, T)                                                                                                       \
             do {                                                                                                          \
@@ -883,7 +883,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             rc = MCA_HIP_OK;
         } else {
             dim3 g1((nf + sa.fpb - 1) / sa.fpb, n_arrays);
-            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
+            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
             rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft<float>(c, sa, g1, smem1, st) : launch_stft<_Float16>(c, sa, g1, smem1, st);
         }
         time_end(c, st);
@@ -1001,7 +1001,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             sa.window = c->d_window; sa.A = c->ws().d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
             sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
             sa.list = c->ws().d_list; sa.n_list = c->ws().d_nlist; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = gpa;
-            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * sizeof(float);
+            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
             // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
             if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, 512), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
             GemmArgs ga{};

@@ -75,6 +75,9 @@ __device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, 
     }
 }
 
+// the per-wave partial sums of a frame's power, in wave order
+__device__ __forceinline__ float sum8(const float *s) { return ((((((s[0] + s[1]) + s[2]) + s[3]) + s[4]) + s[5]) + s[6]) + s[7]; }
+
 template <int MT, bool ULA, typename OutT>
 __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
 {
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
     const int M = MT > 0 ? MT : p.M;
     float2 *tab = smem + M * FFT_SCRATCH;                                 // [TW_WORDS] twiddles + window
     float2 *nyq = tab + TW_WORDS;                                         // [fpb][M] whitened Nyquist bins
-    float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);             // [fpb] sum_c sum_k w_k |X_c[k]|^2 (power gate)
+    float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);             // [fpb][8] per wave: sum_c sum_k w_k |X_c[k]|^2 (power gate)
     constexpr int CPW = (MT > 0 && MT <= 8) ? 1 : 2;   // channels per FFT wave
     fft_table_init(tab, p.window, tid, 512);
     FftTw tw{tab};
@@ -103,7 +106,6 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
         row_base = (long long)(li - p.list0) * REPAIR_GROUP - f_begin;
     }
     const int f_end = min(f_begin + p.fpb, p.n_frames);
-    if (tid < p.fpb) spow[tid] = 0.f;
     __syncthreads();
 
     // raw[cc][0..3]: first half of the current frame; nxt[cc][0..3]: its second half, loaded one
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
             if (tid < M) { const float2 z = smem[tid * FFT_SCRATCH + FFT_H]; acc += z.x * z.x + z.y * z.y; }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-            if (lane == 0) atomicAdd(&spow[f - f_begin], acc);
-        }
+            if (lane == 0) spow[(f - f_begin) * 8 + wave] = acc;        // (one slot per wave, summed in a fixed order below: the
+        }                                                               //  gate's decisions do not depend on the order of atomics)
         {
             const int k = tid;   // bins 0..511
             if constexpr (MT == 0)   // runtime M: whiten the thread's own column in place, pairs re-read it from LDS
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
         __syncthreads();
     }
     if (p.power && tid < f_end - f_begin)
-        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = spow[tid] / ((float)FFT_N * (float)FFT_N) / (float)M;
+        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = sum8(spow + tid * 8) / ((float)FFT_N * (float)FFT_N) / (float)M;
     // Nyquist bins of the block's frames: lane = frame
     if (tid < f_end - f_begin) {
         OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f_begin + tid) * (long long)p.a_row_elems;
@@ -201,14 +203,13 @@ __global__ __launch_bounds__(512) void k_stft_phat_few(StftPhatArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 *tab = smem + 8 * FFT_SCRATCH;                                 // [TW_WORDS]
     float2 *nyq = tab + TW_WORDS;                                         // [fpb][MT] whitened Nyquist bins
-    float *spow = reinterpret_cast<float *>(nyq + p.fpb * MT);            // [fpb]
+    float *spow = reinterpret_cast<float *>(nyq + p.fpb * MT);            // [fpb][8] per wave
     const int a = blockIdx.y;
     const int f_begin = blockIdx.x * p.fpb;
     const int f_end = min(f_begin + p.fpb, p.n_frames);
     const int slot = wave / MT, c = wave % MT;
 
     fft_table_init(tab, p.window, tid, 512);
-    if (tid < p.fpb) spow[tid] = 0.f;
     __syncthreads();
     FftTw tw{tab};
 
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_few(StftPhatArgs p)
                     if (tid < MT) { const float2 z = x[tid * FFT_SCRATCH + FFT_H]; acc += z.x * z.x + z.y * z.y; }
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-                    if (lane == 0) atomicAdd(&spow[fr - f_begin], acc);
+                    if (lane == 0) spow[(fr - f_begin) * 8 + wave] = acc;
                 }
                 pair_stage<MT, ULA, true, OutT>(x + tid, FFT_SCRATCH, MT, arow, p, tid);
             }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_few(StftPhatArgs p)
         __syncthreads();
     }
     if (p.power && tid < f_end - f_begin)
-        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = spow[tid] / ((float)FFT_N * (float)FFT_N) / (float)MT;
+        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = sum8(spow + tid * 8) / ((float)FFT_N * (float)FFT_N) / (float)MT;
     if (tid < f_end - f_begin) {
         OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
         pair_stage<MT, ULA, false, OutT>(nyq + tid * MT, 1, MT, arow, p, FFT_H);
@@ -967,12 +968,12 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
     float2 *tab = scr + 8 * FFT_SCRATCH;                                    // [TW_WIN]
     float2 *nyq = tab + TW_WIN;                                             // [fpb][M]
     const int M = MT > 0 ? MT : p.M;
-    float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);               // [fpb]
+    float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);               // [fpb][8] per wave (4 waves per frame: the other 4 slots stay zero)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = blockIdx.y;
     const int f_begin = blockIdx.x * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
     fft_table_init(tab, nullptr, tid, 512);
-    if (tid < p.fpb) spow[tid] = 0.f;
+    for (int e = tid; e < p.fpb * 8; e += 512) spow[e] = 0.f;
     float wreg[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) wreg[r] = 0.5f * p.window[lane + 64 * r];
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
                 if (k < M) { const float2 z = xs[k * N512_ROW + N512_H]; acc += z.x * z.x + z.y * z.y; }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-                if (lane == 0) atomicAdd(&spow[f + fi - f_begin], acc);
+                if (lane == 0) spow[(f + fi - f_begin) * 8 + (wave & 3)] = acc;
             }
             if constexpr (MT == 0)
                 for (int m = 0; m < M; ++m) xs[m * N512_ROW + k] = whiten(xs[m * N512_ROW + k]);
@@ -1011,7 +1012,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
         __syncthreads();
     }
     if (p.power && tid < f_end - f_begin)
-        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = spow[tid] / (512.f * 512.f) / (float)M;
+        p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = sum8(spow + tid * 8) / (512.f * 512.f) / (float)M;
     if (tid < f_end - f_begin) {
         OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
         pair_stage<MT, ULA, false, OutT>(nyq + tid * M, 1, M, arow, p, N512_H, N512_K);
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_sub2(StftPhatArgs p)
     float2 *scr = sub + 16 * N512_ROW;                                      // [8][FFT_SCRATCH]
     float2 *X = scr;                                                        // [FPP][2][XR] (after the transforms)
     float2 *tab = scr + 8 * FFT_SCRATCH;                                    // [TW_WIN]
-    float *spow = reinterpret_cast<float *>(tab + TW_WIN);                  // [FPP]
+    float *spow = reinterpret_cast<float *>(tab + TW_WIN);                  // [FPP][8] per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = blockIdx.y;
     const int f_begin = blockIdx.x * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
@@ -1067,7 +1068,6 @@ __global__ __launch_bounds__(512) void k_stft_phat_sub2(StftPhatArgs p)
             float2 *S = sub + ((slot * 2 + cw) * R + 2 * pr) * N512_ROW;
             rfft512_pair(v, scr + wave * FFT_SCRATCH, S, S + N512_ROW, lane, tw);
         }
-        if (tid < FPP) spow[tid] = 0.f;
         __syncthreads();
         for (int e = tid; e < nfr * 2 * 512; e += 512) {                    // thread = (frame, channel, m): one radix-R butterfly
             const int jc = e >> 9, m = e & 511;
@@ -1091,12 +1091,12 @@ __global__ __launch_bounds__(512) void k_stft_phat_sub2(StftPhatArgs p)
             if (p.power) {
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-                if (lane == 0) atomicAdd(&spow[j], acc);
+                if (lane == 0) spow[j * 8 + wave] = acc;
             }
         }
         if (p.power) {
             __syncthreads();
-            if (tid < nfr) p.power[(long long)a * p.total_frames + p.frame0 + f + tid] = spow[tid] / ((float)N * (float)N) / 2.f;
+            if (tid < nfr) p.power[(long long)a * p.total_frames + p.frame0 + f + tid] = sum8(spow + tid * 8) / ((float)N * (float)N) / 2.f;
         }
         __syncthreads();
     }
