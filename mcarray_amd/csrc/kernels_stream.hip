@@ -364,16 +364,16 @@ __global__ __launch_bounds__(512) void k_scan_partial(ScanPickArgs p)
     float b = 0.f;
     int nv = 0;
     if (d < p.D) {
-        for (int t0 = t_start; t0 < t_end; t0 += 8) {
-            float c8[8];
+        for (int t0 = t_start; t0 < t_end; t0 += SCAN_LD) {              // SCAN_LD rows (x planes) in flight per thread
+            float c8[SCAN_LD];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < SCAN_LD; ++i) {
                 const int t = min(t0 + i, t_end - 1);
                 const long long o = (long long)t * p.Dp + d;
                 c8[i] = csum(C, o, p.c_planes, p.c_plane_stride);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < SCAN_LD; ++i)
                 if (t0 + i < t_end && (!vc || vc[t0 + i])) { b = p.mu * b + p.one_minus_mu * c8[i]; ++nv; }
         }
         p.part[((long long)a * p.n_chunks + c) * p.D + d] = b;
@@ -537,16 +537,16 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         const int te = min(ts + SCAN_SUB, t_end);
         if (d == 0) s_flagmask = 0u;
         if (act) {
-            for (int t0 = ts; t0 < te; t0 += 8) {
-                float c8[8];
+            for (int t0 = ts; t0 < te; t0 += SCAN_LD) {
+                float c8[SCAN_LD];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < SCAN_LD; ++i) {
                     const int t = min(t0 + i, te - 1);
                     const long long o = (long long)t * p.Dp + d;
                     c8[i] = csum(C, o, p.c_planes, p.c_plane_stride);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < SCAN_LD; ++i) {
                     const int t = t0 + i;
                     if (t < te) {
                         if (!vc || vc[t]) E = mu * E + omu * c8[i];                 // :134-140

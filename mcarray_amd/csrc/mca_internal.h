@@ -21,6 +21,10 @@ constexpr int KG = 513;            // complex K-slots per delay group in the A /
 #endif
 constexpr int SCAN_CHUNK = MCA_SCAN_CHUNK;    // frames per chunk of the exact chunked scan (32: 0.928 ms per bench step, 64: 0.965; must exceed REPAIR_WARM)
 constexpr int SCAN_SUB = MCA_SCAN_SUB;      // frames per LDS sub-batch of k_scan_pick
+#ifndef MCA_SCAN_LD
+#define MCA_SCAN_LD 8
+#endif
+constexpr int SCAN_LD = MCA_SCAN_LD;        // map rows (x split-K planes) a thread of the scan kernels keeps in flight (16 / 32 measured slower: 0.939 / 0.955 vs 0.939 ms per step)
 constexpr int REPAIR_WARM = 24;   // exact rows recomputed BEFORE a flagged frame (adaptive SRP precision): 0.8^25 = 3.8e-3 of the coarse error
                                   // remains, i.e. ~6e-8 of the map's peak -- 30 x below the error of the three-product split itself
 constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mode pass of a k_stft_phat workgroup
