@@ -6,6 +6,7 @@
 //   testBeamformingSeparation        <- test/test_mcarray.cpp:631-800 (dead in the reference; property >= 5.5 dB)
 //   testBeamformingSoundLocalisation <- test/test_mcarray.cpp:384-423 (+-7 degrees; broadband source)
 //   testHookMatchesStream            the DSPONE hook (frame API, double) against the batched stream path
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -372,6 +373,69 @@ static void testSignalVectorOverloads()
     std::printf("SignalVector16s overload: %d samples, DOA bins equal, |int16 out - double out| <= %.2f\n", wa, worst);
 }
 
+static void testAdaptivePrecisionAndPageLockedBuffers()
+{
+    // the C ABI from plain C++: MCA_HIP_SRP_ADAPTIVE (fp16 scan of every frame + exact repair of the tie-sensitive ones) must
+    // report the DOA bins of MCA_HIP_SRP_FP16X3 on a batch large enough for the adaptive path (4 arrays x 2100 frames), fed
+    // through page-locked buffers (mca_hip_host_alloc: chunked, overlapped copies) on one side and pageable ones on the other
+    const int fs = 48000, N = 1024, hop = 512, A = 4, M = 8, F = 2100, S = 1;
+    const long long L = static_cast<long long>(F + 1) * hop;
+    std::vector<double> xyz(3 * M, 0.0);
+    for (int m = 0; m < M; ++m) xyz[3 * m] = 0.04 * m;
+    // white source per array, integer-sample delays (the point is the path, not the acoustics) + sensor noise
+    std::vector<float> pcm(static_cast<size_t>(A) * M * L);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) * (1.0f / 16777216.0f)) - 0.5f; };
+    for (int a = 0; a < A; ++a) {
+        std::vector<float> src(L + 64);
+        for (float &v : src) v = 0.2f * rnd();
+        const int lag = a - 2;                          // samples per microphone step: a different direction per array
+        for (int m = 0; m < M; ++m)
+            for (long long t = 0; t < L; ++t)
+                pcm[(static_cast<size_t>(a) * M + m) * L + t] = src[static_cast<size_t>(t + 32 + lag * m)] + 0.02f * rnd();
+    }
+    const size_t nfs = static_cast<size_t>(A) * F * S;
+    std::vector<int> bin_x(nfs);
+    std::vector<float> rad_x(nfs), prob_x(nfs);
+    mca_hip_config cfg;
+    cfg.struct_size = static_cast<int>(sizeof(cfg)); cfg.device = 0; cfg.sample_rate = fs; cfg.fft_size = N; cfg.n_mics = M;
+    cfg.mic_xyz = xyz.data(); cfg.doa_step_deg = 0.5; cfg.n_sources = S; cfg.use_power_floor = 0; cfg.max_arrays = A;
+    mca_hip_ctx *cx = nullptr, *ca = nullptr;
+    cfg.srp_precision = MCA_HIP_SRP_FP16X3;
+    EXPECT(mca_hip_create(&cfg, &cx) == MCA_HIP_OK);
+    cfg.srp_precision = MCA_HIP_SRP_ADAPTIVE;
+    EXPECT(mca_hip_create(&cfg, &ca) == MCA_HIP_OK);
+    if (!cx || !ca) return;
+    EXPECT(mca_hip_process_frames_host(cx, pcm.data(), A, F, bin_x.data(), rad_x.data(), prob_x.data(), nullptr, nullptr) == MCA_HIP_OK);
+    float *pin = static_cast<float *>(mca_hip_host_alloc(static_cast<long long>(pcm.size() * sizeof(float))));
+    int *bin_a = static_cast<int *>(mca_hip_host_alloc(static_cast<long long>(nfs * sizeof(int))));
+    float *rad_a = static_cast<float *>(mca_hip_host_alloc(static_cast<long long>(nfs * sizeof(float))));
+    EXPECT(pin && bin_a && rad_a);
+    if (pin && bin_a && rad_a) {
+        std::copy(pcm.begin(), pcm.end(), pin);
+        EXPECT(mca_hip_reset_timing(ca) == MCA_HIP_OK);
+        EXPECT(mca_hip_process_frames_host(ca, pin, A, F, bin_a, rad_a, nullptr, nullptr, nullptr) == MCA_HIP_OK);
+        unsigned long long frames = 0, flagged = 0, recomputed = 0;
+        EXPECT(mca_hip_get_repair_stats(ca, &frames, &flagged, &recomputed) == MCA_HIP_OK);
+        EXPECT(frames == static_cast<unsigned long long>(A) * F && flagged >= static_cast<unsigned long long>(A) && recomputed >= flagged);
+        size_t diff = 0;
+        for (size_t i = 0; i < nfs; ++i) diff += bin_a[i] != bin_x[i];
+        EXPECT(diff <= 3);                              // (exact-level ties between the two three-product kernels)
+        std::printf("adaptive vs fp16x3: %zu of %zu bins differ; %llu frames flagged, %llu rows recomputed\n", diff, nfs, flagged, recomputed);
+        // registering a caller's buffer in place gives the same path
+        EXPECT(mca_hip_host_register(pcm.data(), static_cast<long long>(pcm.size() * sizeof(float))) == MCA_HIP_OK);
+        std::vector<int> bin_r(nfs);
+        EXPECT(mca_hip_reset(ca, nullptr) == MCA_HIP_OK);
+        EXPECT(mca_hip_process_frames_host(ca, pcm.data(), A, F, bin_r.data(), nullptr, nullptr, nullptr, nullptr) == MCA_HIP_OK);
+        EXPECT(mca_hip_host_unregister(pcm.data()) == MCA_HIP_OK);
+        size_t diff2 = 0;
+        for (size_t i = 0; i < nfs; ++i) diff2 += bin_r[i] != bin_a[i];
+        EXPECT(diff2 == 0);
+    }
+    mca_hip_host_free(pin); mca_hip_host_free(bin_a); mca_hip_host_free(rad_a);
+    mca_hip_destroy(cx); mca_hip_destroy(ca);
+}
+
 int main(int argc, char **argv)
 {
     const bool cpu_only = argc > 1 && std::string(argv[1]) == "--cpu";
@@ -388,6 +452,7 @@ int main(int argc, char **argv)
             testMultibandBinauralLocalisation();
             testMvdrBeamformer();
             testSignalVectorOverloads();
+            testAdaptivePrecisionAndPageLockedBuffers();
         } catch (const MCArrayException &e) {
             std::printf("FAIL: MCArrayException: %s\n", e.what());
             ++g_fail;
