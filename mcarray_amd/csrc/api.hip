@@ -455,6 +455,21 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
     return MCA_HIP_OK;
 }
 
+// The correctly rounded float reciprocal of d (a small positive integer): the candidate nearest 1/d in exact arithmetic
+// (r d is exact in a double: 24 + <= 24 bits).  The scan kernels divide by d with it (normalised_energy).
+static float exact_reciprocal(float d)
+{
+    const float r0 = (float)(1.0 / (double)d);
+    float best = r0;
+    double err = std::fabs(1.0 - (double)r0 * (double)d);
+    const float cand[2] = {std::nextafterf(r0, 0.f), std::nextafterf(r0, 1.f)};
+    for (float r : cand) {
+        const double e = std::fabs(1.0 - (double)r * (double)d);
+        if (e < err) { err = e; best = r; }
+    }
+    return best;
+}
+
 template <typename OutT>
 int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, hipStream_t st)
 {
@@ -962,6 +977,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     pa.C = c->ws().d_C; pa.c_planes = c->ws().c_planes; pa.c_plane_stride = c->ws().c_plane; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
     pa.chunk = SCAN_CHUNK; pa.n_chunks = n_chunks;
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
+    pa.inv_norm = exact_reciprocal(30.f * (float)c->P);
     pa.state_in = c->d_E[c->e_cur] + a0 * c->D; pa.state_out = c->d_E[c->e_cur ^ 1] + a0 * c->D;
     pa.part = c->ws().d_part; pa.nvoiced = c->ws().d_nv; pa.e_start = c->ws().d_estart; pa.voiced = gate ? c->ws().d_voiced : nullptr;
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
@@ -975,9 +991,16 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     hipLaunchKernelGGL(k_scan_partial, g3, dim3(nthr), 0, st, pa);
     hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays), dim3(nthr), 0, st, pa);
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
-    if (smem3 > 64 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
-    hipLaunchKernelGGL(k_scan_pick, g3, dim3(std::max(nthr, 512)), smem3, st, pa);   // 8 waves: the per-frame pick is one wave per frame
+    const int ppl = c->D - 2 <= 128 ? 2 : c->D - 2 <= 384 ? 6 : 8;            // positions per lane of the peak pick
+#define LAUNCH_PICK(PL, MODE)                                                                                                       \
+    do {                                                                                                                            \
+        if (smem3 > 64 * 1024)                                                                                                      \
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pick<PL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3)); \
+        hipLaunchKernelGGL((k_scan_pick<PL, MODE>), g3, dim3(std::max(nthr, 512)), smem3, st, pa);   /* 8 waves: the per-frame pick is one wave per frame */ \
+    } while (0)
+    if (adaptive) { if (ppl == 2) LAUNCH_PICK(2, 1); else if (ppl == 6) LAUNCH_PICK(6, 1); else LAUNCH_PICK(8, 1); }
+    else { if (ppl == 2) LAUNCH_PICK(2, 0); else if (ppl == 6) LAUNCH_PICK(6, 0); else LAUNCH_PICK(8, 0); }
+#undef LAUNCH_PICK
     DoaFillArgs fa{};
     fa.voiced = c->ws().d_voiced; fa.n_frames = n_frames; fa.S = c->S;
     fa.doa_bin = doa_bin; fa.doa_rad = doa_rad; fa.prob = prob;
@@ -1021,7 +1044,10 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);
         }
         set_call_planes(c, 1);
-        hipLaunchKernelGGL(k_scan_repick, g3, dim3(std::max(nthr, 512)), (size_t)32 * (c->Dp + 8) * sizeof(float), st, pa);
+        const size_t smem4 = (size_t)32 * (c->Dp + 8) * sizeof(float);
+        if (ppl == 2) hipLaunchKernelGGL((k_scan_repick<2>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);
+        else if (ppl == 6) hipLaunchKernelGGL((k_scan_repick<6>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);
+        else hipLaunchKernelGGL((k_scan_repick<8>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);
         if (gate) hipLaunchKernelGGL(k_doa_fill, dim3(n_arrays), dim3(1024), 0, st, fa);   // gated-out frames repeat the last FINAL pick
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());

@@ -9,8 +9,8 @@ template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat_few(StftP
 __global__ void k_sum_planes(float *C, long long n4, int planes, long long stride);
 __global__ void k_scan_partial(ScanPickArgs p);
 __global__ void k_scan_carry(ScanPickArgs p);
-__global__ void k_scan_pick(ScanPickArgs p);
-__global__ void k_scan_repick(ScanPickArgs p);
+template <int PL, int MODE> __global__ void k_scan_pick(ScanPickArgs p);   // PL: positions per lane of the peak pick (2 / 6 / 8, by D)
+template <int PL> __global__ void k_scan_repick(ScanPickArgs p);
 __global__ void k_repair_patch(RepairPatchArgs p);
 __global__ void k_gate(GateArgs p);
 __global__ void k_doa_fill(DoaFillArgs p);

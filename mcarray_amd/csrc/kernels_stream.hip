@@ -423,8 +423,8 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
 }
 
 // selectDOA of one frame by one wave (SteeringBeamforming.cpp:146-195): En = the frame's normalised energies (LDS), lane
-// evaluates the sign / median-3 / second-derivative chain at the positions lane + 64 i, the S maxima are found by wave
-// shuffles with first-index tie-break and written by lane 0.  SENS (coarse pass of the adaptive SRP precision): also
+// evaluates the sign / median-3 / second-derivative chain at PL consecutive positions, the S maxima are found by a DPP
+// reduction of the lanes' maxima and a ballot (first index on ties) and written by lane 0.  SENS (coarse pass of the adaptive SRP precision): also
 // decides whether the picks could come out differently on the exact map; returns that decision (uniform over the wave).
 //
 // Adaptive SRP precision: the correlation map comes from ONE fp16 MFMA product per k-step (error sigma ~3e-6 of the largest
@@ -437,113 +437,149 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
 //     tau of each other (their order, or which one is the last pick, is open), or if the last pick is a zero entry (fewer
 //     than S positive candidates) while some candidate's energy lies within tau of zero (it could be on either side).
 // Every other frame's picks are the exact map's picks.
-template <bool SENS>
-__device__ __forceinline__ bool wave_pick(const float *En, const ScanPickArgs &p, long long out_base, int lane)
+// Maximum over the 64 lanes on v_max_f32 with a DPP source operand (quad swaps, row rotations, the two cross-row broadcasts
+// of gfx9); taken from lane 63, uniform.  (A DPP read needs two wait states after the vector write of its source.)
+__device__ __forceinline__ float wave_max64(float v)
 {
-    const int D = p.D;
-    float sdv[8];
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min64(float v) { return -wave_max64(-v); }
+
+// (E - mn) / d, d = -2 mn = 30 P (:155-156), as the correctly rounded quotient from the correctly rounded reciprocal r of d:
+// q0 = RN(x r), e = x - q0 d (exact in an fma), q = RN(q0 + e r) -- the IEEE quotient for every x in range (Markstein), in
+// three instructions instead of the ten of the scaled division sequence.
+__device__ __forceinline__ float normalised_energy(float E, float mn, float d, float r)
+{
+    const float x = E - mn;
+    const float q0 = x * r;
+    const float e = fmaf(-q0, d, x);
+    return fmaf(e, r, q0);
+}
+
+// selectDOA of one frame by one wave; the S (SENS: S + 1) picks go to obin / oval (LDS) from lane 0.
+template <bool SENS, int PL>
+__device__ __forceinline__ bool wave_pick_pl(const float *En, int D, int S, float tau, int *obin, float *oval, int lane)
+{
+    // lane owns the PL consecutive positions dd = PL lane + i: every first difference, sign and median is formed once.
+    // Everything that depends on the lane only (load offsets with the edges replicated as median_filter does: j = -1 reads
+    // j = 0, j > D - 2 reads j = D - 2; the penalty that removes the positions past D - 3) is a per-lane VALUE, not a lane mask.
+    const int b = PL * lane;
+    float df[PL + 3];                                           // En[j + 1] - En[j], j = clamp(b - 1 + c, 0, D - 2)
+#pragma unroll
+    for (int c = 0; c < PL + 3; ++c) {
+        const int j = min(max(b - 1 + c, 0), max(D - 2, 0));
+        df[c] = En[min(j + 1, D - 1)] - En[j];
+    }
+    float fd[PL + 3], md[PL + 1];
+#pragma unroll
+    for (int c = 0; c < PL + 3; ++c) fd[c] = df[c] < 0.f ? 1.f : 0.f;       // fd(j) = 1 if En[j+1] - En[j] < 0 else 0
+#pragma unroll
+    for (int i = 0; i < PL + 1; ++i) md[i] = __builtin_amdgcn_fmed3f(fd[i], fd[i + 1], fd[i + 2]);       // median filter  :164
+    float sdv[PL];
     float umax = -INFINITY;                                     // SENS: largest |En[dd+1]| over the uncertain positions
     float zmin = INFINITY;                                      // SENS: smallest |sd| over the positions with a non-zero second derivative
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int dd = lane + 64 * i;
-        float sd = -INFINITY;
-        if (dd < D - 2) {
-            // fd(j) = 1 if En[j+1] - En[j] < 0 else 0, j in [0, D-2]; edges replicate (median_filter)
-            const int j0 = max(dd - 1, 0), j3 = min(dd + 2, D - 2);
-            const float e0 = En[j0], e1 = En[j0 + 1];
-            const float ed = En[dd], ed1 = En[dd + 1], ed2 = En[dd + 2];
-            const float e3 = En[j3], e4 = En[j3 + 1];
-            const float dm1 = e1 - e0, d0 = ed1 - ed, d1 = ed2 - ed1, d2 = e4 - e3;
-            const float fm1 = dm1 < 0.f ? 1.f : 0.f;              // fd(d-1) (or fd(0) at the edge)
-            const float f0 = d0 < 0.f ? 1.f : 0.f;                // fd(d)
-            const float f1 = d1 < 0.f ? 1.f : 0.f;                // fd(d+1)
-            const float f2 = d2 < 0.f ? 1.f : 0.f;                // fd(d+2) (or fd(D-2) at the edge)
-            const float m0 = median3f(fm1, f0, f1);               // filtered fd(d)     :164
-            const float m1 = median3f(f0, f1, f2);                // filtered fd(d+1)
-            sd = (m1 - m0) * ed1;                                  // :170-173
-            if (SENS) {
-                const float dmin = fminf(fminf(fabsf(dm1), fabsf(d0)), fminf(fabsf(d1), fabsf(d2)));
-                if (dmin <= p.tau) umax = fmaxf(umax, fabsf(ed1));       // (a trough of negative energy is a candidate too: sd = -En > 0)
-                if (m1 != m0) zmin = fminf(zmin, fabsf(ed1));            // a candidate whose value could be on either side of zero
-            }
+    for (int i = 0; i < PL; ++i) {
+        const float pen = b + i < D - 2 ? -0.f : -INFINITY;      // x + (-0) = x for every x
+        const float ed1 = En[min(b + i + 1, D - 1)];            // En[dd + 1]
+        sdv[i] = (md[i + 1] - md[i]) * ed1 + pen;                // :170-173
+        if (SENS) {
+            const float dmin = fminf(fminf(fabsf(df[i]), fabsf(df[i + 1])), fminf(fabsf(df[i + 2]), fabsf(df[i + 3])));
+            umax = fmaxf(umax, dmin <= tau ? fabsf(ed1) + pen : -INFINITY);        // (a trough of negative energy is a candidate too: sd = -En > 0)
+            zmin = fminf(zmin, md[i + 1] != md[i] ? fabsf(ed1) - pen : INFINITY);  // a candidate whose value could be on either side of zero
         }
-        sdv[i] = sd;
     }
     bool sens = false;
     float prev_bv = 0.f, v_last = 0.f;
-    const int n_pick = SENS ? p.S + 1 : p.S;                      // SENS: one more, the runner-up of the last pick
+    const int n_pick = SENS ? S + 1 : S;                          // SENS: one more, the runner-up of the last pick
     for (int s = 0; s < n_pick; ++s) {                             // :185-194
-        float bv = sdv[0]; int bi = lane;
+        float lv = sdv[0]; int li = 0;                            // this lane's first maximum
 #pragma unroll
-        for (int i = 1; i < 8; ++i)
-            if (sdv[i] > bv) { bv = sdv[i]; bi = lane + 64 * i; }
+        for (int i = 1; i < PL; ++i)
+            if (sdv[i] > lv) { lv = sdv[i]; li = i; }
+        // the wave's maximum, first index on ties: lanes are in position order
+        const float g = wave_max64(lv);
+        const unsigned long long mk = __ballot(lv == g);
+        const int fl = mk ? __ffsll((long long)mk) - 1 : 0;
+        const int bi = PL * fl + __builtin_amdgcn_readlane(li, fl);
+        const float bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv), fl));
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (bi == lane + 64 * i) sdv[i] = 0.f;                 // _secondDerivative[maxIdx] = 0
-        if (SENS && s > 0 && prev_bv > 0.f && prev_bv - bv <= p.tau) sens = true;
+        for (int i = 0; i < PL; ++i)
+            if (bi == b + i) sdv[i] = 0.f;                         // _secondDerivative[maxIdx] = 0
+        if (SENS && s > 0 && prev_bv > 0.f && prev_bv - bv <= tau) sens = true;
         prev_bv = bv;
-        if (s < p.S) {
+        if (s < S) {
             v_last = bv;
-            if (lane == 0) {
-                const long long o = out_base + s;
-                p.doa_bin[o] = bi + 1;
-                if (p.doa_rad) p.doa_rad[o] = p.grid[bi + 1];      // doaIdx2angle(maxIdx+1)
-                if (p.prob) p.prob[o] = bv;
-            }
+            if (lane == 0) { obin[s] = bi + 1; oval[s] = bv; }     // doaIdx2angle(maxIdx+1) and the outputs: by the caller
         }
     }
     if (SENS) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { umax = fmaxf(umax, __shfl_xor(umax, off)); zmin = fminf(zmin, __shfl_xor(zmin, off)); }
-        if (v_last > 0.f ? umax >= v_last - p.tau : umax > -INFINITY) sens = true;
+        umax = wave_max64(umax);
+        zmin = wave_min64(zmin);
+        if (v_last > 0.f ? umax >= v_last - tau : umax > -INFINITY) sens = true;
         // the last pick is (within tau of) one of the zero entries: a candidate whose normalised energy is within tau of zero
         // could be a positive peak -- picked before every zero -- or a negative one
-        if (v_last <= p.tau && zmin <= p.tau) sens = true;
+        if (v_last <= tau && zmin <= tau) sens = true;
     }
     return sens;
 }
 
-// p.mode == 1 (coarse pass of the adaptive SRP precision): a frame whose picks are sensitive to the fp16 error -- and the
-// last frame of the call, so that the state handed to the next call is exact too -- is flagged, and the wave that found it
-// plans its repair on the spot: the groups of REPAIR_GROUP frames that hold its own row and the REPAIR_WARM rows before it
+// k_scan_pick<PL, MODE>: grid (chunks, arrays), 512 threads.  Per batch of SCAN_SUB frames: (1) thread d runs the recursion of
+// delay d and leaves the normalised energies in LDS, (2) one wave per frame picks the peaks into LDS, (3) the batch's outputs
+// are stored together.  MODE 1 (coarse pass of the adaptive SRP precision): a frame whose picks are sensitive to the fp16
+// error -- and the last frame of the call, so that the state handed to the next call is exact too -- is flagged, and a wave
+// plans its repair in step (3): the groups of REPAIR_GROUP frames that hold its own row and the REPAIR_WARM rows before it
 // (its energy is 0.2 sum_k 0.8^k C_{t-k} over the frames that advanced the recursion: with the power gate only the voiced ones,
 // BeamformingSeparationAndLocalisation.cpp:87) go onto the repair list (once: `need` is a test-and-set per group), and the chunk
 // learns which chunk its second pick has to restart from.  need / chunk_from are cleaned by the kernels that consume them
 // (k_repair_patch, k_scan_repick); the list's length is reset by k_scan_carry.
+template <int PL, int MODE>
 __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sEn = reinterpret_cast<float *>(smem_raw);                   // [SCAN_SUB][Dl]
+    __shared__ int s_bin[SCAN_SUB * MCA_MAX_SOURCES];
+    __shared__ float s_val[SCAN_SUB * MCA_MAX_SOURCES];
+    __shared__ unsigned s_flagmask;                                     // MODE 1: the flags of a batch of SCAN_SUB (<= 32) frames
+    static_assert(SCAN_SUB <= 32, "one 32-bit mask per batch");
+    static_assert(SCAN_CHUNK <= 64, "one ballot per chunk");
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
-    const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
+    const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8, S = p.S;
     const int t_start = blockIdx.x * p.chunk;
     const int t_end = min(t_start + p.chunk, p.n_frames);
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
-    const float mn = -15.f * (float)p.P;
+    const float mn = -15.f * (float)p.P, nd = -2.f * mn, nr = p.inv_norm;
     float E = act ? p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d] : 0.f;
-    const bool last_chunk = p.mode == 1 && (int)blockIdx.x == p.last_vchunk[a];   // holds the array's last advancing frame
-    __shared__ unsigned s_flagmask;                                     // mode 1: the flags of a batch of SCAN_SUB (<= 32) frames
-    static_assert(SCAN_SUB <= 32, "one 32-bit mask per batch");
+    // MODE 1: the array's last frame that advances the recursion (this chunk holds it) is always repaired
+    int t_force = -1;
+    if (MODE == 1 && (int)blockIdx.x == p.last_vchunk[a]) {
+        const int u = t_start + lane;
+        const unsigned long long m = __ballot(u < t_end && (!vc || vc[u] != 0));
+        if (m) t_force = t_start + 63 - __clzll((long long)m);
+    }
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
         if (d == 0) s_flagmask = 0u;
         if (act) {
             for (int t0 = ts; t0 < te; t0 += SCAN_LD) {
                 float c8[SCAN_LD];
+                if (p.c_planes == 1) {
 #pragma unroll
-                for (int i = 0; i < SCAN_LD; ++i) {
-                    const int t = min(t0 + i, te - 1);
-                    const long long o = (long long)t * p.Dp + d;
-                    c8[i] = csum(C, o, p.c_planes, p.c_plane_stride);
+                    for (int i = 0; i < SCAN_LD; ++i) c8[i] = C[(long long)min(t0 + i, te - 1) * p.Dp + d];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < SCAN_LD; ++i) c8[i] = csum(C, (long long)min(t0 + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
                 }
 #pragma unroll
                 for (int i = 0; i < SCAN_LD; ++i) {
@@ -551,7 +587,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                     if (t < te) {
                         if (!vc || vc[t]) E = mu * E + omu * c8[i];                 // :134-140
                         if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
-                        sEn[(t - ts) * Dl + d] = (E - mn) / (-2.f * mn);            // :155-156
+                        sEn[(t - ts) * Dl + d] = normalised_energy(E, mn, nd, nr);   // :155-156
                     }
                 }
             }
@@ -559,57 +595,69 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         __syncthreads();
         for (int tl = wave; tl < te - ts; tl += nwaves) {
             const int t = ts + tl;
-            bool flag = false;
-            if (last_chunk) {                                           // the array's last frame that advances the recursion
-                bool later = false;
-                if (vc) for (int u = t + 1; u < t_end; ++u) later |= vc[u] != 0;
-                else later = t + 1 < t_end;
-                flag = !later;
-            }
             if (vc && !vc[t]) {                                         // gated out: selectDOA is not reached (:87)
-                if (lane < p.S) p.doa_bin[((long long)a * p.n_frames + t) * p.S + lane] = -1;
-                flag = false;
-            } else if (p.mode == 1) {
-                flag |= wave_pick<true>(sEn + tl * Dl, p, ((long long)a * p.n_frames + t) * p.S, lane);
-            } else {
-                wave_pick<false>(sEn + tl * Dl, p, ((long long)a * p.n_frames + t) * p.S, lane);
+                if (lane < S) s_bin[tl * MCA_MAX_SOURCES + lane] = -1;
+                continue;
             }
-            if (p.mode == 1) {
-                if (lane == 0 && flag) atomicOr(&s_flagmask, 1u << tl);       // (one coalesced store of the batch's flags below)
-                if (flag) {
-                    // the rows this frame's energy depends on: its own and those of the REPAIR_WARM frames before it that advanced
-                    // the recursion (all of them without the gate, the voiced ones with it), 64 frames per step backwards
-                    int remaining = REPAIR_WARM + 1, u_min = t;
-                    for (int hi = t; hi >= 0 && remaining > 0; hi -= 64) {
-                        const int u = hi - 63 + lane;                        // lane 63 = frame hi
-                        const bool on = u >= 0 && (!vc || vc[u] != 0);
-                        const unsigned long long m = __ballot(on);
-                        const int above = lane < 63 ? __popcll(m >> (lane + 1)) : 0;   // advancing frames after u in this window
-                        const bool take = on && above < remaining;
-                        if (take) {
-                            const int e = a * p.groups_per_array + u / REPAIR_GROUP;
-                            if (atomicExch(&p.need[e], 1) == 0) {
-                                p.list[atomicAdd(p.n_list, 1)] = e;
-                                atomicAdd(&p.stats[1], 1ull);
-                            }
+            const bool sens = wave_pick_pl<MODE == 1, PL>(sEn + tl * Dl, D, S, p.tau, s_bin + tl * MCA_MAX_SOURCES, s_val + tl * MCA_MAX_SOURCES, lane);
+            if (MODE == 1 && lane == 0 && (sens || t == t_force)) atomicOr(&s_flagmask, 1u << tl);
+        }
+        __syncthreads();
+        // the batch's outputs, one thread per (frame, source)
+        if (d < (te - ts) * S) {
+            const int tl = d / S, sidx = d - tl * S;
+            const int bin = s_bin[tl * MCA_MAX_SOURCES + sidx];
+            const long long o = ((long long)a * p.n_frames + ts + tl) * S + sidx;
+            p.doa_bin[o] = bin;
+            if (bin >= 0) {
+                if (p.doa_rad) p.doa_rad[o] = p.grid[bin];
+                if (p.prob) p.prob[o] = s_val[tl * MCA_MAX_SOURCES + sidx];
+            }
+        }
+        if (MODE == 1) {
+            const unsigned fm = s_flagmask;
+            if (d < te - ts) p.flags[(long long)a * p.n_frames + ts + d] = (fm >> d) & 1u;
+            // plan the repair of the flagged frames, one wave per frame
+            int k = 0;
+            for (unsigned rest = fm; rest; rest &= rest - 1, ++k) {
+                if (k % nwaves != wave) continue;
+                const int t = ts + __ffs((int)rest) - 1;
+                // the rows this frame's energy depends on: its own and those of the REPAIR_WARM frames before it that advanced
+                // the recursion (all of them without the gate, the voiced ones with it), 64 frames per step backwards
+                int remaining = REPAIR_WARM + 1, u_min = t;
+                for (int hi = t; hi >= 0 && remaining > 0; hi -= 64) {
+                    const int u = hi - 63 + lane;                        // lane 63 = frame hi
+                    const bool on = u >= 0 && (!vc || vc[u] != 0);
+                    const unsigned long long m = __ballot(on);
+                    const int above = lane < 63 ? __popcll(m >> (lane + 1)) : 0;   // advancing frames after u in this window
+                    const bool take = on && above < remaining;
+                    if (take) {
+                        const int e = a * p.groups_per_array + u / REPAIR_GROUP;
+                        if (atomicExch(&p.need[e], 1) == 0) {
+                            p.list[atomicAdd(p.n_list, 1)] = e;
+                            atomicAdd(&p.stats[1], 1ull);
                         }
-                        const unsigned long long mt = __ballot(take);
-                        if (mt) u_min = hi - 63 + (__ffsll((long long)mt) - 1);
-                        remaining -= __popcll(m);
                     }
-                    if (lane == 0) {
-                        // the second pick of this chunk restarts from the (coarse) start value of the chunk that holds the earliest of those rows
-                        atomicMin(&p.chunk_from[(long long)a * p.n_chunks + blockIdx.x], u_min / p.chunk);
-                        atomicAdd(&p.stats[0], 1ull);
-                    }
+                    const unsigned long long mt = __ballot(take);
+                    if (mt) u_min = hi - 63 + (__ffsll((long long)mt) - 1);
+                    remaining -= __popcll(m);
+                }
+                if (lane == 0) {
+                    // the second pick of this chunk restarts from the (coarse) start value of the chunk that holds the earliest of those rows
+                    atomicMin(&p.chunk_from[(long long)a * p.n_chunks + blockIdx.x], u_min / p.chunk);
+                    atomicAdd(&p.stats[0], 1ull);
                 }
             }
         }
         __syncthreads();
-        if (p.mode == 1 && d < te - ts) p.flags[(long long)a * p.n_frames + ts + d] = (s_flagmask >> d) & 1u;
-        __syncthreads();
     }
 }
+template __global__ void k_scan_pick<2, 0>(ScanPickArgs);
+template __global__ void k_scan_pick<6, 0>(ScanPickArgs);
+template __global__ void k_scan_pick<8, 0>(ScanPickArgs);
+template __global__ void k_scan_pick<2, 1>(ScanPickArgs);
+template __global__ void k_scan_pick<6, 1>(ScanPickArgs);
+template __global__ void k_scan_pick<8, 1>(ScanPickArgs);
 
 // --------------------------------------------------------------------------------------
 // k_scan_repick / k_repair_patch -- adaptive SRP precision: the second pick of the flagged frames on the exact rows
@@ -623,12 +671,15 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 // The chunk with the array's last advancing frame leaves the exact state.
 constexpr int REPICK_B = 32;
 
+template <int PL>
 __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sEn = reinterpret_cast<float *>(smem_raw);                   // [REPICK_B][Dl]
+    __shared__ int s_bin[REPICK_B * MCA_MAX_SOURCES];
+    __shared__ float s_val[REPICK_B * MCA_MAX_SOURCES];
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
-    const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8;
+    const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8, S = p.S;
     const long long ci = (long long)a * p.n_chunks + blockIdx.x;
     const int c_from = p.chunk_from[ci];
     if (c_from > (int)blockIdx.x) return;
@@ -639,7 +690,7 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
-    const float mn = -15.f * (float)p.P;
+    const float mn = -15.f * (float)p.P, nd = -2.f * mn, nr = p.inv_norm;
     float E = act ? p.e_start[((long long)a * p.n_chunks + c_from) * D + d] : 0.f;
     for (int tb = c_from * p.chunk; tb < t_end; tb += REPICK_B) {
         const int te = min(tb + REPICK_B, t_end);
@@ -658,20 +709,34 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
                 if (t < te) {
                     if ((vm >> i) & 1u) E = mu * E + omu * c32[i];      // :134-140
                     if (t >= t_start && p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
-                    if ((bm >> i) & 1u) sEn[i * Dl + d] = (E - mn) / (-2.f * mn);   // :155-156
+                    if ((bm >> i) & 1u) sEn[i * Dl + d] = normalised_energy(E, mn, nd, nr);   // :155-156
                 }
             }
         }
         if (bm) {
             __syncthreads();
             for (int i = wave; i < te - tb; i += nwaves)
-                if ((bm >> i) & 1u) wave_pick<false>(sEn + i * Dl, p, ((long long)a * p.n_frames + tb + i) * p.S, lane);
+                if ((bm >> i) & 1u) wave_pick_pl<false, PL>(sEn + i * Dl, D, S, 0.f, s_bin + i * MCA_MAX_SOURCES, s_val + i * MCA_MAX_SOURCES, lane);
+            __syncthreads();
+            if (d < (te - tb) * S) {
+                const int i = d / S, sidx = d - i * S;
+                if ((bm >> i) & 1u) {
+                    const int bin = s_bin[i * MCA_MAX_SOURCES + sidx];
+                    const long long o = ((long long)a * p.n_frames + tb + i) * S + sidx;
+                    p.doa_bin[o] = bin;
+                    if (p.doa_rad) p.doa_rad[o] = p.grid[bin];
+                    if (p.prob) p.prob[o] = s_val[i * MCA_MAX_SOURCES + sidx];
+                }
+            }
             __syncthreads();
         }
     }
     if (act && (int)blockIdx.x == p.last_vchunk[a]) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
     if (d == 0) p.chunk_from[ci] = 0x7f7f7f7f;                              // consumed: no flagged frame
 }
+template __global__ void k_scan_repick<2>(ScanPickArgs);
+template __global__ void k_scan_repick<6>(ScanPickArgs);
+template __global__ void k_scan_repick<8>(ScanPickArgs);
 
 // k_repair_patch: a fixed grid walks the rows of this pass, 128 threads per row: the exact row (sum of the repair contraction's
 // split-K partial maps, plane 0 first) replaces plane 0 of the map, the other planes of that row become zero; the group's

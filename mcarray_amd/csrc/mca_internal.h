@@ -89,6 +89,7 @@ struct ScanPickArgs {
     int c_planes; long long c_plane_stride;
     int n_frames, Dp, D, P, S, chunk, n_chunks;
     float mu, one_minus_mu;
+    float inv_norm;          // correctly rounded 1 / (30 P): the normalisation (:155-156) divides by 30 P
     const float *state_in;   // [arrays][D]  E_prev at entry
     float *state_out;        // [arrays][D]  E_prev at exit
     float *part;             // [arrays][n_chunks][D]  chunk-local recursion result (E from 0)
