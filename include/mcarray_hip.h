@@ -368,6 +368,9 @@ typedef enum {
 } mca_hip_kernel_id;
 /* enable = 1: bracket every launch of the stream API with hipEvents on its stream */
 int mca_hip_set_timing(mca_hip_ctx *ctx, int enable);
+/* as mca_hip_set_timing for the kernel ids whose bit (1u << id) is set only: every event pair costs the stream ~1.5 us, a
+ * throughput measurement brackets the one kernel it reports on */
+int mca_hip_set_timing_mask(mca_hip_ctx *ctx, unsigned kernel_mask);
 /* synchronises the recorded events; *launches and *total_ms accumulate since the last reset */
 int mca_hip_get_timing(mca_hip_ctx *ctx, int kernel_id, int *launches, double *total_ms);
 int mca_hip_reset_timing(mca_hip_ctx *ctx);

@@ -157,6 +157,7 @@ SYMBOLS = [
     ("mca_hip_mvdr_state_save", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
     ("mca_hip_mvdr_state_load", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
     ("mca_hip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("mca_hip_set_timing_mask", C.c_int, [C.c_void_p, C.c_uint]),
     ("mca_hip_get_timing", C.c_int, [C.c_void_p, C.c_int, c_ip, c_dp]),
     ("mca_hip_reset_timing", C.c_int, [C.c_void_p]),
     ("mca_hip_host_alloc", C.c_void_p, [C.c_longlong]),

@@ -268,6 +268,13 @@ class Context:
     def set_timing(self, enable):
         self._check(self._lib.mca_hip_set_timing(self.h, int(enable)))
 
+    def set_timing_kernels(self, kernel_ids):
+        """event pairs around the launches of these kernel ids only (each pair costs the stream ~1.5 us)"""
+        mask = 0
+        for k in kernel_ids:
+            mask |= 1 << int(k)
+        self._check(self._lib.mca_hip_set_timing_mask(self.h, mask))
+
     def reset_timing(self):
         self._check(self._lib.mca_hip_reset_timing(self.h))
 

@@ -38,6 +38,8 @@ struct Workspace {
     void *d_Ax = nullptr; size_t ax_bytes = 0;        // ADAPTIVE: the two-plane A rows (repair pass, FP16X3 calls)
     float *d_C = nullptr; size_t c_bytes = 0;         // correlation map
     int c_planes = 1;                                 // partial maps (split-K) the last contraction left in d_C
+    bool partial_done = false;                        // the last contraction also left the scan's chunk-local results (d_part, d_nv)
+    int part_planes = 1;                              // ... one set per K half of a split-K launch
     long long c_plane = 0;
     float *d_Cx = nullptr; size_t cx_bytes = 0;       // ADAPTIVE: partial maps of the repair contraction
     // exact chunked scan + power gate
@@ -113,7 +115,8 @@ struct mca_hip_ctx {
     std::vector<double> h_stage;
     StagePool stage;              // device staging of the host-pointer entry points
     // timing
-    bool timing = false;
+    unsigned timing = 0;                 // bit k: launches of kernel id k are bracketed with events
+    bool timing_open = false;
     std::vector<TimedEvent> events;
     std::vector<hipEvent_t> pool;
     int t_launches[MCA_HIP_K_COUNT] = {};
@@ -242,7 +245,8 @@ int build_steering_table(mca_hip_ctx *c)
 
 void time_begin(mca_hip_ctx *c, int id, hipStream_t st)
 {
-    if (!c->timing) return;
+    c->timing_open = (c->timing >> id) & 1u;
+    if (!c->timing_open) return;
     TimedEvent ev; ev.id = id;
     auto get = [&]() { hipEvent_t e; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     ev.a = get(); ev.b = get();
@@ -251,7 +255,8 @@ void time_begin(mca_hip_ctx *c, int id, hipStream_t st)
 }
 void time_end(mca_hip_ctx *c, hipStream_t st)
 {
-    if (!c->timing) return;
+    if (!c->timing_open) return;
+    c->timing_open = false;
     (void)hipEventRecord(c->events.back().b, st);
 }
 
@@ -336,7 +341,7 @@ int ensure_scan_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chun
         if (c->ws().d_estart) (void)hipFree(c->ws().d_estart);
         if (c->ws().d_nv) (void)hipFree(c->ws().d_nv);
         c->ws().d_part = c->ws().d_estart = nullptr; c->ws().d_nv = nullptr; c->ws().scan_ws_chunks = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->ws().d_part, need * c->D * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_part, need * c->D * 4 * 2));      // (two sets when a split-K contraction leaves them)
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_estart, need * c->D * 4));
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_nv, need * 4));
         c->ws().scan_ws_chunks = need; ++c->ws_gen;
@@ -835,6 +840,14 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
     const long long fc = chunk_frames_for(c, n_arrays, n_frames);
     if ((rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames))) return rc;
     if ((rc = ensure_scan_workspace(c, n_arrays, n_frames, (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK))) return rc;
+    // The 256 x 384 contraction leaves the chunk-local results of the scan over frames (k_scan_partial's job) when every
+    // 32-row block of every launch is one scan chunk of one map: no gate, one map, whole chunks, that kernel for every slice.
+    bool fused_partial = SCAN_CHUNK == 32 && !c->cfg.use_power_floor && n_frames % SCAN_CHUNK == 0 && fc % SCAN_CHUNK == 0 &&
+                         plan_gemm(c, (long long)n_arrays * fc).ksplit <= 2 && std::getenv("MCA_HIP_NO_FUSED_PARTIAL") == nullptr;
+    for (int f0 = 0; fused_partial && f0 < n_frames; f0 += (int)fc)
+        fused_partial = plan_gemm(c, (long long)n_arrays * std::min<long long>(fc, n_frames - f0)).v2;
+    c->ws().partial_done = fused_partial;
+    c->ws().part_planes = fused_partial ? plan_gemm(c, (long long)n_arrays * fc).ksplit : 1;
     for (int f0 = 0; f0 < n_frames; f0 += (int)fc) {
         const int nf = (int)std::min<long long>(fc, n_frames - f0);
         StftPhatArgs sa{};
@@ -909,6 +922,12 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
         ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
         ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
+        if (fused_partial) {
+            ga.part = c->ws().d_part; ga.nvoiced = c->ws().d_nv; ga.D = c->D; ga.n_chunks = n_frames / SCAN_CHUNK;
+            ga.part_plane_stride = (long long)n_arrays * ga.n_chunks * c->D;
+            ga.scan_w[31] = 1 - 0.8f;                                              // as pa.one_minus_mu / pa.mu below
+            for (int t = 30; t >= 0; --t) ga.scan_w[t] = ga.scan_w[t + 1] * 0.8f;
+        }
         // one split factor per call (the scan sums the same number of partial maps for every frame): the one that
         // suits the full-size chunks; a shorter last chunk may still fall back to the 128 x 192 kernel
         const bool v2 = plan_gemm(c, ga.rows).v2;
@@ -979,6 +998,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
     pa.inv_norm = exact_reciprocal(30.f * (float)c->P);
     pa.state_in = c->d_E[c->e_cur] + a0 * c->D; pa.state_out = c->d_E[c->e_cur ^ 1] + a0 * c->D;
+    pa.part_planes = c->ws().partial_done ? c->ws().part_planes : 1; pa.part_plane_stride = (long long)n_arrays * n_chunks * c->D;
     pa.part = c->ws().d_part; pa.nvoiced = c->ws().d_nv; pa.e_start = c->ws().d_estart; pa.voiced = gate ? c->ws().d_voiced : nullptr;
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
     const int gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
@@ -988,7 +1008,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     }
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
-    hipLaunchKernelGGL(k_scan_partial, g3, dim3(nthr), 0, st, pa);
+    if (!c->ws().partial_done) hipLaunchKernelGGL(k_scan_partial, g3, dim3(round_up(c->Dp / 4, 64)), 0, st, pa);   // a thread per four delays
     hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays), dim3(nthr), 0, st, pa);
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
     const int ppl = c->D - 2 <= 128 ? 2 : c->D - 2 <= 384 ? 6 : 8;            // positions per lane of the peak pick
@@ -1261,8 +1281,8 @@ static int graph_record(mca_hip_graph *g, int idx)
 {
     mca_hip_ctx *c = g->c;
     const int e_cur = c->e_cur, tail_cur = c->tail_cur;
-    const bool timing = c->timing;
-    c->timing = false;                          // event pairs belong to eager calls
+    const unsigned timing = c->timing;
+    c->timing = 0;                              // event pairs belong to eager calls
     HIP_TRY(c, hipStreamBeginCapture(g->cap, hipStreamCaptureModeRelaxed));
     int rc = mca_hip_localise_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_bin, g->doa_rad,
                                          g->prob, g->energy, g->cap);
@@ -1697,7 +1717,14 @@ int mca_hip_get_energy(mca_hip_ctx *c, double *out)
 int mca_hip_set_timing(mca_hip_ctx *c, int enable)
 {
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
-    c->timing = enable != 0;
+    c->timing = enable != 0 ? ~0u : 0u;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_set_timing_mask(mca_hip_ctx *c, unsigned kernel_mask)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    c->timing = kernel_mask;
     return MCA_HIP_OK;
 }
 

@@ -417,6 +417,32 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
                 for (int j = 0; j < 6; ++j) crow[j * 32] = acc[i][j][r];
             }
         }
+    if (p.part) {
+        // Every 32-row block of the tile is one chunk of the scan over frames (the host only asks for this when that holds):
+        // its chunk-local recursion result is a weighted sum over the block's rows, 16 of them in this lane and 16 in
+        // lane ^ 32, so k_scan_partial's pass over the map is not needed.
+        const int h = lane >> 5;
+        float wt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wt[r] = h ? p.scan_w[(r & 3) + 8 * (r >> 2) + 4] : p.scan_w[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int frow0 = row0 + wm * 64 + i * 32;
+            if (frow0 < p.rows) {
+                const int arr = frow0 / p.chunk_frames, chunk = (p.frame0 + frow0 - arr * p.chunk_frames) >> 5;
+                float *out = p.part + blockIdx.y * p.part_plane_stride + ((long long)arr * p.n_chunks + chunk) * p.D + wn * 192 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc = fmaf(wt[r], acc[i][j][r], sacc);
+                    sacc += __shfl_xor(sacc, 32);
+                    if (h == 0 && wn * 192 + j * 32 + (lane & 31) < p.D) out[j * 32] = sacc;
+                }
+                if (wn == 0 && lane == 0 && blockIdx.y == 0) p.nvoiced[(long long)arr * p.n_chunks + chunk] = 32;
+            }
+        }
+    }
 }
 
 template __global__ void k_srp_gemm_f16_v2<true>(GemmArgs);

@@ -355,71 +355,107 @@ __global__ __launch_bounds__(256) void k_sum_planes(float *C, long long n4, int 
     c4[i] = acc;
 }
 
-__global__ __launch_bounds__(512) void k_scan_partial(ScanPickArgs p)
+// one step of E = 0.8f E + 0.2f C (:134-140), the same two instructions in every kernel that runs the recursion
+__device__ __forceinline__ float iir_step(float mu, float E, float omu, float c) { return fmaf(mu, E, omu * c); }
+
+// grid (chunks, arrays), Dp / 4 threads (rounded up to waves): a thread owns four neighbouring delays and reads whole
+// 16-byte pieces of the map rows, SCAN_CHUNK / 2 rows in flight.
+__global__ __launch_bounds__(256) void k_scan_partial(ScanPickArgs p)
 {
-    const int d = threadIdx.x, a = blockIdx.y, c = blockIdx.x;
+    const int q = threadIdx.x, a = blockIdx.y, c = blockIdx.x, d0 = 4 * q;
     const int t_start = c * p.chunk, t_end = min(t_start + p.chunk, p.n_frames);
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
-    float b = 0.f;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     int nv = 0;
-    if (d < p.D) {
-        for (int t0 = t_start; t0 < t_end; t0 += SCAN_LD) {              // SCAN_LD rows (x planes) in flight per thread
-            float c8[SCAN_LD];
+    constexpr int LD = SCAN_CHUNK / 2;
+    if (d0 < p.Dp) {
+        for (int t0 = t_start; t0 < t_end; t0 += LD) {
+            float4 r[LD];
 #pragma unroll
-            for (int i = 0; i < SCAN_LD; ++i) {
-                const int t = min(t0 + i, t_end - 1);
-                const long long o = (long long)t * p.Dp + d;
-                c8[i] = csum(C, o, p.c_planes, p.c_plane_stride);
+            for (int i = 0; i < LD; ++i) {
+                const long long o = (long long)min(t0 + i, t_end - 1) * p.Dp + d0;
+                r[i] = *reinterpret_cast<const float4 *>(C + o);
+                for (int pl = 1; pl < p.c_planes; ++pl) {          // the partial maps of a split-K contraction, plane 0 first
+                    const float4 w = *reinterpret_cast<const float4 *>(C + o + pl * p.c_plane_stride);
+                    r[i].x += w.x; r[i].y += w.y; r[i].z += w.z; r[i].w += w.w;
+                }
             }
 #pragma unroll
-            for (int i = 0; i < SCAN_LD; ++i)
-                if (t0 + i < t_end && (!vc || vc[t0 + i])) { b = p.mu * b + p.one_minus_mu * c8[i]; ++nv; }
+            for (int i = 0; i < LD; ++i)
+                if (t0 + i < t_end && (!vc || vc[t0 + i])) {
+                    b.x = iir_step(p.mu, b.x, p.one_minus_mu, r[i].x); b.y = iir_step(p.mu, b.y, p.one_minus_mu, r[i].y);
+                    b.z = iir_step(p.mu, b.z, p.one_minus_mu, r[i].z); b.w = iir_step(p.mu, b.w, p.one_minus_mu, r[i].w);
+                    ++nv;
+                }
         }
-        p.part[((long long)a * p.n_chunks + c) * p.D + d] = b;
+        float *out = p.part + ((long long)a * p.n_chunks + c) * p.D;
+        if (d0 < p.D) out[d0] = b.x;
+        if (d0 + 1 < p.D) out[d0 + 1] = b.y;
+        if (d0 + 2 < p.D) out[d0 + 2] = b.z;
+        if (d0 + 3 < p.D) out[d0 + 3] = b.w;
     }
-    if (d == 0) p.nvoiced[(long long)a * p.n_chunks + c] = nv;
+    if (q == 0) p.nvoiced[(long long)a * p.n_chunks + c] = nv;
 }
 
+constexpr int CARRY_TILE = 64;                                       // chunks whose partial results (x planes) a thread holds in flight
 __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
 {
     __shared__ float spow[SCAN_CHUNK + 1];                          // 0.8f^n
+    __shared__ float sg[CARRY_TILE];                                // 0.8f^(voiced frames of the chunk), the tile's chunks
+    __shared__ int s_lv;
     const int d = threadIdx.x, a = blockIdx.x;
     if (p.mode == 1 && a == 0 && d == 0) *p.n_list = 0;              // adaptive SRP precision: the repair list starts empty
-    __shared__ int s_lv;
     if (d == 0) s_lv = -1;
-    __syncthreads();
-    if (p.mode == 1) {
-        // the chunk that holds the array's last frame whose energy advanced (= its last frame without the gate): that frame is
-        // always repaired, so that the state handed to the next call is exact
-        for (int c = d; c < p.n_chunks; c += blockDim.x)
-            if (p.nvoiced[(long long)a * p.n_chunks + c] > 0) atomicMax(&s_lv, c);
-        __syncthreads();
-        if (d == 0) p.last_vchunk[a] = s_lv;
-    }
     for (int n = d; n <= SCAN_CHUNK; n += blockDim.x) {
         float g = 1.f;
         for (int i = 0; i < n; ++i) g *= p.mu;
         spow[n] = g;
     }
-    __syncthreads();
-    if (d >= p.D) return;
-    float E = p.state_in[(long long)a * p.D + d];
     const int *nvp = p.nvoiced + (long long)a * p.n_chunks;
+    const bool act = d < p.D;
+    float E = act ? p.state_in[(long long)a * p.D + d] : 0.f;
     const float *pp = p.part + (long long)a * p.n_chunks * p.D + d;
     float *ep = p.e_start + (long long)a * p.n_chunks * p.D + d;
-    for (int c0 = 0; c0 < p.n_chunks; c0 += 16) {                    // 16 chunks (32 loads) in flight, then the serial composition
-        int nv8[16]; float b8[16];
+    for (int c0 = 0; c0 < p.n_chunks; c0 += CARRY_TILE) {            // a tile's loads all in flight, then the serial composition
+        float b[CARRY_TILE];
+        if (act) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = min(c0 + i, p.n_chunks - 1);
-            nv8[i] = nvp[c]; b8[i] = pp[(long long)c * p.D];
+            for (int i = 0; i < CARRY_TILE; ++i) b[i] = pp[(long long)min(c0 + i, p.n_chunks - 1) * p.D];
+            if (p.part_planes == 2) {                                 // the contraction's two K halves, half 0 first
+                float b1[CARRY_TILE];
+#pragma unroll
+                for (int i = 0; i < CARRY_TILE; ++i) b1[i] = pp[(long long)min(c0 + i, p.n_chunks - 1) * p.D + p.part_plane_stride];
+#pragma unroll
+                for (int i = 0; i < CARRY_TILE; ++i) b[i] += b1[i];
+            }
         }
+        int nvr[2];                                                  // (at least 64 threads: at most two chunks of the tile per thread)
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (c0 + i < p.n_chunks) { ep[(long long)(c0 + i) * p.D] = E; E = spow[nv8[i]] * E + b8[i]; }
+        for (int k = 0; k < 2; ++k) {
+            const int i = d + k * (int)blockDim.x;
+            nvr[k] = i < CARRY_TILE && c0 + i < p.n_chunks ? nvp[c0 + i] : 0;
+        }
+        __syncthreads();                                             // spow written; the previous tile's sg consumed
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = d + k * (int)blockDim.x, n = nvr[k];
+            if (i >= CARRY_TILE) break;
+            sg[i] = spow[n];
+            // the chunk that holds the array's last frame whose energy advanced (= its last frame without the gate): that frame is
+            // always repaired, so that the state handed to the next call is exact
+            if (p.mode == 1 && n > 0) atomicMax(&s_lv, c0 + i);
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < CARRY_TILE; ++i)
+                if (c0 + i < p.n_chunks) { ep[(long long)(c0 + i) * p.D] = E; E = sg[i] * E + b[i]; }
+        }
     }
-    p.state_out[(long long)a * p.D + d] = E;                         // _prevEnergyInDOA (:143)
+    if (act) p.state_out[(long long)a * p.D + d] = E;                // _prevEnergyInDOA (:143)
+    __syncthreads();
+    if (p.mode == 1 && d == 0) p.last_vchunk[a] = s_lv;
 }
 
 // selectDOA of one frame by one wave (SteeringBeamforming.cpp:146-195): En = the frame's normalised energies (LDS), lane
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 for (int i = 0; i < SCAN_LD; ++i) {
                     const int t = t0 + i;
                     if (t < te) {
-                        if (!vc || vc[t]) E = mu * E + omu * c8[i];                 // :134-140
+                        if (!vc || vc[t]) E = iir_step(mu, E, omu, c8[i]);            // :134-140
                         if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
                         sEn[(t - ts) * Dl + d] = normalised_energy(E, mn, nd, nr);   // :155-156
                     }
@@ -707,7 +743,7 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
             for (int i = 0; i < REPICK_B; ++i) {
                 const int t = tb + i;
                 if (t < te) {
-                    if ((vm >> i) & 1u) E = mu * E + omu * c32[i];      // :134-140
+                    if ((vm >> i) & 1u) E = iir_step(mu, E, omu, c32[i]);   // :134-140
                     if (t >= t_start && p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
                     if ((bm >> i) & 1u) sEn[i * Dl + d] = normalised_energy(E, mn, nd, nr);   // :155-156
                 }

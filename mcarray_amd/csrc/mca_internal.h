@@ -82,6 +82,11 @@ struct GemmArgs {
     const void *Bt;          // fp16 steering table tiled for the 256 x 384 kernel: [plane][Kp/32][Dp][32] (a K stage of all columns is contiguous)
     // device-side row count (repair pass): rows = min(rows, (*n_list - list0) * REPAIR_GROUP); workgroups beyond it exit
     const int *n_list; int list0;
+    // chunk-local scan result from the contraction's epilogue (256 x 384 kernel, one map, no gate, 32-row blocks = scan chunks):
+    // part[arr][chunk][d] = sum_t scan_w[t] C[t][d] = the recursion E = 0.8f E + 0.2f C run from zero over the chunk's frames
+    float *part; int *nvoiced; int D, n_chunks;
+    long long part_plane_stride;   // a split-K launch leaves one set of results per K half (summed by k_scan_carry, half 0 first)
+    float scan_w[32];
 };
 
 struct ScanPickArgs {
@@ -92,7 +97,8 @@ struct ScanPickArgs {
     float inv_norm;          // correctly rounded 1 / (30 P): the normalisation (:155-156) divides by 30 P
     const float *state_in;   // [arrays][D]  E_prev at entry
     float *state_out;        // [arrays][D]  E_prev at exit
-    float *part;             // [arrays][n_chunks][D]  chunk-local recursion result (E from 0)
+    float *part;             // [part_planes][arrays][n_chunks][D]  chunk-local recursion result (E from 0); 2 planes: the two K halves of the contraction
+    int part_planes; long long part_plane_stride;
     int *nvoiced;            // [arrays][n_chunks]     voiced frames per chunk
     float *e_start;          // [arrays][n_chunks][D]  E at the start of every chunk
     const unsigned char *voiced;   // [arrays][n_frames] 1 = frame passed the power gate; NULL = ungated (all frames)

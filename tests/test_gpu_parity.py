@@ -174,7 +174,8 @@ def test_state_carries_across_calls():
     ra = two.process_frames_host(pcm[None, :, :(h + 1) * hop], want_energy=True)
     rb = two.process_frames_host(pcm[None, :, h * hop:], want_energy=True)
     assert np.array_equal(np.concatenate([ra["bin"], rb["bin"]], axis=1), r1["bin"])
-    np.testing.assert_allclose(np.concatenate([ra["energy"], rb["energy"]], axis=1), r1["energy"], rtol=0, atol=1e-3)
+    # (the two runs cut the recursion into chunks at different frames: a few ulp of fp32 rounding between them)
+    np.testing.assert_allclose(np.concatenate([ra["energy"], rb["energy"]], axis=1), r1["energy"], rtol=2e-6, atol=1e-3)
     np.testing.assert_allclose(np.concatenate([ra["out"], rb["out"]], axis=2), r1["out"], rtol=0, atol=1e-6)
     # reset gives a fresh module
     two.reset()
