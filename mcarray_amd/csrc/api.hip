@@ -936,7 +936,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         time_begin(c, MCA_HIP_K_SRP_GEMM, st);
         if (v2) {
             const int np = c->a_planes;
-            const size_t smem = (size_t)2 * np * (256 + 384) * 64;        // two 32-deep stages: all 160 KiB with hi + lo planes
+            const size_t smem = (size_t)(np == 2 ? 2 : 4) * np * (256 + 384) * 64;   // 32-deep stages: two with hi + lo planes, four with one plane (all 160 KiB)
             dim3 gv((ga.rows + 255) / 256, ksplit);
 #define V2_LAUNCH(K)                                                                                                      \
             do {                                                                                                          \

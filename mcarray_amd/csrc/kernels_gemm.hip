@@ -282,6 +282,10 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     constexpr int NP = SPLIT ? 2 : 1;
     constexpr int A_BYTES = V2_BM * V3_ROWB, B_BYTES = V2_BN * V3_ROWB;      // per plane: 16 KiB, 24 KiB
     constexpr int STAGE = NP * (A_BYTES + B_BYTES);                         // 80 KiB (SPLIT)
+    // stages in LDS: two with the hi + lo planes (all 160 KiB); the one-plane kernel has room for four, so that the loads of a
+    // stage are issued three stages (~2 us) ahead of their use instead of one
+    constexpr int NS = SPLIT ? 2 : 4;
+    constexpr int LPS = NP * 5;                                             // load instructions per wave and stage (2 A + 3 B per plane)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -348,15 +352,22 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     const int b_off0 = rb * V3_ROWB + ((((lane >> 5)) ^ ((rb >> 2) & 3)) << 4);
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t *)smem_g);
 
-    if (ns > 0) { issue_a(0, 0); issue_b(0, 0); }
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q)
+        if (q < ns) { issue_a(q, q); issue_b(q, q); }
     for (int s = 0; s < ns; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage s is the only one in flight
+        // the loads of stage s have landed when at most those of the stages issued after it are outstanding (loads of one
+        // wave return in order)
+        const int later = min(NS - 2, ns - 1 - s);
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + 1 < ns) issue_a(s + 1, (s + 1) & 1);            // that buffer was last read in stage s-1
+        if (s + NS - 1 < ns) issue_a(s + NS - 1, (s + NS - 1) % NS);      // that buffer was last read in stage s-1
 #define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 1 && s + 1 < ns) issue_b(s + 1, (s + 1) & 1);
+            if (kk == 1 && s + NS - 1 < ns) issue_b(s + NS - 1, (s + NS - 1) % NS);
             // Rolling B fragments: two register slots (a third would spill).  A and column blocks 0, 1 are requested
             // up front; as soon as the MFMAs of block j have issued, block j+2 is requested into the slot they read, so
             // the LDS reads run under the matrix work.  The reads and their waits are inline asm: the compiler waits
@@ -365,8 +376,8 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
             // outstanding" is exact; every wait lists the registers it releases as in/out operands so that nothing
             // can read them earlier.
             f16x8 af[NP][2], bs[2][NP];
-            const unsigned a_addr = lds0 + (s & 1) * STAGE + (a_off0 ^ (kk << 5));
-            const unsigned b_addr = lds0 + (s & 1) * STAGE + NP * A_BYTES + (b_off0 ^ (kk << 5));
+            const unsigned a_addr = lds0 + (s % NS) * STAGE + (a_off0 ^ (kk << 5));
+            const unsigned b_addr = lds0 + (s % NS) * STAGE + NP * A_BYTES + (b_off0 ^ (kk << 5));
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 LDS_RD(af[pl][0], a_addr, pl * A_BYTES);
