@@ -842,7 +842,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
     if ((rc = ensure_scan_workspace(c, n_arrays, n_frames, (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK))) return rc;
     // The 256 x 384 contraction leaves the chunk-local results of the scan over frames (k_scan_partial's job) when every
     // 32-row block of every launch is one scan chunk of one map: no gate, one map, whole chunks, that kernel for every slice.
-    bool fused_partial = SCAN_CHUNK == 32 && !c->cfg.use_power_floor && n_frames % SCAN_CHUNK == 0 && fc % SCAN_CHUNK == 0 &&
+    bool fused_partial = SCAN_CHUNK == 32 && c->a_planes == 1 && !c->cfg.use_power_floor && n_frames % SCAN_CHUNK == 0 && fc % SCAN_CHUNK == 0 &&
                          plan_gemm(c, (long long)n_arrays * fc).ksplit <= 2 && std::getenv("MCA_HIP_NO_FUSED_PARTIAL") == nullptr;
     for (int f0 = 0; fused_partial && f0 < n_frames; f0 += (int)fc)
         fused_partial = plan_gemm(c, (long long)n_arrays * std::min<long long>(fc, n_frames - f0)).v2;

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
                 for (int j = 0; j < 6; ++j) crow[j * 32] = acc[i][j][r];
             }
         }
-    if (p.part) {
+    if constexpr (!SPLIT) if (p.part) {      // (the two-plane kernel has no registers to spare for it)
         // Every 32-row block of the tile is one chunk of the scan over frames (the host only asks for this when that holds):
         // its chunk-local recursion result is a weighted sum over the block's rows, 16 of them in this lane and 16 in
         // lane ^ 32, so k_scan_partial's pass over the map is not needed.
