@@ -78,6 +78,24 @@ def test_stream_vs_oracle_random_ula8_d361(prec):
     ctx.close()
 
 
+@pytest.mark.parametrize("step,D,S", [(0.4, 451, 2), (1.0, 181, 3), (3.0, 61, 1)])
+def test_other_angle_grids_vs_oracle(step, D, S):
+    """the peak pick deals 2 / 6 / 8 consecutive positions to a lane by the number of angles (451 angles: 8 per lane, a map padded
+    to 576 columns); several sources"""
+    fs, N, F, A = 48000, 1024, 36, 2
+    xs = synth.ULA8
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(th), fs, (F + 1) * N // 2, 300 + a) for a, th in enumerate((-41.0, 63.0))])
+    ctx = api.Context(fs, xs, N, step, S, max_arrays=A)
+    assert ctx.D == D
+    r = ctx.process_frames_host(pcm, want_energy=True)
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), S, step, want_map=True)
+        _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=3)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= 2e-4 * np.abs(o["energy"]).max()
+        assert np.abs(r["out"][a] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+
+
 @pytest.mark.parametrize("prec", [api.SRP_FP16X3, api.SRP_FP16])
 def test_split_k_contraction_vs_oracle(prec):
     # >= 1024 rows with 361 angles selects the 256 x 384 split-K MFMA kernel (two partial maps summed by the scan)
@@ -796,3 +814,31 @@ def test_masking_context_rejects_a_changing_stream_count():
     m.process(pcm[:2])
     m.reset()
     m.process(pcm)
+
+
+def test_kernel_timing_and_mask():
+    """mca_hip_set_timing / mca_hip_set_timing_mask / mca_hip_get_timing: event pairs around every kernel group, or around the
+    chosen ones only (what bench.py does inside its timed region); the outputs do not depend on it."""
+    fs, N, F = 48000, 1024, 64
+    xs = synth.ULA8
+    pcm = synth.noise_source_stream(xs, np.deg2rad(20.0), fs, (F + 1) * N // 2, 5)
+    ctx = api.Context(fs, xs, N, 0.5, 1)
+    r0 = ctx.process_frames_host(pcm[None])
+    ctx.reset()
+    ctx.set_timing(True)
+    ctx.reset_timing()
+    r1 = ctx.process_frames_host(pcm[None])
+    n_stft, ms_stft = ctx.get_timing(api.K_STFT_PHAT)
+    n_bf, ms_bf = ctx.get_timing(api.K_BEAMFORM)
+    assert n_stft >= 1 and n_bf >= 1 and ms_stft > 0 and ms_bf > 0
+    ctx.reset()
+    ctx.set_timing_kernels([api.K_BEAMFORM])
+    ctx.reset_timing()
+    r2 = ctx.process_frames_host(pcm[None])
+    assert ctx.get_timing(api.K_STFT_PHAT)[0] == 0 and ctx.get_timing(api.K_SRP_GEMM)[0] == 0
+    assert ctx.get_timing(api.K_BEAMFORM)[0] == n_bf
+    ctx.set_timing(False)
+    for r in (r1, r2):
+        assert np.array_equal(r["bin"], r0["bin"])
+        np.testing.assert_array_equal(r["out"], r0["out"])
+
