@@ -79,8 +79,9 @@ __device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, 
 __device__ __forceinline__ float sum8(const float *s) { return ((((((s[0] + s[1]) + s[2]) + s[3]) + s[4]) + s[5]) + s[6]) + s[7]; }
 
 template <int MT, bool ULA, typename OutT>
-// (one channel per FFT wave: six waves per SIMD = three workgroups per CU are worth a few spilled registers, 0.297 -> 0.291 ms)
-__global__ __launch_bounds__(512, (MT > 0 && MT <= 8) ? 6 : 1) void k_stft_phat(StftPhatArgs p)
+// (__launch_bounds__(512, 6) -- three workgroups per CU -- measured 2 % faster, but its spilled registers add 0.1 GB of
+// scratch traffic per 32 768 frames: not taken)
+__global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *smem = reinterpret_cast<float2 *>(smem_raw);                // [M][FFT_SCRATCH] spectra
