@@ -167,15 +167,24 @@ __device__ __forceinline__ void wave_lds_fence()
 // 512-point complex FFT of v[r] = z[lane + 64 r] through buf (this wave's scratch, FFT_SCRATCH words).
 // The result stays in registers with the same distribution as the input, register index bit-reversed:
 // on return v[i] = Z[lane + 64 * br3(i)].
-template <bool INV>
+template <bool INV, bool AHEAD = false>
 __device__ __forceinline__ void cfft512_regs(float2 (&v)[8], float2 *buf, int lane, const FftTw &tw)
 {
     // stage A: DFT over r, twiddle W512^(lane*q), exchange 1: buf[q*72 + lane]
+    // AHEAD: the twiddles of a stage are read ahead of its butterflies (the compiler cannot move a table read above the
+    // exchange stores -- same address space -- so each read is otherwise waited for right before its product).  Worth
+    // 2 % in k_stft_phat; k_beamform_ola, at 125 registers, loses as much.
+    float2 twa[8];
+    if (AHEAD) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) twa[i] = tw.t1(br3(i), lane);
+    }
     fft8<INV>(v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int q = br3(i);
-        buf[q * FFT_ROW + lane] = (q == 0) ? v[i] : (INV ? cmulc(v[i], tw.t1(q, lane)) : cmul(v[i], tw.t1(q, lane)));
+        const float2 w = (q == 0) ? make_float2(1.f, 0.f) : (AHEAD ? twa[i] : tw.t1(q, lane));
+        buf[q * FFT_ROW + lane] = (q == 0) ? v[i] : (INV ? cmulc(v[i], w) : cmul(v[i], w));
     }
     wave_lds_fence();
     const int qq = lane >> 3, l0 = lane & 7;
@@ -185,11 +194,17 @@ __device__ __forceinline__ void cfft512_regs(float2 (&v)[8], float2 *buf, int la
     // stage B: DFT over l1, twiddle W64^(l0*s), exchange 2: buf[q + 66*l0 + 8*s].  The layout makes the
     // 16-lane write groups (q pair x l0) hit 16 distinct bank pairs and turns the read-back into
     // contiguous rows: the reading lane is (s, q) = (lane >> 3, lane & 7), address lane + 66*l0.
+    float2 twb[8];
+    if (AHEAD) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) twb[i] = tw.t2(br3(i), lane);
+    }
     fft8<INV>(v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int s = br3(i);
-        buf[qq + 66 * l0 + 8 * s] = (s == 0) ? v[i] : (INV ? cmulc(v[i], tw.t2(s, lane)) : cmul(v[i], tw.t2(s, lane)));
+        const float2 w = (s == 0) ? make_float2(1.f, 0.f) : (AHEAD ? twb[i] : tw.t2(s, lane));
+        buf[qq + 66 * l0 + 8 * s] = (s == 0) ? v[i] : (INV ? cmulc(v[i], w) : cmul(v[i], w));
     }
     wave_lds_fence();
 #pragma unroll
@@ -202,9 +217,10 @@ __device__ __forceinline__ void cfft512_regs(float2 (&v)[8], float2 *buf, int la
 // Forward real FFT.  v[r] = (x[2m], x[2m+1]) windowed with HALF the analysis window (the table of
 // fft_table_init carries the 1/2 of the split step), m = lane + 64 r.
 // On return buf[k], k = 0..512, holds X[k] (buf must have >= FFT_SCRATCH words; word 512 is used).
+template <bool AHEAD = false>
 __device__ __forceinline__ void rfft1024(float2 (&v)[8], float2 *buf, int lane, const FftTw &tw)
 {
-    cfft512_regs<false>(v, buf, lane, tw);
+    cfft512_regs<false, AHEAD>(v, buf, lane, tw);
     // split step on pairs (k, 512-k):  X[k] = a + W b,  X[512-k] = conj(a - W b),
     // a = Z[k] + conj Z[512-k],  b = -j (Z[k] - conj Z[512-k]),  W = W1024^k  (Z already halved).
     // Z[k], k = lane + 64 i < 256, is in this lane's registers; its partner lives in lane 64 - lane,

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void k_stft_phat(StftPhatArgs p)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) nxt[cc][r] = src[lane + 64 * (r + 4)];
                 }
-                rfft1024(v, smem + c * FFT_SCRATCH, lane, tw);
+                rfft1024<true>(v, smem + c * FFT_SCRATCH, lane, tw);
             }
         }
         __syncthreads();
