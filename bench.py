@@ -119,7 +119,8 @@ def traffic_from_profiles(roof, dom, precision, shape_matches):
         kk = json.load(open(tj))["kernels"].get(dom)
         if kk:   # gfx950 correction: FETCH_SIZE reports half of a wide coalesced read stream
             roof["traffic"] = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0
-            roof["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)"
+            roof["traffic_unit"] = ("bytes per step of this kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes; in the adaptive mode "
+                                    "k_stft_phat's figure includes its second, list-mode launch of the repair pass: ~3 %)")
             roof["traffic_source"] = "profiles/%s_pmc_traffic_%s.json (committed PMC passes of the same command on an MI355X; not this run)" % (PROFILE_TAG, precision)
 
 
