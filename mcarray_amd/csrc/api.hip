@@ -944,7 +944,9 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
                 hipLaunchKernelGGL(K, gv, dim3(512), smem, st, ga);                                                       \
             } while (0)
+            static const bool use_v3 = std::getenv("MCA_HIP_GEMM_V2") == nullptr;       // A/B switch: the 32x32x16 one-plane kernel
             if (c->a_planes == 2) V2_LAUNCH((k_srp_gemm_f16_v2<true>));
+            else if (use_v3) V2_LAUNCH(k_srp_gemm_f16_v3);
             else V2_LAUNCH((k_srp_gemm_f16_v2<false>));
 #undef V2_LAUNCH
         } else {

@@ -24,6 +24,7 @@ __global__ void k_beamform_gen(BeamformArgs p);
 __global__ void k_srp_gemm_f32(GemmArgs p);
 template <bool SPLIT, int BN> __global__ void k_srp_gemm_f16(GemmArgs p);
 template <bool SPLIT> __global__ void k_srp_gemm_f16_v2(GemmArgs p);
+__global__ void k_srp_gemm_f16_v3(GemmArgs p);      // one plane, v_mfma_f32_16x16x32_f16
 template <int BN> __global__ void k_srp_gemm_repair(GemmArgs p);
 
 template <typename T> struct C2;

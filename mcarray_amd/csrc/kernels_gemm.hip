@@ -456,6 +456,159 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v2(GemmArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_srp_gemm_f16_v3: the one-plane 256 x 384 contraction on v_mfma_f32_16x16x32_f16.
+// Same tile, stages, DMA and split-K as k_srp_gemm_f16_v2<false>; the 16x16x32 form needs the same fragment bytes per
+// MAC (a fragment spans the stage's whole 32-deep K: 4 A + 12 B reads and 48 MFMAs per stage and wave instead of
+// 2 x (2 + 6) reads and 24 MFMAs) and runs the matrix pipe at a higher clock under the same load (timing probe with the
+// 32x32 kernel's operand stream: 168.6 -> 155.4 us).  Fragment: lane l holds row (l & 15), K chunk (l >> 4) of the
+// 64-byte LDS row, i.e. a ds_read_b128 covers 16 whole rows; with the v2 swizzle its lane groups would hit banks
+// twice, so the physical chunk is the logical one XOR g[(row >> 2) & 3], g = {0, 2, 3, 1} (every 16-lane read group
+// then takes 16 distinct (row % 4, chunk) slots), on the DMA source address and on the read address alike.
+// C/D of the MFMA: col = lane & 15, row = 4 (lane >> 4) + r.
+// ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int v3_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+__global__ __launch_bounds__(512) void k_srp_gemm_f16_v3(GemmArgs p)
+{
+    constexpr int A_BYTES = V2_BM * V3_ROWB, B_BYTES = V2_BN * V3_ROWB;      // 16 KiB, 24 KiB
+    constexpr int STAGE = A_BYTES + B_BYTES;                                // 40 KiB: four stages in LDS
+    constexpr int NS = 4, LPS = 5;                                          // load instructions per wave and stage (2 A + 3 B)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0 = blockIdx.x * V2_BM;
+    const unsigned char *A = reinterpret_cast<const unsigned char *>(p.A);
+    const unsigned char *B = reinterpret_cast<const unsigned char *>(p.Bt);  // [stage][384][32]
+
+    const int nst_all = p.Kp / V3_BK;
+    const int per = (nst_all + gridDim.y - 1) / gridDim.y;
+    const int s_beg = blockIdx.y * per, s_end = min(s_beg + per, nst_all);
+    const int ns = s_end - s_beg;
+
+    // one LDS-DMA instruction = 16 rows x 64 B: lane -> (row lane >> 2, physical chunk lane & 3); wave w takes the A row
+    // blocks w, w + 8 and the B row blocks w, w + 8, w + 16 (16 rows each; blocks start at multiples of 16 rows, so the
+    // swizzle term only depends on the lane's row inside the block)
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int r0 = wave * 16 + lrow;
+    const int lch = pch ^ v3_swz(r0);
+    const unsigned char *a_lane = A + ((long long)(row0 + r0) * p.a_row_elems + lch * 8) * 2;
+    const unsigned char *b_lane = B + r0 * V3_ROWB + lch * 16;
+    const long long a_blk = (long long)128 * p.a_row_elems * 2;
+    const int dst0 = wave * 1024;
+
+    f32x4 acc[4][12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    auto issue_a = [&](int s, int buf) {
+        const long long koff_a = (long long)(s_beg + s) * V3_BK * 2;
+        unsigned char *sb = smem_g + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a_lane + i * a_blk + koff_a), (lds_void_t *)(sb + dst0 + i * 8192), 16, 0, 0);
+    };
+    auto issue_b = [&](int s, int buf) {
+        const long long koff_b = (long long)(s_beg + s) * B_BYTES;
+        unsigned char *sb = smem_g + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(b_lane + i * (128 * V3_ROWB) + koff_b), (lds_void_t *)(sb + A_BYTES + dst0 + i * 8192), 16, 0, 0);
+    };
+
+    // fragment addresses: lane (row l & 15, K chunk l >> 4); row blocks are 16 rows = 1 KiB apart
+    const int ra = wm * 64 + (lane & 15), rb = wn * 192 + (lane & 15);
+    const int a_off0 = ra * V3_ROWB + (((lane >> 4) ^ v3_swz(ra)) << 4);
+    const int b_off0 = rb * V3_ROWB + (((lane >> 4) ^ v3_swz(rb)) << 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t *)smem_g);
+
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q)
+        if (q < ns) { issue_a(q, q); issue_b(q, q); }
+    for (int s = 0; s < ns; ++s) {
+        const int later = min(NS - 2, ns - 1 - s);                 // stages issued after this one (loads of a wave return in order)
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = s + NS - 1 < ns;
+        if (more) issue_a(s + NS - 1, (s + NS - 1) % NS);          // that buffer was last read in stage s-1
+#define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+        f16x8 af[4], bs[2];
+        const unsigned a_addr = lds0 + (s % NS) * STAGE + a_off0;
+        const unsigned b_addr = lds0 + (s % NS) * STAGE + A_BYTES + b_off0;
+        LDS_RD(af[0], a_addr, 0); LDS_RD(af[1], a_addr, 1024); LDS_RD(af[2], a_addr, 2048); LDS_RD(af[3], a_addr, 3072);
+        LDS_RD(bs[0], b_addr, 0); LDS_RD(bs[1], b_addr, 1024);
+        // rolling B fragments as in v2: block j's MFMAs issue, then block j + 2 is requested into the slot they read
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            if (j == 6 && more) issue_b(s + NS - 1, (s + NS - 1) % NS);
+            if (j == 0) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bs[0]));
+            else if (j < 11) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bs[j % 2]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 2]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bs[j % 2], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 2 < 12) LDS_RD(bs[j % 2], b_addr, (j + 2) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef LDS_RD
+    }
+    float *Cp = p.C + (long long)blockIdx.y * p.c_plane_elems;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int frow = row0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+            if (frow < p.rows) {
+                const int arr = frow / p.chunk_frames, fl = frow - arr * p.chunk_frames;
+                float *crow = Cp + ((long long)arr * p.total_frames + p.frame0 + fl) * p.Dp + wn * 192 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) crow[j * 16] = acc[i][j][r];
+            }
+        }
+    if (p.part) {
+        // Every 32-row block of the tile is one chunk of the scan over frames (the host only asks for this when that holds):
+        // its chunk-local recursion result is a weighted sum over the block's rows -- 8 of them in this lane (two 16-row MFMA
+        // blocks x 4 registers), the rest in the lanes 16, 32 and 48 further -- so k_scan_partial's pass over the map is not needed.
+        float wt[2][4];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g4 = lane >> 4;                           // (selects, not an indexed read of the argument block)
+                const float w01 = g4 == 0 ? p.scan_w[b2 * 16 + r] : p.scan_w[b2 * 16 + 4 + r];
+                const float w23 = g4 == 2 ? p.scan_w[b2 * 16 + 8 + r] : p.scan_w[b2 * 16 + 12 + r];
+                wt[b2][r] = g4 < 2 ? w01 : w23;
+            }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int frow0 = row0 + wm * 64 + ch * 32;
+            if (frow0 < p.rows) {
+                const int arr = frow0 / p.chunk_frames, chunk = (p.frame0 + frow0 - arr * p.chunk_frames) >> 5;
+                float *out = p.part + blockIdx.y * p.part_plane_stride + ((long long)arr * p.n_chunks + chunk) * p.D + wn * 192 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc = fmaf(wt[b2][r], acc[2 * ch + b2][j][r], sacc);
+                    sacc += __shfl_xor(sacc, 16);
+                    sacc += __shfl_xor(sacc, 32);
+                    if (lane < 16 && wn * 192 + j * 16 + lane < p.D) out[j * 16] = sacc;
+                }
+                if (wn == 0 && lane == 0 && blockIdx.y == 0) p.nvoiced[(long long)arr * p.n_chunks + chunk] = 32;
+            }
+        }
+    }
+}
+
 template __global__ void k_srp_gemm_f16_v2<true>(GemmArgs);
 template __global__ void k_srp_gemm_f16_v2<false>(GemmArgs);
 
