@@ -547,7 +547,8 @@ __global__ __launch_bounds__(512) void k_srp_gemm_f16_v3(GemmArgs p)
         // rolling B fragments as in v2: block j's MFMAs issue, then block j + 2 is requested into the slot they read
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            if (j == 6 && more) issue_b(s + NS - 1, (s + NS - 1) % NS);
+            // (the B burst behind the last column block's reads: measured at column block 2 / 4 / 6 / 9 / 11: 159.7 / 157 / 156 / 154.5 / 153.5 us)
+            if (j == 11 && more) issue_b(s + NS - 1, (s + NS - 1) % NS);
             if (j == 0) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bs[0]));
             else if (j < 11) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bs[j % 2]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs[j % 2]));
