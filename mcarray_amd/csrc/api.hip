@@ -1012,7 +1012,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
     if (!c->ws().partial_done) hipLaunchKernelGGL(k_scan_partial, g3, dim3(round_up(c->Dp / 4, 64)), 0, st, pa);   // a thread per four delays
-    hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays), dim3(nthr), 0, st, pa);
+    hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays, nthr / 64), dim3(64), 0, st, pa);   // one wave per 64 delays
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
     const int ppl = c->D - 2 <= 128 ? 2 : c->D - 2 <= 384 ? 6 : 8;            // positions per lane of the peak pick
 #define LAUNCH_PICK(PL, MODE)                                                                                                       \

@@ -406,10 +406,12 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
     __shared__ float spow[SCAN_CHUNK + 1];                          // 0.8f^n
     __shared__ float sg[CARRY_TILE];                                // 0.8f^(voiced frames of the chunk), the tile's chunks
     __shared__ int s_lv;
-    const int d = threadIdx.x, a = blockIdx.x;
+    // grid (arrays, slices of 64 delays): one wave per slice spreads the strided loads over many CUs (17.7 -> 16 us; four waves
+    // per slice fetching side by side into LDS with one of them composing measured 19.6 us: the composition wants registers)
+    const int tl = threadIdx.x, d = blockIdx.y * blockDim.x + tl, a = blockIdx.x;
     if (p.mode == 1 && a == 0 && d == 0) *p.n_list = 0;              // adaptive SRP precision: the repair list starts empty
-    if (d == 0) s_lv = -1;
-    for (int n = d; n <= SCAN_CHUNK; n += blockDim.x) {
+    if (tl == 0) s_lv = -1;
+    for (int n = tl; n <= SCAN_CHUNK; n += blockDim.x) {
         float g = 1.f;
         for (int i = 0; i < n; ++i) g *= p.mu;
         spow[n] = g;
@@ -435,13 +437,13 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
         int nvr[2];                                                  // (at least 64 threads: at most two chunks of the tile per thread)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int i = d + k * (int)blockDim.x;
+            const int i = tl + k * (int)blockDim.x;
             nvr[k] = i < CARRY_TILE && c0 + i < p.n_chunks ? nvp[c0 + i] : 0;
         }
         __syncthreads();                                             // spow written; the previous tile's sg consumed
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int i = d + k * (int)blockDim.x, n = nvr[k];
+            const int i = tl + k * (int)blockDim.x, n = nvr[k];
             if (i >= CARRY_TILE) break;
             sg[i] = spow[n];
             // the chunk that holds the array's last frame whose energy advanced (= its last frame without the gate): that frame is
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
     }
     if (act) p.state_out[(long long)a * p.D + d] = E;                // _prevEnergyInDOA (:143)
     __syncthreads();
-    if (p.mode == 1 && d == 0) p.last_vchunk[a] = s_lv;
+    if (p.mode == 1 && d == 0) p.last_vchunk[a] = s_lv;              // (every slice finds the same chunk; slice 0 writes it)
 }
 
 // selectDOA of one frame by one wave (SteeringBeamforming.cpp:146-195): En = the frame's normalised energies (LDS), lane
