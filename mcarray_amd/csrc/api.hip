@@ -65,7 +65,7 @@ struct mca_hip_ctx {
     bool ula = false, stream_ok = false, generic = false, force_v1 = false;
     bool n512 = false;             // 512-sample frames with <= 8 microphones: k_stft_phat_512 / k_beamform_512 instead of the any-length kernels
     std::string stream_why;       // why the stream API is unavailable for this configuration
-    int v2_min_rows = 16384;       // (a lane of the bench shape: 4 arrays x 4096 frames)
+    int v2_min_rows = 16384;       // one operand plane; twice that with two (plan_gemm)
     float step = 0.f;
     std::vector<float> delays, grid;
     std::vector<int2> pairs;
@@ -278,7 +278,9 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
     // a call that is worked off in pieces (the chunks of the host-pointer path) plans every piece as the whole call would
     // be planned: a row's result then does not depend on how the call was cut (same kernel, same K segments, same order)
     if (c->plan_rows > 0) rows = c->plan_rows;
-    g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= c->v2_min_rows && !c->force_v1;
+    // 256 x 384 tiles from 16 384 rows with one operand plane (128 workgroups of k_srp_gemm_f16_v3 beat the 128 x 192 kernel
+    // there: 134 vs 156 us, and leave the scan's chunk results), from 32 768 rows with the hi + lo planes (343 vs 299 us at 16 384)
+    g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= (long long)c->v2_min_rows * (c->a_planes == 2 ? 2 : 1) && !c->force_v1;
     if (g.v2) {
         g.ksplit = rows >= 65536 ? 1 : 2;   // 256 x 384 tiles need >= ~256 workgroups to fill the chip
     } else {
