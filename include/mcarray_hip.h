@@ -145,6 +145,16 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long lon
                                 long long mic_stride, int n_arrays, int n_frames,
                                 const float *doa_rad_dev, float *out_pcm_dev, void *stream);
 
+/* The same with the grid bins behind the angles: doa_bin_dev[a][t][s] as written by
+ * mca_hip_localise_frames_dev (-1 = no frame has fired yet, the initial _currentDOA = 0,
+ * BeamformingSeparationAndLocalisation.cpp:51), doa_rad_dev = the grid angles of those bins.  With
+ * one source on the 1024-sample path the steering phasors then come from a per-angle table built
+ * once per context (no sincos per frame); other configurations run as mca_hip_separate_frames_dev. */
+int mca_hip_separate_frames_bins_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,
+                                     long long mic_stride, int n_arrays, int n_frames,
+                                     const int *doa_bin_dev, const float *doa_rad_dev,
+                                     float *out_pcm_dev, void *stream);
+
 /* Both of the above in sequence = SourceSeparationAndLocalisation::processParametrisation
  * (SourceSeparationAndLocalisation.cpp:79-94) for every frame. */
 int mca_hip_process_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,

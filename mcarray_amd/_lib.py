@@ -96,6 +96,8 @@ SYMBOLS = [
       C.c_void_p, C.c_void_p]),
     ("mca_hip_separate_frames_dev", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mca_hip_separate_frames_bins_dev", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mca_hip_process_frames_dev", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
       C.c_void_p, C.c_void_p, C.c_void_p]),

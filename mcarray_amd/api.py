@@ -168,8 +168,9 @@ class Context:
 
     # ---- stream API, device tensors (torch used for memory only) ----
     def process_frames_dev(self, pcm, n_frames, doa_bin, doa_rad, prob, energy=None, out_pcm=None, stream=None,
-                           localise=True, separate=True):
-        """pcm: torch float32 cuda tensor [A][M][>= (F+1)*hop]; outputs preallocated cuda tensors."""
+                           localise=True, separate=True, bins_are_grid=False):
+        """pcm: torch float32 cuda tensor [A][M][>= (F+1)*hop]; outputs preallocated cuda tensors.
+        bins_are_grid (separation only): doa_rad holds the grid angles of doa_bin (the localiser's own picks)."""
         A, M, L = pcm.shape
         if M != self.M:
             raise MCArrayHipError("pcm has %d channels, context has %d microphones" % (M, self.M))
@@ -184,8 +185,12 @@ class Context:
             self._check(self._lib.mca_hip_localise_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_bin),
                                                               ptr(doa_rad), ptr(prob), ptr(energy), stream))
         if separate and out_pcm is not None:
-            self._check(self._lib.mca_hip_separate_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_rad),
-                                                              ptr(out_pcm), stream))
+            if bins_are_grid and doa_bin is not None:
+                self._check(self._lib.mca_hip_separate_frames_bins_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_bin), ptr(doa_rad),
+                                                                       ptr(out_pcm), stream))
+            else:
+                self._check(self._lib.mca_hip_separate_frames_dev(self.h, ptr(pcm), M * L, L, A, n_frames, ptr(doa_rad),
+                                                                  ptr(out_pcm), stream))
 
     # ---- real-time mode: the stream call as a HIP graph ----
     def graph_create(self, pcm, n_frames, doa_bin, doa_rad, prob, energy=None, out_pcm=None):

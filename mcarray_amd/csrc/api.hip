@@ -4,7 +4,7 @@
 // per-context state and workspace, and enqueues the kernels.  No compute happens on the host
 // and there is no CPU fallback: without a gfx950 device mca_hip_create fails.
 #include "../../include/mcarray_hip.h"
-#include "fft512.h"
+#include "fft1024c.h"
 #include "kernels.h"
 #include "stage.h"
 
@@ -75,6 +75,7 @@ struct mca_hip_ctx {
     double *d_micx = nullptr;
     int2 *d_pairs = nullptr;
     void *d_B = nullptr, *d_Bt = nullptr;
+    float2 *d_bftab = nullptr; int bf_pairs = 0;   // k_beamform_wave: steering rows per grid angle, [D + 1][bf_pairs][1024] (built on first use)
     // stream state (double buffered: kernels read [cur], write [cur^1])
     float *d_E[2] = {nullptr, nullptr};
     float *d_tail[2] = {nullptr, nullptr};
@@ -159,7 +160,7 @@ void free_ctx(mca_hip_ctx *c)
 {
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt);
+    F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt); F(c->d_bftab);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
     F(c->d_rstats); F(c->d_gate_state);
@@ -1096,10 +1097,63 @@ int mca_hip_get_repair_stats(mca_hip_ctx *c, unsigned long long *frames, unsigne
     return MCA_HIP_OK;
 }
 
+// the wave-per-run beamformer (k_beamform_wave) serves one source on the 1024-sample path when the caller's DOAs are grid
+// bins (the localiser's own picks); everything else stays on k_beamform_ola / _512 / _gen
+static bool wave_beamformer_applies(const mca_hip_ctx *c)
+{
+    const bool off = std::getenv("MCA_HIP_BF_OLA") != nullptr;      // A/B switch for measurements
+    return !off && !c->generic && !c->n512 && c->S == 1 && c->M >= 2 && c->M <= MCA_MAX_MICS;
+}
+
+// steering rows of every grid angle (+ the initial DOA): allocated and built once, outside any capture
+static int ensure_bf_table(mca_hip_ctx *c)
+{
+    if (c->d_bftab || !wave_beamformer_applies(c)) return MCA_HIP_OK;
+    const int np = (c->M + 1) / 2;
+    HIP_TRY(c, hipMalloc((void **)&c->d_bftab, (size_t)(c->D + 1) * np * 1024 * sizeof(float2)));
+    c->bf_pairs = np;
+    const double unit = (double)c->cfg.sample_rate / (double)FFT_N / 346.1;     // Beamformer.cpp:59 without 2 pi
+    hipLaunchKernelGGL(k_bf_table, dim3(c->D + 1, np), dim3(256), 0, nullptr, c->d_bftab, c->d_grid, c->d_micx, c->M, np, unit);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    return MCA_HIP_OK;
+}
+
 static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
-                         int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, hipStream_t st)
+                         int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, hipStream_t st, const int *doa_bin = nullptr)
 {
     const size_t a0 = (size_t)c->a0;
+    if (doa_bin && c->d_bftab && wave_beamformer_applies(c)) {
+        BeamformWaveArgs wa{};
+        wa.pcm = pcm; wa.array_stride = array_stride; wa.mic_stride = mic_stride;
+        wa.M = c->M; wa.n_pairs = c->bf_pairs; wa.n_frames = n_frames;
+        // frames per run (one wave each; every run re-analyses one extra frame for its overlap-add carry): long runs are
+        // cheaper per frame, short ones fill the chip -- two waves per SIMD want 2048 runs
+        const int ft_env = std::getenv("MCA_HIP_BFW_FT") ? std::atoi(std::getenv("MCA_HIP_BFW_FT")) : 0;
+        wa.ft = ft_env > 0 ? ft_env : 16;
+        while (!ft_env && wa.ft > 2 && (long long)n_arrays * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
+        wa.window = c->d_window; wa.doa_bin = doa_bin; wa.table = c->d_bftab; wa.out = out_pcm;
+        wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->H;
+        const int runs = (n_frames + wa.ft - 1) / wa.ft;
+        const size_t smem = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2);
+        time_begin(c, MCA_HIP_K_BEAMFORM, st);
+        const int var = std::getenv("MCA_HIP_BFW_VAR") ? std::atoi(std::getenv("MCA_HIP_BFW_VAR")) & 15 : 12;
+#define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa); \
+                            else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa); break;
+        const int abl = std::getenv("MCA_HIP_BFW_ABL") ? std::atoi(std::getenv("MCA_HIP_BFW_ABL")) & 3 : 0;     // measurement only: wrong results
+        if (abl == 1) hipLaunchKernelGGL((k_beamform_wave<false, 14, 1>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa);
+        else if (abl == 2) hipLaunchKernelGGL((k_beamform_wave<false, 14, 2>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa);
+        else if (abl == 3) hipLaunchKernelGGL((k_beamform_wave<false, 14, 3>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa);
+        else
+        switch (var) {
+            BFW_CASE(0) BFW_CASE(1) BFW_CASE(2) BFW_CASE(3) BFW_CASE(4) BFW_CASE(5) BFW_CASE(6) BFW_CASE(7)
+            BFW_CASE(8) BFW_CASE(9) BFW_CASE(10) BFW_CASE(11) BFW_CASE(12) BFW_CASE(13) BFW_CASE(14) BFW_CASE(15)
+        }
+#undef BFW_CASE
+        time_end(c, st);
+        HIP_TRY(c, hipGetLastError());
+        return MCA_HIP_OK;
+    }
     BeamformArgs ba{};
     ba.pcm = pcm; ba.array_stride = array_stride; ba.mic_stride = mic_stride;
     ba.M = c->M; ba.Mpad = c->M; ba.S = c->S; ba.n_frames = n_frames; ba.fs = c->cfg.sample_rate;
@@ -1197,19 +1251,37 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     return MCA_HIP_OK;
 }
 
-int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
-                                int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, void *stream)
+// doa_bin: the grid bins behind doa_rad when they are the localiser's own picks (NULL: arbitrary angles)
+static int separate_frames_dev_bins(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                    int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, void *stream, const int *doa_bin)
 {
     int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
     if (rc) return rc;
     if (!doa_rad || !out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
     const size_t fs_ = (size_t)n_frames * c->S, fo_ = (size_t)c->S * n_frames * c->H;
     rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
-        return separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st);
+        return separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st,
+                             doa_bin ? doa_bin + a0 * fs_ : nullptr);
     });
     if (rc) return rc;
     c->tail_cur ^= 1;
     return MCA_HIP_OK;
+}
+
+int mca_hip_separate_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, void *stream)
+{
+    return separate_frames_dev_bins(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, stream, nullptr);
+}
+
+int mca_hip_separate_frames_bins_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
+                                     int n_arrays, int n_frames, const int *doa_bin, const float *doa_rad, float *out_pcm, void *stream)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
+    int rc = ensure_bf_table(c);
+    if (rc) return rc;
+    return separate_frames_dev_bins(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, stream, doa_bin);
 }
 
 int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
@@ -1222,11 +1294,13 @@ int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array
     if (rc) return rc;
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
     if (!out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
+    if ((rc = ensure_bf_table(c))) return rc;
     const size_t fs_ = (size_t)n_frames * c->S, fd_ = (size_t)n_frames * c->D, fo_ = (size_t)c->S * n_frames * c->H;
     rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
         int r = localise_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_bin + a0 * fs_, doa_rad + a0 * fs_,
                               prob ? prob + a0 * fs_ : nullptr, energy ? energy + a0 * fd_ : nullptr, st);
-        if (!r) r = separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st);
+        if (!r) r = separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st,
+                                  doa_bin + a0 * fs_);
         return r;
     });
     if (rc) return rc;
@@ -1272,6 +1346,7 @@ int mca_hip_graph_create(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (out_pcm && !doa_rad) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev is NULL (the separation stage steers with it)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if ((rc = reserve_impl(c, n_arrays, n_frames, true))) return rc;   // recording must not allocate (a recording runs as one lane)
+    if (out_pcm && (rc = ensure_bf_table(c))) return rc;
     mca_hip_graph *g = new mca_hip_graph();
     g->c = c; g->pcm = pcm; g->array_stride = array_stride; g->mic_stride = mic_stride; g->n_arrays = n_arrays; g->n_frames = n_frames;
     g->doa_bin = doa_bin; g->doa_rad = doa_rad; g->prob = prob; g->energy = energy; g->out_pcm = out_pcm;
@@ -1292,7 +1367,7 @@ static int graph_record(mca_hip_graph *g, int idx)
     int rc = mca_hip_localise_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_bin, g->doa_rad,
                                          g->prob, g->energy, g->cap);
     if (!rc && g->out_pcm)
-        rc = mca_hip_separate_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_rad, g->out_pcm, g->cap);
+        rc = separate_frames_dev_bins(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_rad, g->out_pcm, g->cap, g->doa_bin);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(g->cap, &graph);
     c->timing = timing;
@@ -1391,6 +1466,7 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
     if (!d_pcm || !d_bin || !d_rad || !d_prob || (energy && !d_en) || (out_pcm && !d_out) || (I16 && !d_i16))
         return fail(c, MCA_HIP_ERR_OUT_OF_MEMORY, "device staging buffers for the host-pointer call");
     int rc = check_stream_args(c, d_pcm, as, ms, n_arrays, n_frames);
+    if (!rc && out_pcm) rc = ensure_bf_table(c);
     if (rc) return rc;
 
     if (!is_pinned(pcm)) {
@@ -1402,7 +1478,7 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
             HIP_TRY(c, hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
         }
         rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
-        if (!rc && out_pcm) rc = mca_hip_separate_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr);
+        if (!rc && out_pcm) rc = separate_frames_dev_bins(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr, d_bin);
         if (rc) return rc;
         HIP_TRY(c, hipDeviceSynchronize());
         HIP_TRY(c, hipMemcpy(doa_bin, d_bin, n_fs * 4, hipMemcpyDeviceToHost));
@@ -1443,7 +1519,7 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
         c->cur_lane = 0; c->a0 = a0;                          // the chunk's arrays on lane 0's workspace, per-array state at its offset
         rc = localise_impl(c, d_pcm + (size_t)a0 * as, as, ms, na, n_frames, d_bin + a0 * fs_, d_rad + a0 * fs_, d_prob + a0 * fs_,
                            energy ? d_en + a0 * fd_ : nullptr, s_run);
-        if (!rc && out_pcm) rc = separate_impl(c, d_pcm + (size_t)a0 * as, as, ms, na, n_frames, d_rad + a0 * fs_, d_out + a0 * fo_, s_run);
+        if (!rc && out_pcm) rc = separate_impl(c, d_pcm + (size_t)a0 * as, as, ms, na, n_frames, d_rad + a0 * fs_, d_out + a0 * fo_, s_run, d_bin + a0 * fs_);
         c->a0 = 0;
         if (rc) break;
         HIP_TRY(c, hipEventRecord(c->io_ev[MAXC + k], s_run));

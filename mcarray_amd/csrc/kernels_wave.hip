@@ -1,0 +1,187 @@
+// kernels_wave.hip -- wave-per-run stream kernels on the 1024-point complex transform of fft1024c.h (gfx950).
+//
+//   k_bf_table        steering table of the delay-and-sum stage for every angle of the DOA grid
+//   k_beamform_wave   PCM -> FFT of channel PAIRS -> delay-and-sum (Beamformer.cpp:51-71) -> inverse FFT -> overlap-add,
+//                     one wave per run of frames, no workgroup barrier inside the frame loop
+//
+// Delay-and-sum without ever separating the two channels of a pair.  With z_p = x_a + j x_b (a = 2p, b = 2p + 1) and
+// Z_p = DFT(z_p) = X_a + j X_b, the beamformed frame y = IDFT(Y), Y[k] = (1/M) sum_c X_c[k] P_c[k] extended to a
+// Hermitian spectrum (P_c[1024 - k] = conj P_c[k]; the imaginary parts of Y[0] and Y[512] are ignored by the reference's
+// CCS inverse, i.e. P_c[512] counts with its real part), equals
+//     y = Re IDFT(W),   W[k] = sum_p Z_p[k] T_p[k],   T_p[k] = (P_a[k] - j P_b[k]) / (M N),   k = 0..1023
+// because Y = W' + conj-mirror(W') for W' = W N / 2.  T depends on the steering angle only: one 8 KB row per (angle, pair),
+// built once per context (k_bf_table) and read through L2 -- the kernel computes no sincos and keeps no phasor state.
+#include "fft1024c.h"
+#include "mca_internal.h"
+
+namespace mca {
+
+// grid (D + 1, pairs) x 256.  Row 0: DOA = 0 rad, the module's initial _currentDOA
+// (BeamformingSeparationAndLocalisation.cpp:51) that frames before the first pick are steered with; row 1 + d: grid[d].
+__global__ __launch_bounds__(256) void k_bf_table(float2 *tab, const float *grid, const double *mic_x, int M, int n_pairs, double unit)
+{
+    const int d = blockIdx.x, pr = blockIdx.y;
+    const double doa = d == 0 ? 0.0 : (double)grid[d - 1];
+    const double cd = cos(doa + 1.57079632679489661923);                   // cos(DOA + M_PI/2), Beamformer.cpp:59
+    const double sc = 1.0 / ((double)M * 1024.0);
+    float2 *row = tab + ((long long)d * n_pairs + pr) * 1024;
+    for (int k = threadIdx.x; k < 1024; k += 256) {
+        const int kap = k <= 512 ? k : k - 1024;
+        double pa[2] = {0.0, 0.0}, pb[2] = {0.0, 0.0};
+        for (int e = 0; e < 2; ++e) {
+            const int c = 2 * pr + e;
+            if (c >= M) continue;
+            double turns = (double)kap * (unit * mic_x[c] * cd);            // k s_c / (2 pi), s_c of Beamformer.cpp:59
+            turns -= rint(turns);
+            double sn, cs;
+            sincospi(2.0 * turns, &sn, &cs);
+            if (k == 512) sn = 0.0;                                          // Im Y[512] is dropped by the CCS inverse
+            (e == 0 ? pa : pb)[0] = cs; (e == 0 ? pa : pb)[1] = sn;
+        }
+        row[k] = make_float2((float)((pa[0] + pb[1]) * sc), (float)((pa[1] - pb[0]) * sc));     // (P_a - j P_b) / (M N)
+    }
+}
+
+// (x_a, x_b) * w for two consecutive points whose window samples share a register pair: op_sel broadcasts the low / high half
+__device__ __forceinline__ float2 win_lo(float a, float b, v2f w)
+{
+    v2f x = {a, b}, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(w));
+    return from_v2f(r);
+}
+__device__ __forceinline__ float2 win_hi(float a, float b, v2f w)
+{
+    v2f x = {a, b}, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(w));
+    return from_v2f(r);
+}
+
+// grid (ceil(runs / 4), arrays) x 256 threads = 4 waves, one run of p.ft frames each.  Every run also analyses the frame
+// before its first one (its second half is the overlap-add carry).  Per frame: for each channel pair the windowed samples
+// (z = (x_a, x_b) w), the 1024-point transform, W += Z T[doa bin]; then the inverse transform of W, whose real part is the
+// beamformed frame.  The run is ONE loop over its (frame, pair) steps with the same loads in every step -- the next step's
+// samples (the last step reloads its own) and this step's table row -- so that the counted waits on the row leave the
+// sample loads in flight behind the transform.  ODD: the last pair has one channel (its imaginary input is zero).
+#ifndef BFW_OCC
+#define BFW_OCC 2
+#endif
+template <bool ODD, int VAR, int ABL>
+__global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs p)
+{
+    constexpr bool PF = VAR & 1, TMID = VAR & 4;
+    constexpr int FOPT = ((VAR >> 1) & 1) | ((VAR >> 3) & 1) << 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *tab = reinterpret_cast<float2 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
+    f1k_table_init(tab, tid, 256);
+    F1kLane lc;
+    lc.init(lane);
+    __syncthreads();
+
+    const int a = blockIdx.y, run = blockIdx.x * 4 + wave;
+    const int t0 = run * p.ft;
+    if (t0 >= p.n_frames) return;
+    const int t1 = min(t0 + p.ft, p.n_frames);
+    const int tfirst = t0 > 0 ? t0 - 1 : 0;
+    const int NP = p.n_pairs;
+
+    v2f win[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { win[i].x = p.window[lane + 128 * i]; win[i].y = p.window[lane + 128 * i + 64]; }
+    float carry[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) carry[i] = t0 == 0 ? p.tail_in[(long long)a * FFT_H + lane + 64 * i] : 0.f;
+
+    const float *base = p.pcm + (long long)a * p.array_stride + lane;
+    const int *bins = p.doa_bin + (long long)a * p.n_frames;
+    float xa[16], xb[16];
+    auto load_pair = [&](int t, int pr) {
+        const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)t * FFT_H;
+        const float *pb = (ODD && pr == NP - 1) ? pa : pa + p.mic_stride;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
+    };
+    float pf = 0.f;
+    if (PF) {   // the run's first frames are nowhere yet: touch all of them at once (64-byte pieces, 16 per load and channel quarter)
+        const long long span = (long long)min(4, t1 + 1 - tfirst) * FFT_H;     // samples per channel: frames tfirst .. tfirst + 2
+        for (int c = 0; c < p.M; ++c)
+            for (long long o = lane * 16; o < span; o += 64 * 16) pf += base[(long long)c * p.mic_stride + (long long)tfirst * FFT_H - lane + o];
+    }
+    load_pair(tfirst, 0);
+
+    float2 W[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
+    int t = tfirst, pr = 0;
+    const float2 *trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
+    for (;;) {
+        float2 z[16], T[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
+        if (ODD && pr == NP - 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i].y = 0.f;
+        }
+        const bool last_pair = pr == NP - 1, last = last_pair && t + 1 >= t1;
+        if (!TMID) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[i] = trow[pr * 1024 + 64 * dr16(i)];
+            if (FOPT & 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const int tn = last ? t : (last_pair ? t + 1 : t), pn = last ? pr : (last_pair ? 0 : pr + 1);
+            if (!(ABL & 1)) load_pair(tn, pn);
+            // one load that touches every 64-byte piece of this pair's new half frame two frames ahead pulls it into L2
+            // (lane -> channel lane >> 5, piece lane & 31), so that the sample loads of the next frames find it there
+            if (PF) {
+                const int tp = min(t + 2, p.n_frames - 1);
+                pf = *(base - lane + (long long)(2 * pr + ((lane >> 5) && !(ODD && last_pair))) * p.mic_stride + (long long)(tp + 1) * FFT_H + (lane & 31) * 16);
+            }
+        }
+        if (FOPT & 2) __builtin_amdgcn_sched_barrier(0);
+        // TMID: the steering row is requested in the middle of the transform (fewest live registers) and used right behind it
+        fft1024c<false, FOPT>(z, buf, lane, tab, lc, [&]() {
+            if (TMID) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) T[i] = (ABL & 2) ? make_float2(1e-3f * (float)(i + pr), 1e-3f) : trow[pr * 1024 + 64 * dr16(i)];
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < 16; ++i) W[i] = cmac(W[i], z[i], T[i]);
+        if (last_pair) {
+            // W[p] holds bin lane + 64 dr16(p); the inverse takes register i = bin lane + 64 i and returns sample lane + 64 dr16(p)
+            float2 y[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] = W[dr16(i)];
+            fft1024c<true, FOPT>(y, buf, lane, tab, lc);
+            if (t >= t0) {
+                float *o = p.out + (long long)a * p.n_frames * FFT_H + (long long)t * FFT_H + lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[64 * i] = carry[i] + y[dr16(i)].x;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) carry[i] = y[dr16(i + 8)].x;
+            if (last) break;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
+            ++t; pr = 0;
+            trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
+        } else {
+            ++pr;
+        }
+    }
+    if (t1 == p.n_frames) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.tail_out[(long long)a * FFT_H + lane + 64 * i] = carry[i];
+    }
+    if (pf == 1.2345e-38f) p.tail_out[0] = pf;     // (keeps the touching loads alive)
+}
+
+#define INST_BFW(V) template __global__ void k_beamform_wave<false, V, 0>(BeamformWaveArgs); template __global__ void k_beamform_wave<true, V, 0>(BeamformWaveArgs);
+template __global__ void k_beamform_wave<false, 14, 1>(BeamformWaveArgs); template __global__ void k_beamform_wave<false, 14, 2>(BeamformWaveArgs);
+template __global__ void k_beamform_wave<false, 14, 3>(BeamformWaveArgs);
+INST_BFW(0) INST_BFW(1) INST_BFW(2) INST_BFW(3) INST_BFW(4) INST_BFW(5) INST_BFW(6) INST_BFW(7)
+INST_BFW(8) INST_BFW(9) INST_BFW(10) INST_BFW(11) INST_BFW(12) INST_BFW(13) INST_BFW(14) INST_BFW(15)
+
+}  // namespace mca

@@ -172,6 +172,19 @@ struct BeamformArgs {
     const float2 *tw;        // [N/2] exp(-j 2 pi i / N)
 };
 
+// wave-per-run delay-and-sum on the 1024-point complex transform (kernels_wave.hip): one source, any M <= 16
+struct BeamformWaveArgs {
+    const float *pcm;
+    long long array_stride, mic_stride;
+    int M, n_pairs, n_frames, ft;
+    const float *window;     // [1024] periodic Hann
+    const int *doa_bin;      // [arrays][n_frames] grid index of the frame's DOA, -1: the initial _currentDOA = 0
+    const float2 *table;     // [D + 1][n_pairs][1024] (P_a - j P_b) / (M N) per steering angle (k_bf_table)
+    float *out;              // [arrays][n_frames*hop]
+    const float *tail_in;    // [arrays][hop] overlap-add carry at entry
+    float *tail_out;         // at exit
+};
+
 struct Gcc2ScanArgs {
     const float *C;          // [c_planes][arrays][n_frames][Dp] un-smoothed GCC-PHAT R_t[d] (split-K partial maps, summed here)
     int c_planes; long long c_plane_stride;
