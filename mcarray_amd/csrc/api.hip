@@ -482,6 +482,36 @@ template <typename OutT>
 int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, hipStream_t st)
 {
     const int M = c->M; const bool ula = c->ula;
+    // 4 or 8 microphones: one wave per run of frames on the 1024-point transform of channel pairs (k_stft_phat_wave)
+    if ((M == 8 || M == 4) && std::getenv("MCA_HIP_STFT_WG") == nullptr) {
+        StftPhatArgs w = a;
+        dim3 gw;
+        if (a.list) { w.fpb = 1; gw = dim3(grid.x, 1); }      // a listed group of REPAIR_GROUP = 4 frames per workgroup, a frame per wave
+        else {
+            const int env = std::getenv("MCA_HIP_SPW_FPW") ? std::atoi(std::getenv("MCA_HIP_SPW_FPW")) : 0;
+            w.fpb = env > 0 ? env : 16;       // frames per wave: two waves per SIMD want 2048 runs
+            while (!env && w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
+            gw = dim3(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
+        }
+        const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 4 * w.fpb * (M / 2)) * sizeof(float2);
+        const bool pl2 = a.a_planes == 2, pw = a.power != nullptr;
+#define LAUNCH_W2(MT, U, PL2)                                                                                  \
+        do {                                                                                                     \
+            if (pw) hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, true>), gw, dim3(256), smw, st, w);   \
+            else hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, false>), gw, dim3(256), smw, st, w);     \
+        } while (0)
+#define LAUNCH_W(MT, U)                                                                                          \
+        do {                                                                                                     \
+            if constexpr (sizeof(OutT) == 2) { if (pl2) LAUNCH_W2(MT, U, true); else LAUNCH_W2(MT, U, false); }  \
+            else LAUNCH_W2(MT, U, false);                                                                        \
+        } while (0)
+        if (M == 8 && ula) LAUNCH_W(8, true); else if (M == 8) LAUNCH_W(8, false);
+        else if (ula) LAUNCH_W(4, true); else LAUNCH_W(4, false);
+#undef LAUNCH_W2
+#undef LAUNCH_W
+        HIP_TRY(c, hipGetLastError());
+        return MCA_HIP_OK;
+    }
 #define LAUNCH(MT, U)                                                                                        \
     do {                                                                                                     \
         if (smem > 64 * 1024)                                                                                \

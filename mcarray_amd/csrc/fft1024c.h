@@ -160,8 +160,10 @@ struct F1kLane {
 // mid(): called right behind the exchange's stores -- the place where the fewest registers are live; the callers issue
 // global loads there.
 template <bool INV, int OPT = 3, typename Mid = F1kNoMid>
-__device__ __forceinline__ void fft1024c(float2 (&v)[16], float2 *buf, int lane, const float2 *tab, const F1kLane &lc, Mid mid = Mid())
+__device__ __forceinline__ void fft1024c(float2 (&v)[16], float2 *buf, int lane, const float2 *tab, const F1kLane &lc, Mid mid = Mid(), int row = -1)
 {
+    // row: the residue k mod 64 this lane receives (default: its own number); any permutation of the lanes reads conflict
+    // free as long as every ds_read_b128 lane group sees 16 different rows mod 16
     constexpr bool SCHED = OPT & 2;
     // the stage's twiddles are read ahead of its butterflies
     float2 tw[16];
@@ -187,7 +189,7 @@ __device__ __forceinline__ void fft1024c(float2 (&v)[16], float2 *buf, int lane,
     wave_lds_fence();
     mid();
     if (SCHED) __builtin_amdgcn_sched_barrier(0);
-    lds_read16_b128(v, buf + lane * F1K_ROW);
+    lds_read16_b128(v, buf + (row < 0 ? lane : row) * F1K_ROW);
     wave_lds_fence();
     fft16<INV>(v);
 }

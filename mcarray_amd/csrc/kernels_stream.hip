@@ -10,6 +10,7 @@
 // correlation map C [split-K plane][array][frame][Dp] fp32.
 #include "fft512.h"
 #include "mca_internal.h"
+#include "phat_pairs.h"
 
 namespace mca {
 
@@ -28,53 +29,6 @@ namespace mca {
 // operands re-read from LDS.  ULA: pairs with equal (j - i) share one delay table
 // (host-verified, bitwise-equal float delays), so their PHAT spectra are summed: G = M - 1
 // groups instead of P = M(M-1)/2 -- the contraction depth of the SRP GEMM drops by M/2.
-__device__ __forceinline__ float2 whiten(float2 z)
-{
-    const float pw = z.x * z.x + z.y * z.y;
-    const float s = pw > 1e-30f ? rsqrtf(pw) : 0.f;
-    return make_float2(z.x * s, z.y * s);
-}
-
-// pair products of one bin.  x: whitened spectra of the bin, element m at x[m * xstride].
-template <int MT, bool ULA, bool WHITEN, typename OutT>
-__device__ __forceinline__ void pair_stage(const float2 *x, int xstride, int M, OutT *arow, const StftPhatArgs &p, int k, int kg = KG)
-{
-    if constexpr (MT > 0) {
-        float2 r[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) r[m] = WHITEN ? whiten(x[m * xstride]) : x[m * xstride];
-        if constexpr (ULA) {
-            float2 acc[MT - 1];
-#pragma unroll
-            for (int g = 0; g < MT - 1; ++g) acc[g] = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = i + 1; j < MT; ++j) acc[j - i - 1] = cmacc(acc[j - i - 1], r[i], r[j]);
-#pragma unroll
-            for (int g = 0; g < MT - 1; ++g) store_a(arow, p, g * kg + k, acc[g]);
-        } else {
-            int pi = 0;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = i + 1; j < MT; ++j) { store_a(arow, p, pi * kg + k, cmulc(r[i], r[j])); ++pi; }
-        }
-    } else {
-        if (ULA) {
-            for (int g = 0; g < M - 1; ++g) {
-                float2 acc = make_float2(0.f, 0.f);
-                for (int i = 0; i + g + 1 < M; ++i) acc = cmacc(acc, x[i * xstride], x[(i + g + 1) * xstride]);
-                store_a(arow, p, g * kg + k, acc);
-            }
-        } else {
-            int pi = 0;
-            for (int i = 0; i < M; ++i)
-                for (int j = i + 1; j < M; ++j) { store_a(arow, p, pi * kg + k, cmulc(x[i * xstride], x[j * xstride])); ++pi; }
-        }
-    }
-}
-
 // the per-wave partial sums of a frame's power, in wave order
 __device__ __forceinline__ float sum8(const float *s) { return ((((((s[0] + s[1]) + s[2]) + s[3]) + s[4]) + s[5]) + s[6]) + s[7]; }
 

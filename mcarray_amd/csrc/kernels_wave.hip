@@ -13,6 +13,7 @@
 // built once per context (k_bf_table) and read through L2 -- the kernel computes no sincos and keeps no phasor state.
 #include "fft1024c.h"
 #include "mca_internal.h"
+#include "phat_pairs.h"
 
 namespace mca {
 
@@ -183,5 +184,195 @@ template __global__ void k_beamform_wave<false, 14, 1>(BeamformWaveArgs); templa
 template __global__ void k_beamform_wave<false, 14, 3>(BeamformWaveArgs);
 INST_BFW(0) INST_BFW(1) INST_BFW(2) INST_BFW(3) INST_BFW(4) INST_BFW(5) INST_BFW(6) INST_BFW(7)
 INST_BFW(8) INST_BFW(9) INST_BFW(10) INST_BFW(11) INST_BFW(12) INST_BFW(13) INST_BFW(14) INST_BFW(15)
+
+// --------------------------------------------------------------------------------------
+// k_stft_phat_wave: STFT analysis + GCC-PHAT pair products (SteeringBeamforming.cpp:104-130 up to the steering sum), one
+// wave per run of frames, everything between the PCM loads and the A-row stores in registers.
+// --------------------------------------------------------------------------------------
+// Per frame the wave transforms the MT / 2 channel pairs (z = x_a + j x_b).  Lane l of the result holds the bins
+// lam + 64 s, lam = l for l <= 32 and 96 - l above: the mirror bin 1024 - k of a lane's bin k then lives in lane l ^ 32,
+// register 15 - s, and ONE v_permlane32_swap per dword brings the partner's upper half over (pairs of registers swap into
+// each other's places; a v_swap puts them back).  Lanes 0 and 32 are their own mirrors (lam = 0: register (16 - s) & 15,
+// lam = 32: register 15 - s) and sit the exchange out.  Then per bin k < 512
+//     2 X_a = Z[k] + conj Z[1024 - k],   2 X_b = -j (Z[k] - conj Z[1024 - k])
+// are whitened (the factor 2 drops out) and kept: 8 bins x MT channels per lane.  After the last pair the lane forms the
+// pair products of its 8 bins (pair_stage of kernels_stream.hip) and stores them.  The Nyquist bins (lane 0, register 8:
+// X_a = Re Z, X_b = Im Z) are parked in LDS and finished after the run, lane = frame.
+// z = 2 X: |X|^2 > 1e-30 <=> |z|^2 > 4e-30.  alive: the channel has a non-zero sample in this frame (a channel of exact
+// zeros must give X = 0 like the reference's own transform; riding on its partner's transform it would come out as the
+// partner's rounding noise, which the whitening would blow up to unit modulus).
+__device__ __forceinline__ float2 whiten4(float2 z, float &pw, bool alive = true)
+{
+    v2f zv = to_v2f(z), sq, r;
+    asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(zv));
+    pw = sq.x + sq.y;
+    const float s = (pw > 4e-30f && alive) ? rsqrtf(pw) : 0.f;
+    v2f sv = {s, s};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(zv), "v"(sv));
+    return from_v2f(r);
+}
+
+// A-row stores: a wave-uniform row pointer, a per-lane byte offset (the lane's residue) and a compile-time element index
+template <bool PL2>
+__device__ __forceinline__ void store_a_wave(_Float16 *row, unsigned voff, int cidx, float2 v, int Kp)
+{
+    const float2_t vv = {v.x, v.y};
+    const half2_t hi = __builtin_convertvector(vv, half2_t);
+    char *b = reinterpret_cast<char *>(row + 2 * cidx);
+    *reinterpret_cast<half2_t *>(b + voff) = hi;
+    if (PL2) {
+        const float2_t back = __builtin_convertvector(hi, float2_t);
+        *reinterpret_cast<half2_t *>(reinterpret_cast<char *>(row + Kp + 2 * cidx) + voff) = __builtin_convertvector(vv - back, half2_t);
+    }
+}
+template <bool PL2>
+__device__ __forceinline__ void store_a_wave(float *row, unsigned voff, int cidx, float2 v, int)
+{
+    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row + 2 * cidx) + 2 * voff) = v;
+}
+
+template <int MT, bool ULA, typename OutT, bool PL2, bool POWER>
+__global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
+{
+    constexpr int NP = MT / 2, NOUT = PairOut<MT, ULA>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *tab = reinterpret_cast<float2 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
+    float2 *nyq = tab + F1K_TWORDS + 4 * F1K_SCRATCH + wave * (p.fpb * NP);      // [fpb][NP] Z_p[512] of the run's frames
+    f1k_table_init(tab, tid, 256);
+    F1kLane lc;
+    lc.init(lane);
+    __syncthreads();
+    const int lam = lane <= 32 ? lane : 96 - lane;
+    const unsigned voff = (unsigned)lam * 4u;                                      // byte offset of the lane's residue in an fp16 row
+    const bool self = (lane & 31) == 0;                                            // lanes 0 and 32
+    v2f win[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { win[i].x = p.window[lane + 128 * i]; win[i].y = p.window[lane + 128 * i + 64]; }
+
+    // regular mode: wave w of workgroup b takes the run of p.fpb frames number 4 b + w.  List mode (repair pass of the adaptive
+    // SRP precision): workgroup b walks the listed groups of REPAIR_GROUP = 4 frames, wave w takes frame w of a group.
+    const int li_end = p.list ? min(*p.n_list, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
+    for (int li = p.list ? p.list0 + (int)blockIdx.x : 0; li < li_end; li += li_step) {
+        int a = blockIdx.y;
+        int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+        long long row_base = (long long)a * p.n_frames;     // A row of frame f = row_base + f
+        if (p.list) {
+            const int e = p.list[li];
+            a = e / p.groups_per_array;
+            const int g_begin = (e - a * p.groups_per_array) * REPAIR_GROUP;
+            row_base = (long long)(li - p.list0) * REPAIR_GROUP - g_begin;
+            f_begin = g_begin + wave; f_end = min(f_begin + 1, p.n_frames);
+        }
+        if (f_begin >= f_end) continue;
+        const float *base = p.pcm + (long long)a * p.array_stride + lane;
+        float xa[16], xb[16];
+        auto load_pair = [&](int f, int pr) {
+            const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)(p.frame0 + f) * FFT_H;
+            const float *pb = pa + p.mic_stride;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
+        };
+        load_pair(f_begin, 0);
+        for (int f = f_begin; f < f_end; ++f) {
+            float2 Xh[MT][8];
+            float pall = 0.f, pdc = 0.f, pny = 0.f;
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                float2 z[16];
+                // a channel of exact zeros? (any set bit below the sign)
+                unsigned oa = 0, ob = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    oa |= __float_as_uint(xa[i]) | __float_as_uint(xa[i + 1]);
+                    ob |= __float_as_uint(xb[i]) | __float_as_uint(xb[i + 1]);
+                }
+                const bool alive_a = __any((oa << 1) != 0), alive_b = __any((ob << 1) != 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
+                // the next pair's samples (the run's last step reloads its own) are requested in the middle of the transform
+                fft1024c<false, 3>(z, buf, lane, tab, lc, [&]() {
+                    const bool lastp = pr == NP - 1, last = lastp && f + 1 >= f_end;
+                    load_pair(last ? f : (lastp ? f + 1 : f), last ? pr : (lastp ? 0 : pr + 1));
+                }, lam);
+                // z[q] = Z[lam + 64 dr16(q)];  the register of bin index s is dr16(s)
+                if (lane == 0) {
+                    const float2 n = z[dr16(8)];
+                    nyq[(f - f_begin) * NP + pr] = make_float2(alive_a ? n.x : 0.f, alive_b ? n.y : 0.f);
+                    if (POWER) pny += (alive_a ? n.x * n.x : 0.f) + (alive_b ? n.y * n.y : 0.f);          // Nyquist: X_a = Re, X_b = Im
+                    // lane 0 is its own mirror, one register further: slot 15 - s takes register (16 - s) & 15
+                    const float2 z0 = z[dr16(0)];
+#pragma unroll
+                    for (int j = 8; j < 15; ++j) z[dr16(j)] = z[dr16(j + 1)];
+                    z[dr16(15)] = z0;
+                } else if (!self) {
+                    // upper halves (s = 8..15) across the half waves: (s, s + 4) swap into each other's places and back
+#pragma unroll
+                    for (int s = 8; s < 12; ++s) {
+                        float2 &u = z[dr16(s)], &w = z[dr16(s + 4)];
+                        swap_rows32(u.x, w.x); swap_rows32(w.x, u.x);
+                        swap_rows32(u.y, w.y); swap_rows32(w.y, u.y);
+                        const float2 t = u; u = w; w = t;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float2 zk = z[dr16(s)], zm = z[dr16(15 - s)];                                    // Z[k], Z[1024 - k]
+                    const float2 a2 = make_float2(zk.x + zm.x, zk.y - zm.y);                               // 2 X_a
+                    const float2 b2 = make_float2(zk.y + zm.y, zm.x - zk.x);                               // 2 X_b
+                    float pwa, pwb;
+                    Xh[2 * pr][s] = whiten4(a2, pwa, alive_a);
+                    Xh[2 * pr + 1][s] = whiten4(b2, pwb, alive_b);
+                    if (POWER) {
+                        const float pw = (alive_a ? pwa : 0.f) + (alive_b ? pwb : 0.f);
+                        pall += pw;
+                        if (s == 0) pdc += pw;
+                    }
+                }
+            }
+            OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f) * (long long)p.a_row_elems;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float2 r[MT], out[NOUT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) r[m] = Xh[m][s];
+                pair_products<MT, ULA>(r, out);
+#pragma unroll
+                for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, voff, g * KG + 64 * s, out[g], p.Kp);
+            }
+            if (POWER) {
+                // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2 over the channels, / M;
+                // w = 2 except DC and Nyquist; the sums above are over |2 X|^2
+                float pacc = 0.5f * pall - (lane == 0 ? 0.25f * pdc : 0.f) + pny;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) pacc += __shfl_xor(pacc, off);
+                if (lane == 0) p.power[(long long)a * p.total_frames + p.frame0 + f] = pacc / ((float)FFT_N * (float)FFT_N) / (float)MT;
+            }
+        }
+        // Nyquist bins of the run: lane = frame
+        wave_lds_fence();
+        if (lane < f_end - f_begin) {
+            float2 xn[MT], out[NOUT];
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const float2 n = nyq[lane * NP + pr];
+                float pw;
+                xn[2 * pr] = whiten4(make_float2(2.f * n.x, 0.f), pw);
+                xn[2 * pr + 1] = whiten4(make_float2(2.f * n.y, 0.f), pw);
+            }
+            OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f_begin + lane) * (long long)p.a_row_elems;
+            pair_products<MT, ULA>(xn, out);
+#pragma unroll
+            for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, 0u, g * KG + FFT_H, out[g], p.Kp);
+        }
+        wave_lds_fence();
+    }
+}
+
+#define INST_SPW1(MT, ULA, T, PL2) template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, false>(StftPhatArgs); \
+                                   template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, true>(StftPhatArgs);
+#define INST_SPW(MT, ULA) INST_SPW1(MT, ULA, _Float16, false) INST_SPW1(MT, ULA, _Float16, true) INST_SPW1(MT, ULA, float, false)
+INST_SPW(8, true) INST_SPW(8, false) INST_SPW(4, true) INST_SPW(4, false)
 
 }  // namespace mca
