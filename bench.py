@@ -218,6 +218,13 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_frame": per_frame}
     traffic_from_profiles(roof, dom, args.precision, A == 8 and F == 4096)
+    # the whole path against the same roofline: `frac` above is the dominant kernel's own share (its algorithmic bytes over its
+    # own duration); the per-kernel byte definitions double-count the PCM (both FFT kernels read all M channels: 16 384 B each
+    # of the path's 18 440 B per frame), so the kernels' fractions do not add up to the path's
+    roof["path_frac"] = value * BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world)
+    roof["path_achieved"] = value * BYTES_PER_FRAME / 1e9
+    roof["path_note"] = ("end to end: frames/s x %d algorithmic bytes per frame (SURVEY 8d) / (%d GPU x %.0f GB/s); `frac` is the dominant "
+                         "kernel alone -- the two FFT kernels each count the PCM read, so per-kernel fractions are not additive" % (BYTES_PER_FRAME, world, HBM_PEAK_GBPS))
 
     line = None
     if rank == 0:

@@ -55,6 +55,15 @@ typedef enum {
                                 energy map keeps fp16 accuracy on unrepaired frames. */
 } mca_hip_srp_precision;
 
+/* Weighting of the generalised cross-correlation inside dsp::GeneralisedCrossCorrelation::calculateCorrelationsForPrecomputedTauMatrix
+ * (call site SteeringBeamforming.cpp:115-119; the code itself is in DSPONE, which the reference does not vendor).
+ * PHAT is the build's reading and what BASELINE.json's north_star names.  NONE -- the plain cross-spectrum
+ * X_a conj X_b -- is the reading under which the reference's own SRP test stimulus (1 kHz sines, test_mcarray.cpp:384-423)
+ * localises within its 7 degrees; it is offered so that a maintainer who has DSPONE can switch once
+ * tools/pin_against_dspone.cpp has settled which one DSPONE implements.  NONE needs MCA_HIP_SRP_FP32 (un-normalised spectra
+ * do not fit fp16 operands): frame API always, stream API at N = 1024 with 4 or 8 microphones. */
+typedef enum { MCA_HIP_GCC_PHAT = 0, MCA_HIP_GCC_NONE = 1 } mca_hip_gcc_weighting;
+
 typedef struct mca_hip_ctx mca_hip_ctx;
 
 /* Configuration = the constructor arguments of the reference's modules
@@ -79,6 +88,8 @@ typedef struct {
                                   the frame API exposes mca_hip_fft_log_power for the caller's gate */
     int srp_precision;         /* mca_hip_srp_precision */
     int max_arrays;            /* number of independent arrays whose state the context holds (>= 1) */
+    int gcc_weighting;         /* mca_hip_gcc_weighting; 0 = PHAT.  (Appended in round 3: a struct_size that ends before this
+                                  field is accepted and means PHAT.) */
 } mca_hip_config;
 
 /* ---- page-locked host memory ---------------------------------------------- */

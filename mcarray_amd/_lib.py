@@ -31,6 +31,7 @@ class Config(C.Structure):
         ("use_power_floor", C.c_int),
         ("srp_precision", C.c_int),
         ("max_arrays", C.c_int),
+        ("gcc_weighting", C.c_int),
     ]
 
 

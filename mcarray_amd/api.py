@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import MCArrayHipError
 
 SRP_FP32, SRP_FP16X3, SRP_FP16, SRP_ADAPTIVE = 0, 1, 2, 3
+GCC_PHAT, GCC_NONE = 0, 1            # mca_hip_gcc_weighting
 K_STFT_PHAT, K_SRP_GEMM, K_SCAN_PICK, K_BEAMFORM, K_GCC2_SCAN, K_MASK, K_FOLD, K_REPAIR = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {K_STFT_PHAT: "k_stft_phat", K_SRP_GEMM: "k_srp_gemm", K_SCAN_PICK: "k_scan_pick", K_BEAMFORM: "k_beamform_ola",
                 K_FOLD: "k_sum_planes", K_REPAIR: "repair"}
@@ -53,7 +54,7 @@ class Context:
     """Owns one mca_hip_ctx (the state of max_arrays independent module objects)."""
 
     def __init__(self, sample_rate, mic_positions, fft_size=1024, doa_step_deg=5.0, n_sources=1, use_power_floor=False,
-                 srp_precision=SRP_FP32, max_arrays=1, device=0):
+                 srp_precision=SRP_FP32, max_arrays=1, device=0, gcc_weighting=GCC_PHAT):
         self._lib = _lib.load()
         self.xyz = _xyz(mic_positions)
         self.M = len(self.xyz)
@@ -74,6 +75,7 @@ class Context:
         cfg.use_power_floor = int(use_power_floor)
         cfg.srp_precision = srp_precision
         cfg.max_arrays = max_arrays
+        cfg.gcc_weighting = gcc_weighting
         h = C.c_void_p()
         rc = self._lib.mca_hip_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -185,8 +185,8 @@ int init_last_state(mca_hip_ctx *c, hipStream_t st)
     HIP_TRY(c, hipMemcpyAsync(c->d_last_bin, b.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->d_last_rad, 0, n * 4, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_last_prob, pr.data(), n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipMemsetAsync(c->d_gate_state, 0, (size_t)c->cfg.max_arrays * 4 * 8, st));
+    HIP_TRY(c, hipStreamSynchronize(st));       // (the host vectors above go out of scope; mca_hip_reset returns with nothing queued)
     return MCA_HIP_OK;
 }
 
@@ -386,8 +386,8 @@ void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_ro
 
 // Does a call of this shape run coarse + repair?  The repair pass needs the list mode of k_stft_phat (1024-sample frames,
 // more than two microphones) and has a fixed cost of a few small launches, so small batches -- which are latency bound
-// whatever the precision -- and gated streams (the rows a frame's energy depends on are then the last VOICED ones) run as
-// plain FP16X3, which is what the repair pass reproduces.
+// whatever the precision -- run as plain FP16X3, which is what the repair pass reproduces.  (Gated streams do take the
+// adaptive path: the planning wave lists the last 25 VOICED rows behind a flagged frame)
 bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     const long long rows = c->plan_rows > 0 ? c->plan_rows : (long long)n_arrays * n_frames;     // (see plan_gemm)
@@ -483,7 +483,7 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
 {
     const int M = c->M; const bool ula = c->ula;
     // 4 or 8 microphones: one wave per run of frames on the 1024-point transform of channel pairs (k_stft_phat_wave)
-    if ((M == 8 || M == 4) && std::getenv("MCA_HIP_STFT_WG") == nullptr) {
+    if ((M == 8 || M == 4) && (a.no_phat || std::getenv("MCA_HIP_STFT_WG") == nullptr)) {
         StftPhatArgs w = a;
         dim3 gw;
         if (a.list) { w.fpb = 1; gw = dim3(grid.x, 1); }      // a listed group of REPAIR_GROUP = 4 frames per workgroup, a frame per wave
@@ -495,15 +495,15 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
         }
         const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 4 * w.fpb * (M / 2)) * sizeof(float2);
         const bool pl2 = a.a_planes == 2, pw = a.power != nullptr;
-#define LAUNCH_W2(MT, U, PL2)                                                                                  \
-        do {                                                                                                     \
-            if (pw) hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, true>), gw, dim3(256), smw, st, w);   \
-            else hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, false>), gw, dim3(256), smw, st, w);     \
+#define LAUNCH_W2(MT, U, PL2, NP)                                                                                  \
+        do {                                                                                                         \
+            if (pw) hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, true, NP>), gw, dim3(256), smw, st, w);   \
+            else hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, false, NP>), gw, dim3(256), smw, st, w);     \
         } while (0)
-#define LAUNCH_W(MT, U)                                                                                          \
-        do {                                                                                                     \
-            if constexpr (sizeof(OutT) == 2) { if (pl2) LAUNCH_W2(MT, U, true); else LAUNCH_W2(MT, U, false); }  \
-            else LAUNCH_W2(MT, U, false);                                                                        \
+#define LAUNCH_W(MT, U)                                                                                              \
+        do {                                                                                                         \
+            if constexpr (sizeof(OutT) == 2) { if (pl2) LAUNCH_W2(MT, U, true, false); else LAUNCH_W2(MT, U, false, false); } \
+            else { if (a.no_phat) LAUNCH_W2(MT, U, false, true); else LAUNCH_W2(MT, U, false, false); }              \
         } while (0)
         if (M == 8 && ula) LAUNCH_W(8, true); else if (M == 8) LAUNCH_W(8, false);
         else if (ula) LAUNCH_W(4, true); else LAUNCH_W(4, false);
@@ -570,7 +570,17 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
 {
     if (!cfg || !out) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "cfg/out is NULL");
     *out = nullptr;
-    if (cfg->struct_size != (int)sizeof(mca_hip_config)) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "struct_size mismatch");
+    // (a caller built against the header before gcc_weighting was appended passes the shorter size: PHAT)
+    if (cfg->struct_size != (int)sizeof(mca_hip_config) && cfg->struct_size != (int)offsetof(mca_hip_config, gcc_weighting))
+        return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "struct_size mismatch");
+    mca_hip_config cfg_full{};
+    std::memcpy(&cfg_full, cfg, (size_t)cfg->struct_size);
+    cfg_full.struct_size = (int)sizeof(mca_hip_config);
+    cfg = &cfg_full;
+    if (cfg->gcc_weighting != MCA_HIP_GCC_PHAT && cfg->gcc_weighting != MCA_HIP_GCC_NONE)
+        return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "gcc_weighting must be MCA_HIP_GCC_PHAT or MCA_HIP_GCC_NONE");
+    if (cfg->gcc_weighting == MCA_HIP_GCC_NONE && cfg->srp_precision != MCA_HIP_SRP_FP32)
+        return fail(nullptr, MCA_HIP_ERR_UNSUPPORTED, "gcc_weighting NONE needs srp_precision MCA_HIP_SRP_FP32 (un-normalised spectra do not fit fp16 operands)");
     if (cfg->n_mics < 2 || cfg->n_mics > MCA_MAX_MICS) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "n_mics must be in [2,16]");
     if (!cfg->mic_xyz) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "mic_xyz is NULL");
     if (cfg->n_sources < 1 || cfg->n_sources > MCA_MAX_SOURCES) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "n_sources must be in [1,4]");
@@ -613,6 +623,10 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         else if ((size_t)(c->M + c->S) * (c->H + 1) * 8 + (size_t)c->S * c->H * 4 + 17 * c->S * 8 + 16 > 160 * 1024) {
             c->stream_ok = false; c->stream_why = "fft_size x n_mics exceeds the 160 KiB LDS of a CU in the stream API (use the frame API)";
         }
+    }
+    if (c->stream_ok && c->cfg.gcc_weighting == MCA_HIP_GCC_NONE && (c->generic || (c->M != 4 && c->M != 8))) {
+        c->stream_ok = false;
+        c->stream_why = "gcc_weighting NONE: the stream API serves it at fft_size 1024 with 4 or 8 microphones (the frame API takes any shape)";
     }
     c->n512 = c->N == 512 && c->M <= 8 && c->stream_ok && std::getenv("MCA_HIP_NO_N512") == nullptr;
     c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switches for measurements
@@ -823,15 +837,20 @@ int mca_hip_state_load(mca_hip_ctx *c, const void *blob, long long blob_bytes)
     if (!blob || blob_bytes < (long long)sizeof(StateHeader)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is NULL or truncated");
     StateHeader h;
     std::memcpy(&h, blob, sizeof(h));
-    if (h.magic != STATE_MAGIC || h.version != STATE_VERSION) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "not a state blob of this library version");
+    // version 1 blobs end before the _silenceFramesCounter part (the only change of version 2): they load with the counters at zero
+    if (h.magic != STATE_MAGIC || (h.version != STATE_VERSION && h.version != 1)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "not a state blob of this library version");
     if (h.M != c->M || h.D != c->D || h.S != c->S || h.H != c->H || h.max_arrays != c->cfg.max_arrays || h.use_floor != c->cfg.use_power_floor ||
         h.delays_hash != delays_hash(c))
         return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob was saved by a context with a different configuration");
-    if (blob_bytes < mca_hip_state_size(c)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is truncated");
+    const long long v1_short = h.version == 1 ? (long long)c->cfg.max_arrays * 4 : 0;       // bytes of the part a version-1 blob lacks
+    if (blob_bytes < mca_hip_state_size(c) - v1_short) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is truncated");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipDeviceSynchronize());
     const unsigned char *in = static_cast<const unsigned char *>(blob) + sizeof(h);
-    for (const StatePart &p : state_parts(c)) { HIP_TRY(c, hipMemcpy(p.ptr, in, p.bytes, hipMemcpyHostToDevice)); in += p.bytes; }
+    for (const StatePart &p : state_parts(c)) {
+        if (h.version == 1 && p.ptr == c->d_silence) { HIP_TRY(c, hipMemset(p.ptr, 0, p.bytes)); continue; }
+        HIP_TRY(c, hipMemcpy(p.ptr, in, p.bytes, hipMemcpyHostToDevice)); in += p.bytes;
+    }
     c->gcc2_frames_done = h.gcc2_frames_done;
     return MCA_HIP_OK;
 }
@@ -894,6 +913,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         sa.power = c->cfg.use_power_floor ? c->ws().d_power : nullptr; sa.total_frames = n_frames;
         sa.window = c->d_window; sa.A = a_buf(c); sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
+        sa.no_phat = c->cfg.gcc_weighting == MCA_HIP_GCC_NONE ? 1 : 0;
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         if (c->n512) {
             // 512-sample frames: two frames of up to 8 channels per pass on the wave-level transform
@@ -1101,9 +1121,14 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         }
         set_call_planes(c, 1);
         const size_t smem4 = (size_t)32 * (c->Dp + 8) * sizeof(float);
-        if (ppl == 2) hipLaunchKernelGGL((k_scan_repick<2>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);
-        else if (ppl == 6) hipLaunchKernelGGL((k_scan_repick<6>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);
-        else hipLaunchKernelGGL((k_scan_repick<8>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);
+#define LAUNCH_REPICK(PL)                                                                                                           \
+        do {                                                                                                                        \
+            if (smem4 > 64 * 1024)      /* grids finer than 0.45 degrees: Dp >= 512 */                                              \
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_repick<PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)); \
+            hipLaunchKernelGGL((k_scan_repick<PL>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);                                  \
+        } while (0)
+        if (ppl == 2) LAUNCH_REPICK(2); else if (ppl == 6) LAUNCH_REPICK(6); else LAUNCH_REPICK(8);
+#undef LAUNCH_REPICK
         if (gate) hipLaunchKernelGGL(k_doa_fill, dim3(n_arrays), dim3(1024), 0, st, fa);   // gated-out frames repeat the last FINAL pick
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
@@ -1248,21 +1273,6 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     return MCA_HIP_OK;
 }
 
-extern "C++" {
-namespace {
-
-// Runs body(first array, arrays, stream) for the whole call on the caller's stream.
-template <typename Body>
-int run_lanes(mca_hip_ctx *c, int n_arrays, int, hipStream_t st, Body body)
-{
-    c->n_lanes_last = 1;
-    c->cur_lane = 0; c->a0 = 0;
-    return body(0, n_arrays, st);
-}
-
-}  // namespace
-}  // extern "C++"
-
 int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
                                 int n_arrays, int n_frames, int *doa_bin, float *doa_rad, float *prob,
                                 float *energy, void *stream)
@@ -1270,11 +1280,8 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
     if (rc) return rc;
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
-    const size_t fs_ = (size_t)n_frames * c->S, fd_ = (size_t)n_frames * c->D;
-    rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
-        return localise_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_bin + a0 * fs_,
-                             doa_rad ? doa_rad + a0 * fs_ : nullptr, prob ? prob + a0 * fs_ : nullptr, energy ? energy + a0 * fd_ : nullptr, st);
-    });
+    c->n_lanes_last = 1; c->cur_lane = 0; c->a0 = 0;
+    rc = localise_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, (hipStream_t)stream);
     if (rc) return rc;
     c->last_arrays = n_arrays; c->last_frames = n_frames;
     c->e_cur ^= 1;
@@ -1288,11 +1295,8 @@ static int separate_frames_dev_bins(mca_hip_ctx *c, const float *pcm, long long 
     int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
     if (rc) return rc;
     if (!doa_rad || !out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
-    const size_t fs_ = (size_t)n_frames * c->S, fo_ = (size_t)c->S * n_frames * c->H;
-    rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
-        return separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st,
-                             doa_bin ? doa_bin + a0 * fs_ : nullptr);
-    });
+    c->n_lanes_last = 1; c->cur_lane = 0; c->a0 = 0;
+    rc = separate_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, (hipStream_t)stream, doa_bin);
     if (rc) return rc;
     c->tail_cur ^= 1;
     return MCA_HIP_OK;
@@ -1325,14 +1329,9 @@ int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
     if (!out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
     if ((rc = ensure_bf_table(c))) return rc;
-    const size_t fs_ = (size_t)n_frames * c->S, fd_ = (size_t)n_frames * c->D, fo_ = (size_t)c->S * n_frames * c->H;
-    rc = run_lanes(c, n_arrays, n_frames, (hipStream_t)stream, [&](int a0, int na, hipStream_t st) {
-        int r = localise_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_bin + a0 * fs_, doa_rad + a0 * fs_,
-                              prob ? prob + a0 * fs_ : nullptr, energy ? energy + a0 * fd_ : nullptr, st);
-        if (!r) r = separate_impl(c, pcm + (size_t)a0 * array_stride, array_stride, mic_stride, na, n_frames, doa_rad + a0 * fs_, out_pcm + a0 * fo_, st,
-                                  doa_bin + a0 * fs_);
-        return r;
-    });
+    c->n_lanes_last = 1; c->cur_lane = 0; c->a0 = 0;
+    rc = localise_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, (hipStream_t)stream);
+    if (!rc) rc = separate_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, (hipStream_t)stream, doa_bin);
     if (rc) return rc;
     c->last_arrays = n_arrays; c->last_frames = n_frames;
     c->e_cur ^= 1; c->tail_cur ^= 1;
@@ -1392,6 +1391,7 @@ static int graph_record(mca_hip_graph *g, int idx)
     mca_hip_ctx *c = g->c;
     const int e_cur = c->e_cur, tail_cur = c->tail_cur;
     const unsigned timing = c->timing;
+    const unsigned long long adapt_frames = c->adapt_frames_total;
     c->timing = 0;                              // event pairs belong to eager calls
     HIP_TRY(c, hipStreamBeginCapture(g->cap, hipStreamCaptureModeRelaxed));
     int rc = mca_hip_localise_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_bin, g->doa_rad,
@@ -1402,6 +1402,7 @@ static int graph_record(mca_hip_graph *g, int idx)
     const hipError_t e = hipStreamEndCapture(g->cap, &graph);
     c->timing = timing;
     c->e_cur = e_cur; c->tail_cur = tail_cur;   // nothing ran: the state has not moved
+    c->adapt_frames_total = adapt_frames;       // ... and no frame was processed (mca_hip_graph_launch counts the replays)
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(c, MCA_HIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     g->graph[idx] = graph;
@@ -1430,6 +1431,7 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
         if (rc) return rc;
     }
     HIP_TRY(c, hipGraphLaunch(g->exec[idx], (hipStream_t)stream));
+    if (adaptive_applies(c, g->n_arrays, g->n_frames)) c->adapt_frames_total += (unsigned long long)g->n_arrays * g->n_frames;   // (a recording counts nothing)
     c->e_cur ^= 1;                              // as the eager calls do
     if (g->out_pcm) c->tail_cur ^= 1;
     c->last_arrays = g->n_arrays; c->last_frames = g->n_frames;
@@ -1526,6 +1528,15 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
     for (int i = 0; i < 2 * MAXC; ++i)
         if (!c->io_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->io_ev[i], hipEventDisableTiming));
     hipStream_t s_in = c->io_stream[0], s_run = c->io_stream[1], s_out = c->io_stream[2];
+    // the three internal streams are non-blocking: nothing orders them after earlier work on the null stream or on a caller's
+    // stream (a *_dev call or a graph launch that still writes d_E / d_tail, the memsets of mca_hip_reset).  This entry point
+    // is synchronous anyway, so it starts from an idle device.
+    HIP_TRY(c, hipDeviceSynchronize());
+    // on every exit -- also the early ones of HIP_TRY -- the planning override is dropped and the streams are drained
+    struct Guard {
+        mca_hip_ctx *c; hipStream_t s[3];
+        ~Guard() { c->plan_rows = 0; c->a0 = 0; for (hipStream_t q : s) (void)hipStreamSynchronize(q); }
+    } guard{c, {s_in, s_run, s_out}};
     // (with the power gate the call stays one chunk: mca_hip_copy_gate reads the flags of the whole call from one workspace)
     const int nchunk = c->cfg.use_power_floor ? 1 : std::min(n_arrays, MAXC);
     const bool out_pinned[5] = {is_pinned(doa_bin), is_pinned(doa_rad), is_pinned(prob), is_pinned(energy), is_pinned(out_pcm)};
@@ -1766,7 +1777,7 @@ int mca_hip_steering_process_frame(mca_hip_ctx *c, const double *const *frames, 
     const double mu = (double)memf, omu = (double)(1 - memf);
     double *Ein = c->d_E64[c->e64_cur], *Eout = c->d_E64[c->e64_cur ^ 1];
     hipLaunchKernelGGL(k_frame_srp<double>, dim3(c->D), dim3(256), 0, 0, reinterpret_cast<const C2<double> *>(c->d_fr), c->K, c->D,
-                       c->P, c->d_pairs, c->d_delays, Ein, Eout, mu, omu);
+                       c->P, c->d_pairs, c->d_delays, Ein, Eout, mu, omu, c->cfg.gcc_weighting == MCA_HIP_GCC_NONE ? 1 : 0);
     hipLaunchKernelGGL(k_frame_pick<double>, dim3(1), dim3(512), 0, 0, Eout, c->D, c->P, n_sources, c->d_grid, c->d_res,
                        c->d_res + MCA_MAX_SOURCES, c->d_bins);
     HIP_TRY(c, hipGetLastError());

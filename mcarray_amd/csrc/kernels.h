@@ -22,7 +22,7 @@ template <int R, typename OutT> __global__ void k_stft_phat_sub2(StftPhatArgs p)
 __global__ void k_beamform_gen(BeamformArgs p);
 __global__ void k_bf_table(float2 *tab, const float *grid, const double *mic_x, int M, int n_pairs, double unit);
 template <bool ODD, int VAR, int ABL> __global__ void k_beamform_wave(BeamformWaveArgs p);
-template <int MT, bool ULA, typename OutT, bool PL2, bool POWER> __global__ void k_stft_phat_wave(StftPhatArgs p);
+template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT> __global__ void k_stft_phat_wave(StftPhatArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);
 template <bool SPLIT, int BN> __global__ void k_srp_gemm_f16(GemmArgs p);
@@ -33,7 +33,7 @@ template <int BN> __global__ void k_srp_gemm_repair(GemmArgs p);
 template <typename T> struct C2;
 template <typename T>
 __global__ void k_frame_srp(const C2<T> *X, int K, int D, int P, const int2 *pairs, const float *delays,
-                            const T *E_in, T *E_out, T mu, T omu);
+                            const T *E_in, T *E_out, T mu, T omu, int no_phat);
 template <typename T>
 __global__ void k_frame_pick(const T *E, int D, int P, int S, const float *grid, T *doa, T *prob, int *bins);
 template <typename T>

@@ -32,7 +32,7 @@ __device__ __forceinline__ T block_sum(T v, T *sred)
 // X: [M][K] complex T (CCS order), delays: [P][D] float samples, E_in/E_out: [D].
 template <typename T>
 __global__ __launch_bounds__(256) void k_frame_srp(const C2<T> *X, int K, int D, int P, const int2 *pairs,
-                                                   const float *delays, const T *E_in, T *E_out, T mu, T omu)
+                                                   const float *delays, const T *E_in, T *E_out, T mu, T omu, int no_phat)
 {
     __shared__ T sred[4];
     const int d = blockIdx.x, tid = threadIdx.x;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_frame_srp(const C2<T> *X, int K, int D,
             C2<T> a = A[k], b = B[k];
             T gr = a.x * b.x + a.y * b.y, gi = a.y * b.x - a.x * b.y;     // A conj(B)
             T mag = sqrt(gr * gr + gi * gi);
-            T inv = mag > (T)1e-30 ? (T)1 / mag : (T)0;
+            T inv = no_phat ? (T)1 : (mag > (T)1e-30 ? (T)1 / mag : (T)0);     // gcc_weighting: PHAT / NONE
             double turns = (double)k * tau / N;
             turns -= rint(turns);
             T sn, cs;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_frame_power(const C2<T> *X, int M, int 
 }
 
 #define INST_FRAME(T)                                                                                            \
-    template __global__ void k_frame_srp<T>(const C2<T> *, int, int, int, const int2 *, const float *, const T *, T *, T, T); \
+    template __global__ void k_frame_srp<T>(const C2<T> *, int, int, int, const int2 *, const float *, const T *, T *, T, T, int); \
     template __global__ void k_frame_pick<T>(const T *, int, int, int, const float *, T *, T *, int *);            \
     template __global__ void k_frame_beamform<T>(const C2<T> *, int, int, int, const double *, double, C2<T> *);     \
     template __global__ void k_frame_power<T>(const C2<T> *, int, int, T *);

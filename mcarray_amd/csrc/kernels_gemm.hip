@@ -154,7 +154,7 @@ __device__ __forceinline__ void gemm_f16_tile(const GemmArgs &p, int row0, int c
     }
     const int nk_all = p.Kp / G16_BK, per = (nk_all + ksplit - 1) / ksplit;   // split-K over blockIdx.z
     const int kt0 = z * per, nk = min(kt0 + per, nk_all);
-    G16_GLOAD(kt0 * G16_BK)
+    if (kt0 < nk) { G16_GLOAD(kt0 * G16_BK) }     // (an empty split -- more segments than K steps -- loads nothing and leaves a zero tile)
     for (int kt = kt0; kt < nk; ++kt) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {

@@ -201,12 +201,14 @@ INST_BFW(8) INST_BFW(9) INST_BFW(10) INST_BFW(11) INST_BFW(12) INST_BFW(13) INST
 // z = 2 X: |X|^2 > 1e-30 <=> |z|^2 > 4e-30.  alive: the channel has a non-zero sample in this frame (a channel of exact
 // zeros must give X = 0 like the reference's own transform; riding on its partner's transform it would come out as the
 // partner's rounding noise, which the whitening would blow up to unit modulus).
+// NOPHAT (gcc_weighting NONE): X itself, z / 2.
+template <bool NOPHAT = false>
 __device__ __forceinline__ float2 whiten4(float2 z, float &pw, bool alive = true)
 {
     v2f zv = to_v2f(z), sq, r;
     asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(zv));
     pw = sq.x + sq.y;
-    const float s = (pw > 4e-30f && alive) ? rsqrtf(pw) : 0.f;
+    const float s = NOPHAT ? (alive ? 0.5f : 0.f) : ((pw > 4e-30f && alive) ? rsqrtf(pw) : 0.f);
     v2f sv = {s, s};
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(zv), "v"(sv));
     return from_v2f(r);
@@ -231,7 +233,7 @@ __device__ __forceinline__ void store_a_wave(float *row, unsigned voff, int cidx
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row + 2 * cidx) + 2 * voff) = v;
 }
 
-template <int MT, bool ULA, typename OutT, bool PL2, bool POWER>
+template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT>
 __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
 {
     constexpr int NP = MT / 2, NOUT = PairOut<MT, ULA>::N;
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                     const float2 a2 = make_float2(zk.x + zm.x, zk.y - zm.y);                               // 2 X_a
                     const float2 b2 = make_float2(zk.y + zm.y, zm.x - zk.x);                               // 2 X_b
                     float pwa, pwb;
-                    Xh[2 * pr][s] = whiten4(a2, pwa, alive_a);
-                    Xh[2 * pr + 1][s] = whiten4(b2, pwb, alive_b);
+                    Xh[2 * pr][s] = whiten4<NOPHAT>(a2, pwa, alive_a);
+                    Xh[2 * pr + 1][s] = whiten4<NOPHAT>(b2, pwb, alive_b);
                     if (POWER) {
                         const float pw = (alive_a ? pwa : 0.f) + (alive_b ? pwb : 0.f);
                         pall += pw;
@@ -358,8 +360,8 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
             for (int pr = 0; pr < NP; ++pr) {
                 const float2 n = nyq[lane * NP + pr];
                 float pw;
-                xn[2 * pr] = whiten4(make_float2(2.f * n.x, 0.f), pw);
-                xn[2 * pr + 1] = whiten4(make_float2(2.f * n.y, 0.f), pw);
+                xn[2 * pr] = whiten4<NOPHAT>(make_float2(2.f * n.x, 0.f), pw);
+                xn[2 * pr + 1] = whiten4<NOPHAT>(make_float2(2.f * n.y, 0.f), pw);
             }
             OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f_begin + lane) * (long long)p.a_row_elems;
             pair_products<MT, ULA>(xn, out);
@@ -370,9 +372,10 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
     }
 }
 
-#define INST_SPW1(MT, ULA, T, PL2) template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, false>(StftPhatArgs); \
-                                   template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, true>(StftPhatArgs);
-#define INST_SPW(MT, ULA) INST_SPW1(MT, ULA, _Float16, false) INST_SPW1(MT, ULA, _Float16, true) INST_SPW1(MT, ULA, float, false)
+#define INST_SPW1(MT, ULA, T, PL2, NP) template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, false, NP>(StftPhatArgs); \
+                                       template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, true, NP>(StftPhatArgs);
+#define INST_SPW(MT, ULA) INST_SPW1(MT, ULA, _Float16, false, false) INST_SPW1(MT, ULA, _Float16, true, false) INST_SPW1(MT, ULA, float, false, false) \
+                          INST_SPW1(MT, ULA, float, false, true)
 INST_SPW(8, true) INST_SPW(8, false) INST_SPW(4, true) INST_SPW(4, false)
 
 }  // namespace mca

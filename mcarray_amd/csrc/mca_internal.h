@@ -46,6 +46,7 @@ struct StftPhatArgs {
     // list mode (k_stft_phat only; the repair pass of the adaptive SRP precision): workgroup b takes the REPAIR_GROUP frames of
     // list[list0 + b] = array * groups_per_array + group and writes A rows b * REPAIR_GROUP ...; b >= *n_list - list0 exits
     const int *list; const int *n_list; int list0, list_cap, groups_per_array;   // list_cap: groups of this pass at most
+    int no_phat;             // 1: gcc_weighting NONE -- the pair products of the spectra themselves (k_stft_phat_wave, fp32 rows only)
 };
 
 __device__ __forceinline__ void store_a(float *row, const StftPhatArgs &, int cidx, float2 v)

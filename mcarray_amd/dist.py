@@ -149,5 +149,25 @@ def launch_ranks(n, argv, master_port=None):
                    MASTER_PORT=str(master_port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
-    codes = [p.wait() for p in procs]
+    # poll: a rank that dies before the rendezvous would leave the others waiting for the collective's timeout
+    import time
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    pr.terminate()
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = pr.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[i] = pr.wait()
+            break
+        time.sleep(0.05)
     return max((abs(c) for c in codes), default=0)

@@ -244,13 +244,26 @@ void mca_or_precompute_tau_matrix(const double *tau, int D, int K, double *T)
 void mca_or_gcc_phat_tau_matrix(const double *A, const double *B, const double *T,
                                 int K, int D, double *out)
 {
+    mca_or_gcc_tau_matrix(A, B, T, K, D, out, MCA_OR_GCC_PHAT);
+}
+
+/* The same steered sum with the weighting as a parameter: MCA_OR_GCC_PHAT (the build's [INFERRED] reading of
+ * dsp::GeneralisedCrossCorrelation, SURVEY A.3, and what north_star names) or MCA_OR_GCC_NONE (the plain cross-spectrum
+ * X_a conj X_b: the reading under which the reference's own sine test, test_mcarray.cpp:384-423, would pass -- DESIGN.md
+ * section 2).  The deciding code is inside DSPONE; tools/pin_against_dspone.cpp settles it on a machine that has it. */
+void mca_or_gcc_tau_matrix(const double *A, const double *B, const double *T,
+                           int K, int D, double *out, int weighting)
+{
     double *g = (double *)malloc(sizeof(double) * 2 * (size_t)K);
     for (int k = 0; k < K; ++k) {
         double ar = A[2 * k], ai = A[2 * k + 1], br = B[2 * k], bi = B[2 * k + 1];
         double gr = ar * br + ai * bi;
         double gi = ai * br - ar * bi;
-        double mag = sqrt(gr * gr + gi * gi);
-        if (mag < 1e-30) mag = 1e-30;
+        double mag = 1.0;
+        if (weighting == MCA_OR_GCC_PHAT) {
+            mag = sqrt(gr * gr + gi * gi);
+            if (mag < 1e-30) mag = 1e-30;
+        }
         g[2 * k] = gr / mag; g[2 * k + 1] = gi / mag;
     }
     for (int d = 0; d < D; ++d) {
@@ -279,7 +292,10 @@ struct mca_or_steering {
     double *corr;     /* P x D  (_correlations) */
     double *ccorr;    /* D complex (_complexCorrelation) */
     double *E, *Eprev;/* D (_energyInDOA, _prevEnergyInDOA) */
+    int weighting;    /* MCA_OR_GCC_PHAT (default) / MCA_OR_GCC_NONE */
 };
+
+void mca_or_steering_set_weighting(mca_or_steering *s, int weighting) { s->weighting = weighting; }
 
 mca_or_steering *mca_or_steering_create(int fs, const double *xyz, int M, int ccs_len, double step_deg)
 {
@@ -361,6 +377,57 @@ void mca_or_select_doa(const double *Ein, int D, int numPairs, float step, int n
     free(E); free(fd); free(ff); free(sd);
 }
 
+/* Is the outcome of selectDOA on E pinned at all?  Returns 1 if moving any normalised energy by up to eps/2 (so any first
+ * difference by up to eps) could change one of the numOfSources picks -- the cases a single-precision implementation may
+ * legitimately resolve differently from this double-precision one:
+ *   (a) two of the numOfSources + 1 largest second-derivative values lie within eps of each other (a tie between peaks);
+ *   (b) a position whose second derivative reads a first difference within eps of zero (its sign, :161, could flip and with it
+ *       the median filter's output, :164) holds an energy that reaches the last pick: a peak could appear or vanish there --
+ *       at the map's edge too, far from the winning bin;
+ *   (c) the last pick is a zero entry (fewer positive peaks than sources) while some candidate's energy is within eps of zero.
+ * Test infrastructure (the classifier of GPU / oracle bin differences in tests/parity_helpers.py and tools/fuzz_parity.py);
+ * it mirrors the sensitivity test that the adaptive SRP precision runs on the device (k_scan_pick, kernels_stream.hip). */
+int mca_or_select_doa_fragile(const double *Ein, int D, int numPairs, int numOfSources, double eps)
+{
+    if (D < 3) return 0;
+    double *E = (double *)malloc(sizeof(double) * (size_t)D);
+    double *df = (double *)malloc(sizeof(double) * (size_t)D);
+    double *fd = (double *)malloc(sizeof(double) * (size_t)D);
+    double *ff = (double *)malloc(sizeof(double) * (size_t)D);
+    double *sd = (double *)malloc(sizeof(double) * (size_t)D);
+    const double minEnergyInDOA = -15 * numPairs;
+    for (int i = 0; i < D; ++i) E[i] = (Ein[i] - minEnergyInDOA) / (-2 * minEnergyInDOA);
+    for (int i = 0; i < D - 1; ++i) { df[i] = E[i + 1] - E[i]; fd[i] = (df[i] < 0.0) ? 1.0 : 0.0; }
+    median3(fd, ff, D - 1);
+    double umax = -1.0, zmin = 1e300;        /* largest |E| over the uncertain positions; smallest |E| over the candidates */
+    int any_uncertain = 0;
+    for (int i = 0; i < D - 2; ++i) {
+        sd[i] = (ff[i + 1] - ff[i]) * E[i + 1];
+        double dmin = 1e300;
+        for (int c = -1; c <= 2; ++c) {      /* ff[i], ff[i + 1] read fd[i - 1 .. i + 2], edges replicated */
+            int j = i + c; if (j < 0) j = 0; if (j > D - 2) j = D - 2;
+            const double a = fabs(df[j]); if (a < dmin) dmin = a;
+        }
+        const double ae = fabs(E[i + 1]);
+        if (dmin <= eps) { any_uncertain = 1; if (ae > umax) umax = ae; }
+        if (ff[i + 1] != ff[i] && ae < zmin) zmin = ae;
+    }
+    int fragile = 0;
+    double prev = 0.0, v_last = 0.0;
+    for (int s = 0; s < numOfSources + 1; ++s) {
+        double max = sd[0]; int maxIdx = 0;
+        for (int i = 1; i < D - 2; ++i) if (sd[i] > max) { max = sd[i]; maxIdx = i; }
+        sd[maxIdx] = 0;
+        if (s > 0 && prev > 0.0 && prev - max <= eps) fragile = 1;                      /* (a) */
+        prev = max;
+        if (s < numOfSources) v_last = max;
+    }
+    if (v_last > 0.0 ? (any_uncertain && umax >= v_last - eps) : any_uncertain) fragile = 1;   /* (b) */
+    if (v_last <= eps && zmin <= eps) fragile = 1;                                      /* (c) */
+    free(E); free(df); free(fd); free(ff); free(sd);
+    return fragile;
+}
+
 void mca_or_steering_process_frame(mca_or_steering *s, const double *const *frames,
                                    double *DOA, double *prob, int *doa_bin, int numOfSources,
                                    double *energy_out, double *corr_out)
@@ -370,7 +437,7 @@ void mca_or_steering_process_frame(mca_or_steering *s, const double *const *fram
     for (int p = 0; p < P; ++p) {
         const double *A = frames[s->pair[2 * p]];        /* :110 */
         const double *B = frames[s->pair[2 * p + 1]];    /* :111 */
-        mca_or_gcc_phat_tau_matrix(A, B, s->T + 2 * (size_t)p * D * K, K, D, s->ccorr);   /* :115-119 */
+        mca_or_gcc_tau_matrix(A, B, s->T + 2 * (size_t)p * D * K, K, D, s->ccorr, s->weighting);   /* :115-119 */
         for (int d = 0; d < D; ++d) s->corr[(size_t)p * D + d] = s->ccorr[2 * d];           /* wipp::real :122 */
     }
     if (corr_out) {
@@ -456,6 +523,7 @@ void mca_or_bsl_destroy(mca_or_bsl *b)
     mca_or_steering_destroy(b->st); free(b);
 }
 
+void mca_or_bsl_set_weighting(mca_or_bsl *b, int weighting) { mca_or_steering_set_weighting(b->st, weighting); }
 const double *mca_or_bsl_current_doa(const mca_or_bsl *b) { return b->curDOA; }
 const int *mca_or_bsl_current_bin(const mca_or_bsl *b) { return b->curBin; }
 
@@ -513,8 +581,16 @@ void mca_or_ssl_stream(int fs, int N, const double *xyz, int M, int S, double st
                        const double *pcm, long stride, int F,
                        int *doa_bin, double *doa_rad, double *prob, double *out_pcm, double *energy_map)
 {
+    mca_or_ssl_stream_w(fs, N, xyz, M, S, step_deg, MCA_OR_GCC_PHAT, pcm, stride, F, doa_bin, doa_rad, prob, out_pcm, energy_map);
+}
+
+void mca_or_ssl_stream_w(int fs, int N, const double *xyz, int M, int S, double step_deg, int weighting,
+                         const double *pcm, long stride, int F,
+                         int *doa_bin, double *doa_rad, double *prob, double *out_pcm, double *energy_map)
+{
     const int hop = N / 2, ccs = N + 2;
     mca_or_bsl *b = mca_or_bsl_create(fs, ccs, xyz, M, S, 0, step_deg);
+    mca_or_bsl_set_weighting(b, weighting);
     const int D = b->st->D;
     double *win = (double *)malloc(sizeof(double) * (size_t)N);
     mca_or_hann_periodic(win, N);

@@ -68,6 +68,11 @@ void mca_or_gcc_phat_tau_matrix(const double *A, const double *B, const double *
 
 /* ---- SteeringBeamforming: src/mcarray/SteeringBeamforming.cpp ---------- */
 typedef struct mca_or_steering mca_or_steering;
+/* GCC weighting of the steered sum (mca_or_gcc_tau_matrix): PHAT is what every object starts with */
+#define MCA_OR_GCC_PHAT 0
+#define MCA_OR_GCC_NONE 1
+void mca_or_gcc_tau_matrix(const double *A, const double *B, const double *T, int K, int D, double *out, int weighting);
+void mca_or_steering_set_weighting(mca_or_steering *s, int weighting);
 mca_or_steering *mca_or_steering_create(int fs, const double *xyz, int M,
                                         int fft_ccs_length, double doa_step_deg); /* :34-94 */
 void mca_or_steering_destroy(mca_or_steering *s);
@@ -85,6 +90,9 @@ void mca_or_steering_reset(mca_or_steering *s);
 /* selectDOA alone (:146-195) on a given un-normalised energy vector */
 void mca_or_select_doa(const double *E, int D, int n_pairs, float step, int n_sources,
                        double *DOA, double *prob, int *doa_bin);
+/* 1 if perturbations of the normalised energies of up to eps/2 could change a pick (peak ties, sign-chain ties, zero picks):
+ * the classifier of single- vs double-precision bin differences used by the tests; see mca_oracle.c */
+int mca_or_select_doa_fragile(const double *E, int D, int n_pairs, int n_sources, double eps);
 
 /* ---- Beamformer: src/mcarray/Beamformer.cpp:51-71 ---------------------- */
 void mca_or_beamformer_process_frame(int fs, const double *xyz, int M, int fft_ccs_length,
@@ -93,6 +101,7 @@ void mca_or_beamformer_process_frame(int fs, const double *xyz, int M, int fft_c
 /* ---- BeamformingSeparationAndLocalisation:
  *      src/mcarray/BeamformingSeparationAndLocalisation.cpp:29-119 -------- */
 typedef struct mca_or_bsl mca_or_bsl;
+void mca_or_bsl_set_weighting(mca_or_bsl *b, int weighting);
 mca_or_bsl *mca_or_bsl_create(int fs, int fft_ccs_length, const double *xyz, int M,
                               int n_sources, int use_power_floor, double doa_step_deg);
 void mca_or_bsl_destroy(mca_or_bsl *b);
@@ -112,6 +121,10 @@ const int    *mca_or_bsl_current_bin(const mca_or_bsl *b);
  * pcm: M channels, channel c at pcm + c*stride, (F+1)*hop samples each.
  * doa_bin[F*S], prob[F*S], out_pcm[S][F*hop] (channel s at out + s*F*hop),
  * energy_map (may be NULL) [F][D].                                        */
+/* mca_or_ssl_stream with the GCC weighting as a parameter */
+void mca_or_ssl_stream_w(int fs, int N, const double *xyz, int M, int n_sources, double doa_step_deg, int weighting,
+                         const double *pcm, long stride, int n_frames,
+                         int *doa_bin, double *doa_rad, double *prob, double *out_pcm, double *energy_map);
 void mca_or_ssl_stream(int fs, int N, const double *xyz, int M, int n_sources,
                        double doa_step_deg, const double *pcm, long stride, int F,
                        int *doa_bin, double *doa_rad, double *prob, double *out_pcm,

@@ -89,23 +89,27 @@ def stft_frames(pcm, N):
     return np.fft.rfft(fr, axis=-1).transpose(1, 0, 2)
 
 
-def gcc_phat(A, B, tau, K):
-    """R[d] = Re sum_k Ghat[k] exp(+j 2 pi k tau_d / N)  """
+def gcc_phat(A, B, tau, K, weighting="phat"):
+    """R[d] = Re sum_k Ghat[k] exp(+j 2 pi k tau_d / N)  (SURVEY A.3); weighting "phat" (Ghat = G / |G|) or "none" (Ghat = G)"""
     G = A * np.conj(B)
-    mag = np.maximum(np.abs(G), 1e-30)
-    Gh = G / mag
+    if weighting == "phat":
+        Gh = G / np.maximum(np.abs(G), 1e-30)
+    elif weighting == "none":
+        Gh = G
+    else:
+        raise ValueError(weighting)
     N = 2 * (K - 1)
     ph = 2 * np.pi * np.outer(tau, np.arange(K)) / N
     return (Gh[None, :] * np.exp(1j * ph)).sum(axis=1)
 
 
-def srp_map(X, delays):
+def srp_map(X, delays, weighting="phat"):
     """X complex [M][K]; delays [P][D] -> per-pair R [P][D] (real)."""
     M, K = X.shape
     pairs = pair_list(M)
     R = np.empty((len(pairs), delays.shape[1]))
     for p, (i, j) in enumerate(pairs):
-        R[p] = gcc_phat(X[i], X[j], delays[p], K).real
+        R[p] = gcc_phat(X[i], X[j], delays[p], K, weighting).real
     return R
 
 
@@ -164,7 +168,7 @@ def irfft_ccs(Y, N):
     return np.fft.irfft(Y, n=N, axis=-1)
 
 
-def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0):
+def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0, weighting="phat"):
     xyz = xyz_of(xyz)
     M = len(xyz)
     hop = N // 2
@@ -183,7 +187,7 @@ def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0):
     out = np.zeros((nout, F * hop))
     tail = np.zeros((nout, hop))
     for t in range(F):
-        R = srp_map(X[t], delays)
+        R = srp_map(X[t], delays, weighting)
         E = energy_update(E, R)
         emap[t] = E
         doas[t], probs[t], bins[t] = select_doa(E.copy(), P, step, n_sources)

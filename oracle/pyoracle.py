@@ -28,7 +28,8 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libmca_oracle.so")
+        # MCA_ORACLE_LIB: another build of the same source (the sanitizer build of tests/test_oracle_asan.py)
+        so = os.environ.get("MCA_ORACLE_LIB") or os.path.join(_HERE, "libmca_oracle.so")
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
@@ -64,6 +65,7 @@ def lib():
         L.mca_or_fft_log_power.argtypes = [C.POINTER(c_dp), C.c_int, C.c_int]
         L.mca_or_precompute_tau_matrix.argtypes = [c_dp, C.c_int, C.c_int, c_dp]
         L.mca_or_gcc_phat_tau_matrix.argtypes = [c_dp, c_dp, c_dp, C.c_int, C.c_int, c_dp]
+        L.mca_or_gcc_tau_matrix.argtypes = [c_dp, c_dp, c_dp, C.c_int, C.c_int, c_dp, C.c_int]
         L.mca_or_steering_create.restype = C.c_void_p
         L.mca_or_steering_create.argtypes = [C.c_int, c_dp, C.c_int, C.c_int, C.c_double]
         L.mca_or_steering_destroy.argtypes = [C.c_void_p]
@@ -76,6 +78,8 @@ def lib():
         L.mca_or_steering_delays.argtypes = [C.c_void_p, C.c_int]
         L.mca_or_steering_process_frame.argtypes = [C.c_void_p, C.POINTER(c_dp), c_dp, c_dp, c_ip, C.c_int, c_dp, c_dp]
         L.mca_or_select_doa.argtypes = [c_dp, C.c_int, C.c_int, C.c_float, C.c_int, c_dp, c_dp, c_ip]
+        L.mca_or_select_doa_fragile.restype = C.c_int
+        L.mca_or_select_doa_fragile.argtypes = [c_dp, C.c_int, C.c_int, C.c_int, C.c_double]
         L.mca_or_beamformer_process_frame.argtypes = [C.c_int, c_dp, C.c_int, C.c_int, C.POINTER(c_dp), c_dp, C.c_double]
         L.mca_or_bsl_create.restype = C.c_void_p
         L.mca_or_bsl_create.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_double]
@@ -85,6 +89,10 @@ def lib():
         L.mca_or_bsl_separate.argtypes = [C.c_void_p, C.POINTER(c_dp)]
         L.mca_or_ssl_stream.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, c_dp, C.c_long,
                                         C.c_int, c_ip, c_dp, c_dp, c_dp, c_dp]
+        L.mca_or_ssl_stream_w.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, C.c_long,
+                                          C.c_int, c_ip, c_dp, c_dp, c_dp, c_dp]
+        L.mca_or_steering_set_weighting.argtypes = [C.c_void_p, C.c_int]
+        L.mca_or_bsl_set_weighting.argtypes = [C.c_void_p, C.c_int]
         L.mca_or_ssl_stream_gated.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, C.c_long,
                                               C.c_int, c_ip, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp]
         L.mca_or_freqgcc_create.restype = C.c_void_p
@@ -261,6 +269,31 @@ def select_doa(E, n_pairs, step_deg, n_sources=1):
     return doa, prob, b
 
 
+def precompute_tau_matrix(tau, K):
+    """dsp::GeneralisedCrossCorrelation::precomputeTauMatrix [INFERRED, SURVEY A.3]: T[d][k] = exp(+j 2 pi k tau_d / N) as
+    [D][K][2] doubles"""
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    T = np.empty((len(tau), K, 2))
+    lib().mca_or_precompute_tau_matrix(_dp(tau), len(tau), K, _dp(T))
+    return T
+
+
+def gcc_tau_matrix(A_ccs, B_ccs, T, K, D, weighting=0):
+    """calculateCorrelationsForPrecomputedTauMatrix on two CCS frames: [D][2] complex correlations (mca_or_gcc_tau_matrix)"""
+    A = np.ascontiguousarray(A_ccs, dtype=np.float64)
+    B = np.ascontiguousarray(B_ccs, dtype=np.float64)
+    out = np.empty((D, 2))
+    lib().mca_or_gcc_tau_matrix(_dp(A), _dp(B), _dp(np.ascontiguousarray(T)), K, D, _dp(out), int(weighting))
+    return out
+
+
+def select_doa_fragile(E, n_pairs, n_sources=1, eps=1e-6):
+    """True if selectDOA's picks on the energy row E are not pinned against perturbations of size eps of the normalised
+    energies (peak ties, sign-chain ties, zero picks): mca_or_select_doa_fragile."""
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    return bool(lib().mca_or_select_doa_fragile(_dp(E), len(E), int(n_pairs), int(n_sources), float(eps)))
+
+
 def beamformer_process_frame(fs, xyz, frames, doa):
     """mca::Beamformer::processFrame (Beamformer.cpp:51-71). frames [M][ccs] -> out [ccs]"""
     a = _xyz(xyz)
@@ -303,8 +336,12 @@ class BSL:
         return frames
 
 
-def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0, want_map=False, want_audio=True):
-    """Whole SourceSeparationAndLocalisation stream. pcm [M][(F+1)*hop]."""
+GCC_WEIGHTING = {"phat": 0, "none": 1}
+
+
+def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0, want_map=False, want_audio=True, weighting="phat"):
+    """Whole SourceSeparationAndLocalisation stream. pcm [M][(F+1)*hop].  weighting: "phat" (default) or "none" -- the GCC
+    weighting of the steered sum (mca_or_gcc_tau_matrix)."""
     a = _xyz(xyz)
     pcm = np.ascontiguousarray(pcm, dtype=np.float64)
     M, L = pcm.shape
@@ -318,8 +355,8 @@ def ssl_stream(fs, N, xyz, pcm, n_sources=1, step_deg=5.0, want_map=False, want_
     nout = min(M, S)
     out = np.zeros((nout, F * hop)) if want_audio else None
     emap = np.empty((F, D)) if want_map else None
-    lib().mca_or_ssl_stream(fs, N, _dp(a), M, S, step_deg, _dp(pcm), L, F, _ip(bins), _dp(doa), _dp(prob),
-                            _dp(out) if want_audio else None, _dp(emap) if want_map else None)
+    lib().mca_or_ssl_stream_w(fs, N, _dp(a), M, S, step_deg, GCC_WEIGHTING[weighting], _dp(pcm), L, F, _ip(bins), _dp(doa), _dp(prob),
+                              _dp(out) if want_audio else None, _dp(emap) if want_map else None)
     return dict(bin=bins, doa=doa, prob=prob, out=out, energy=emap)
 
 

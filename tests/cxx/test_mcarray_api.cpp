@@ -51,6 +51,21 @@ static void testArrayDescription()
     EXPECT(static_cast<int>(std::round(M_PI / step) + 1) == 37);
     EXPECT(std::fabs(doaIdx2angle(18, step)) < 1e-6);
     EXPECT(std::fabs(doaToDelayFarFieldSamples(static_cast<float>(M_PI / 2), 0.21f, 48000) - 0.21 / 346.1 * 48000) < 1e-4);
+    // the rest of microhponeArrayHelpers.h (:74-139)
+    EXPECT(std::fabs(maxFreqForSpatialAliasing(0.086f) - 346.1 / (2 * 0.086)) < 1e-3);
+    EXPECT(std::fabs(delayToDOA(0.f, 0.21f) - M_PI / 2) < 1e-6);
+    EXPECT(std::fabs(delaySamplesToDOA(doaToDelayFarFieldSamples(0.3f, 0.21f, 48000), 0.21f, 48000.f) - (M_PI / 2 - 0.3)) < 1e-4);   // acos vs sin convention
+    {
+        SignalPtr deg(new BaseType[2]);
+        deg[0] = 180; deg[1] = -90;
+        SignalPtr rad = toRadiasn(deg, 2), back = toDegrees(rad, 2);
+        EXPECT(std::fabs(rad[0] - M_PI) < 1e-12 && std::fabs(rad[1] + M_PI / 2) < 1e-12 && std::fabs(back[0] - 180) < 1e-9 && deg[0] == 180);
+        // calculateBinauralPower: |(1 + 2j) + (3 - 2j)|^2 = 16 and |(0 + 1j) + (0 + 1j)|^2 = 4 -> mean 10 -> 10 log10(5)
+        const Complex l[2] = {{1, 2}, {0, 1}}, r[2] = {{3, -2}, {0, 1}};
+        Complex m[2];
+        EXPECT(std::fabs(calculateBinauralPower(l, r, m, 2) - 10 * std::log10(5.0)) < 1e-12);
+        EXPECT(m[0].re == 4 && m[0].im == 0 && m[1].re == 0 && m[1].im == 2);
+    }
     std::printf("testArrayDescription done\n");
 }
 

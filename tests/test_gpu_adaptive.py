@@ -24,17 +24,7 @@ def force_small(monkeypatch):
     monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "256")       # read by mca_hip_create: adaptive also for small batches
 
 
-def _assert_bins(gpu_bins, ora_bins, ora_energy, n_pairs, max_ties):
-    """bins equal except numerical ties of the fp32-level paths against the fp64 oracle (as tests/test_gpu_parity.py)"""
-    ties = 0
-    for idx in np.argwhere(gpu_bins != ora_bins):
-        t = idx[0]
-        g, o = int(gpu_bins[tuple(idx)]), int(ora_bins[tuple(idx)])
-        En = (ora_energy[t] + 15.0 * n_pairs) / (30.0 * n_pairs)
-        assert abs(En[g] - En[o]) < 1e-5, "DOA bin mismatch that is not a tie: frame %d gpu %d oracle %d" % (t, g, o)
-        ties += 1
-    assert ties <= max_ties
-    return ties
+from parity_helpers import assert_bins as _assert_bins   # the same bar as tests/test_gpu_parity.py
 
 
 @pytest.mark.parametrize("xs,step,S,thetas", [(synth.ULA8, 0.5, 1, (23.0, -61.5, 79.0)), (synth.REEM_C, 5.0, 2, (-40.0, 10.0, 55.0)),
@@ -188,3 +178,17 @@ def test_adaptive_with_power_gate_equals_fp16x3_at_full_size():
         base = tw.select_doa(E, P, tw.doa_step(0.5), S)[2]
         assert any(not np.array_equal(tw.select_doa(E + prng.standard_normal(E.shape) * 2e-6 * np.abs(E).max(), P, tw.doa_step(0.5), S)[2], base)
                    for _ in range(32)), (a_, t_)
+
+
+def test_adaptive_fine_grid_dp512(force_small):
+    """a 0.4 degree grid (451 angles, Dp = 576 > 512 columns): the second pick's LDS tile exceeds 64 KiB and needs the
+    dynamic-shared-memory opt-in (k_scan_repick); bins against the oracle."""
+    fs, N, F = 48000, 1024, 150
+    pcm = synth.noise_source_stream(synth.ULA8, np.deg2rad(-17.3), fs, (F + 1) * N // 2, 31)
+    ctx = api.Context(fs, synth.ULA8, N, 0.4, 1, srp_precision=api.SRP_ADAPTIVE)
+    assert ctx.D == 451
+    r = ctx.process_frames_host(pcm[None], want_energy=False)
+    assert ctx.repair_stats()["frames"] == F
+    o = po.ssl_stream(fs, N, synth.ULA8, pcm.astype(np.float64), 1, 0.4, want_map=True, want_audio=False)
+    _assert_bins(r["bin"][0], o["bin"], o["energy"], ctx.P, max_ties=2)
+    ctx.close()

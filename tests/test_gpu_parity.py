@@ -2,8 +2,8 @@
 the CPU oracle and the committed golden vectors.  Run on the MI355X box with `-m gpu`.
 
 Tolerances (fp32 GPU vs fp64 oracle), written where they are used:
-  * DOA bin: bit-exact, except frames the oracle itself flags as numerical ties (two candidate
-    peaks whose normalised energies differ by < 1e-6) where +-1 bin is accepted and counted.
+  * DOA bin: bit-exact, except frames the oracle itself flags as fragile (mca_or_select_doa_fragile at 1e-6 of the
+    normalised energy: peak ties, sign-chain ties, zero picks -- tests/parity_helpers.py), which are counted and bounded.
   * energy map E_t[d]: |gpu - oracle| <= TOL_E * max|E| with TOL_E = 2e-5 (fp32), 2e-5 (fp16x3), 2e-4 (fp16)
   * beamformed audio: |gpu - oracle| <= 2e-5 * max|out| + 1e-7
 """
@@ -24,19 +24,7 @@ def _golden(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
-def _assert_bins(gpu_bins, ora_bins, ora_energy, n_pairs, max_ties=0):
-    """exact match, or a flagged numerical tie in the oracle's own map (+-1 bin)."""
-    ties = 0
-    bad = np.argwhere(gpu_bins != ora_bins)
-    for idx in bad:
-        t = idx[-2] if gpu_bins.ndim >= 2 else idx[0]
-        g, o = int(gpu_bins[tuple(idx)]), int(ora_bins[tuple(idx)])
-        E = ora_energy[t] if ora_energy.ndim == 2 else ora_energy[tuple(idx[:-1])]
-        En = (E + 15.0 * n_pairs) / (30.0 * n_pairs)
-        assert abs(g - o) <= 1 and abs(En[g] - En[o]) < 1e-6, "DOA bin mismatch that is not a tie: gpu %d oracle %d" % (g, o)
-        ties += 1
-    assert ties <= max_ties, "%d flagged ties" % ties
-    return ties
+from parity_helpers import assert_bins as _assert_bins   # exact, or a frame the oracle itself flags as fragile (counted)
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -257,7 +245,7 @@ def test_invalid_arguments_are_rejected():
         ctx.process_frames_host(np.zeros((2, 8, 2048), dtype=np.float32))   # more arrays than max_arrays
 
 
-@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16])
+@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16, api.SRP_ADAPTIVE])
 def test_full_size_properties(prec):
     """BASELINE config 3 size (8 arrays x 4096 frames, 361 angles) through size-independent properties."""
     torch = pytest.importorskip("torch")
@@ -298,7 +286,16 @@ def test_full_size_properties(prec):
     # (3) arrays are independent units: array 5 alone == array 5 in the batch (bit-exact)
     solo = api.Context(fs, synth.ULA8, N, 0.5, 1, srp_precision=prec, max_arrays=1)
     b3, d3, pr3, o3 = run(solo, pcm[5:6].contiguous(), 1)
-    assert torch.equal(b3[0], b[5]) and torch.equal(o3[0], o[5])
+    if prec == api.SRP_ADAPTIVE:
+        # (the two calls repair different row sets -- every array's and call's tail, the frames flagged in this batch -- so an
+        # exact-level tie may resolve differently: bins equal up to a handful of frames, audio equal wherever the bins are)
+        diff = (b3[0] != b[5]).flatten()
+        assert int(diff.sum()) <= 4
+        same_hops = (~diff).repeat_interleave(hop)
+        same_hops[hop:] &= same_hops[:-hop].clone()            # a hop also carries the previous frame's second half
+        assert torch.equal(o3[0, 0][same_hops], o[5, 0][same_hops])
+    else:
+        assert torch.equal(b3[0], b[5]) and torch.equal(o3[0], o[5])
     # (4) STFT -> delay-and-sum -> ISTFT is the identity for identical channels steered broadside
     same = pcm[0:1, 0:1, :].expand(1, 8, L).contiguous()
     d0 = torch.zeros(1, F, 1, dtype=torch.float32, device=dev)
@@ -842,3 +839,59 @@ def test_kernel_timing_and_mask():
         assert np.array_equal(r["bin"], r0["bin"])
         np.testing.assert_array_equal(r["out"], r0["out"])
 
+
+
+def test_configs4_per_gpu_shape_adaptive_vs_oracle():
+    """BASELINE configs[4]'s per-GPU shape -- 128 arrays x 256 frames -- in the shipped default (ADAPTIVE), against the oracle on
+    sampled arrays (first, middle, last: 3 x 256 frames), and array independence at this shape."""
+    torch = pytest.importorskip("torch")
+    fs, N, F, A = 48000, 1024, 256, 128
+    hop = N // 2
+    rng = np.random.default_rng(44)
+    thetas = rng.uniform(-80, 80, A)
+    sample = (0, 63, 127)
+    pcm = np.empty((A, 8, (F + 1) * hop), dtype=np.float32)
+    for a in range(A):
+        pcm[a] = synth.noise_source_stream(synth.ULA8, np.deg2rad(thetas[a]), fs, (F + 1) * hop, 7000 + a)
+    ctx = api.Context(fs, synth.ULA8, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+    r = ctx.process_frames_host(pcm, want_energy=False)
+    st = ctx.repair_stats()
+    assert st["frames"] == A * F and 0 < st["recomputed"] < 0.25 * A * F, st       # the adaptive path ran; the tails stay a fraction
+    for a in sample:
+        o = po.ssl_stream(fs, N, synth.ULA8, pcm[a].astype(np.float64), 1, 0.5, want_map=True)
+        _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=2)
+        ok = (r["bin"][a] == o["bin"]).all()
+        if ok:
+            assert np.abs(r["out"][a] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+        assert np.all(np.abs(np.rad2deg(r["doa"][a, 16:, 0]) - thetas[a]) <= 0.76)
+    ctx.close()
+
+
+def test_gcc_weighting_none_localises_the_references_literal_sines():
+    """mca_hip_config.gcc_weighting = NONE (plain cross-spectrum instead of PHAT; MCA_HIP_SRP_FP32): the reference's literal SRP
+    stimulus -- 1 kHz sines on the 4-microphone Reem-C array, test_mcarray.cpp:384-423 -- localises within its 7 degrees at every
+    angle on the GPU, bins equal to the oracle's under the same weighting; under PHAT (the default) it does not
+    (tests/test_oracle_reference_properties.py keeps that as a strict xfail).  DESIGN.md section 2."""
+    fs, N, F = 48000, 1024, 12
+    ctx = api.Context(fs, synth.REEM_C, N, 5.0, 1, srp_precision=api.SRP_FP32, gcc_weighting=api.GCC_NONE, max_arrays=17)
+    angles = list(range(-80, 81, 10))
+    pcm = np.stack([synth.sine_stream(synth.REEM_C, np.deg2rad(a), fs, (F + 1) * N // 2, 1000.0, 5000.0) for a in angles]).astype(np.float32)
+    r = ctx.process_frames_host(pcm, want_energy=True)
+    for i, a in enumerate(angles):
+        o = po.ssl_stream(fs, N, synth.REEM_C, pcm[i].astype(np.float64), 1, 5.0, want_map=True, weighting="none")
+        _assert_bins(r["bin"][i], o["bin"], o["energy"], ctx.P, max_ties=0)
+        assert np.abs(r["energy"][i] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+        assert np.all(np.abs(np.rad2deg(r["doa"][i, :, 0]) - a) <= 7.0)
+        assert np.abs(r["out"][i] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+    # a broadband source under NONE, 8 microphones, the 0.5 degree grid
+    pcm = synth.noise_source_stream(synth.ULA8, np.deg2rad(33.0), fs, 41 * 512, 5)
+    c8 = api.Context(fs, synth.ULA8, N, 0.5, 1, srp_precision=api.SRP_FP32, gcc_weighting=api.GCC_NONE)
+    r = c8.process_frames_host(pcm[None], want_energy=True)
+    o = po.ssl_stream(fs, N, synth.ULA8, pcm.astype(np.float64), 1, 0.5, want_map=True, weighting="none")
+    _assert_bins(r["bin"][0], o["bin"], o["energy"], c8.P, max_ties=1)
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+    c8.close()
+    # fp16 operands cannot carry un-normalised spectra: refused, not silently whitened
+    with pytest.raises(api.MCArrayHipError):
+        api.Context(fs, synth.ULA8, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, gcc_weighting=api.GCC_NONE)

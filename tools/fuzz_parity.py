@@ -7,14 +7,17 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from mcarray_amd import api, synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
+import parity_helpers  # noqa: E402
 
 os.environ.setdefault("MCA_HIP_ADAPT_MIN_ROWS", "128")      # let the adaptive mode run on the small batches the oracle can follow
 TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: 2e-4}
-# a DOA-bin difference is a numerical tie if the ORACLE's normalised energies at the two bins are closer than this
-# (ADAPTIVE: held to the bar of the exact modes -- its bins are those of FP16X3)
-TIE = {api.SRP_FP32: 1e-5, api.SRP_FP16X3: 1e-5, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: 1e-5}
+# a DOA-bin difference is CLASSIFIED if the oracle's own pick on that frame is fragile under perturbations of this size of the
+# normalised energies (mca_or_select_doa_fragile: peak ties, sign-chain ties, zero picks; tests/parity_helpers.py) -- the bar of
+# the GPU tests for the exact modes (ADAPTIVE is held to it: its bins are those of FP16X3), the mode's own error for plain fp16
+TIE = {api.SRP_FP32: parity_helpers.EPS_TIE, api.SRP_FP16X3: parity_helpers.EPS_TIE, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: parity_helpers.EPS_TIE}
 
 
 def main(cases, seed, only_prec=None, adaptive_shapes=False):
@@ -62,11 +65,10 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False):
                 scale = np.abs(o["energy"]).max() + 1e-300
                 err = np.abs(r["energy"][a] - o["energy"]).max() / scale
                 assert err <= TOL_E[prec], "energy error %.2e" % err
-                mism = np.argwhere(r["bin"][a] != o["bin"])
-                for t, s_ in mism:
-                    g, ob = int(r["bin"][a, t, s_]), int(o["bin"][t, s_])
-                    En = (o["energy"][t] + 15.0 * ctx.P) / (30.0 * ctx.P)
-                    assert abs(En[g] - En[ob]) < TIE[prec], "bin %d vs %d at frame %d (oracle energies differ by %.1e)" % (g, ob, t, abs(En[g] - En[ob]))
+                mism = np.unique(np.argwhere(r["bin"][a] != o["bin"])[:, 0])
+                for t in mism:
+                    assert po.select_doa_fragile(o["energy"][t], ctx.P, S, TIE[prec]), \
+                        "UNCLASSIFIED bin difference at frame %d: gpu %s oracle %s (the oracle's pick is pinned at %.0e)" % (t, r["bin"][a, t].tolist(), o["bin"][t].tolist(), TIE[prec])
                     ties += 1
                 if len(mism):
                     continue            # a flipped near-tie steers the beamformer elsewhere: the audio is not comparable
@@ -82,7 +84,8 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False):
         except Exception as e:  # noqa: BLE001
             bad += 1
             print("FAIL", tag, "--", e, "| cut", locals().get("cut"), "repair", ctx.repair_stats() if prec == api.SRP_ADAPTIVE else None)
-    print("%d cases, %d failures, %d cases went through the adaptive path, %d oracle-level ties in total" % (cases, bad, n_adaptive, n_ties))
+    print("%d cases, %d failures (unclassified bin differences, energy / audio errors, refused shapes), %d cases went through the adaptive path, "
+          "%d classified differences (oracle-fragile frames) in total" % (cases, bad, n_adaptive, n_ties))
     return bad
 
 
