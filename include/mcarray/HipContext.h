@@ -18,7 +18,7 @@ public:
                bool usePowerFloor, int srpPrecision = MCA_HIP_SRP_FP32, int maxArrays = 1, int device = 0)
     {
         std::vector<double> xyz = mics.xyz();
-        mca_hip_config cfg;
+        mca_hip_config cfg = mca_hip_config();     // zeroed: fields appended later (gcc_weighting: 0 = PHAT) keep their defaults
         cfg.struct_size = static_cast<int>(sizeof(cfg));
         cfg.device = device;
         cfg.sample_rate = sampleRate;

@@ -412,7 +412,7 @@ static void testAdaptivePrecisionAndPageLockedBuffers()
     const size_t nfs = static_cast<size_t>(A) * F * S;
     std::vector<int> bin_x(nfs);
     std::vector<float> rad_x(nfs), prob_x(nfs);
-    mca_hip_config cfg;
+    mca_hip_config cfg = mca_hip_config();       // zero first: fields a caller does not know yet (gcc_weighting) keep their defaults
     cfg.struct_size = static_cast<int>(sizeof(cfg)); cfg.device = 0; cfg.sample_rate = fs; cfg.fft_size = N; cfg.n_mics = M;
     cfg.mic_xyz = xyz.data(); cfg.doa_step_deg = 0.5; cfg.n_sources = S; cfg.use_power_floor = 0; cfg.max_arrays = A;
     mca_hip_ctx *cx = nullptr, *ca = nullptr;

@@ -183,7 +183,7 @@ def test_adaptive_with_power_gate_equals_fp16x3_at_full_size():
 def test_adaptive_fine_grid_dp512(force_small):
     """a 0.4 degree grid (451 angles, Dp = 576 > 512 columns): the second pick's LDS tile exceeds 64 KiB and needs the
     dynamic-shared-memory opt-in (k_scan_repick); bins against the oracle."""
-    fs, N, F = 48000, 1024, 150
+    fs, N, F = 48000, 1024, 330
     pcm = synth.noise_source_stream(synth.ULA8, np.deg2rad(-17.3), fs, (F + 1) * N // 2, 31)
     ctx = api.Context(fs, synth.ULA8, N, 0.4, 1, srp_precision=api.SRP_ADAPTIVE)
     assert ctx.D == 451
