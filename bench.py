@@ -36,6 +36,7 @@ BYTES_PER_FRAME = M * HOP * 4 + HOP * 4 + 8          # 18 440 B (PCM 
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0 TB/s spec
 PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0, "adaptive": 2500.0}   # dense MFMA peaks, same guide
 PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2, "adaptive": 3}
+ROW_PAD = 64                                           # floats of padding behind every channel row of the synthetic input (synth_batch)
 PROFILE_TAG = "r02"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
 
 
@@ -46,7 +47,10 @@ def synth_batch(xs, seeds, n_frames, device, noise=0.01):
     L = (n_frames + 1) * HOP
     xs_t = torch.tensor(xs, device=device, dtype=torch.float64)
     theta = torch.empty(n_arrays, device=device, dtype=torch.float64)
-    out = torch.empty(n_arrays, n_mics, L, device=device, dtype=torch.float32)
+    # channel rows are ROW_PAD floats longer than their (F + 1) * hop samples (the C ABI takes the strides): a row pitch of a power
+    # of two plus a little -- 257 half frames = 2^19 + 2^11 bytes at 128 arrays x 256 frames -- lines the loads of all resident
+    # waves up on the same few HBM channels (k_beamform_wave 0.33 instead of 0.295 ms)
+    out = torch.zeros(n_arrays, n_mics, L + ROW_PAD, device=device, dtype=torch.float32)
     f = torch.fft.rfftfreq(L, d=1.0 / FS).to(device=device, dtype=torch.float64)
     for a in range(n_arrays):   # one array at a time keeps the fp64 temporaries small
         gen = torch.Generator(device=device).manual_seed(seeds[a])
@@ -56,7 +60,7 @@ def synth_batch(xs, seeds, n_frames, device, noise=0.01):
         adv = xs_t * torch.sin(theta[a]) / 346.1
         x = torch.fft.irfft(S[None, :] * torch.exp(2j * np.pi * f[None, :] * adv[:, None]), n=L, dim=1)
         x = x + torch.randn(n_mics, L, device=device, dtype=torch.float64, generator=gen) * noise
-        out[a] = x.clamp_(-1.0, 1.0).to(torch.float32)
+        out[a, :, :L] = x.clamp_(-1.0, 1.0).to(torch.float32)
     return out, theta
 
 

@@ -1,11 +1,11 @@
 #!/bin/bash
 # HBM traffic of every mca:: kernel from rocprofv3 PMC counters, two separate passes (FETCH_SIZE costs 3 of the
 # 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots").  usage: tools/pmc_traffic.sh <precision> <outdir>
-prec=${1:-fp16x3}; out=${2:-gpurun_out/pmc_traffic}
+prec=${1:-fp16x3}; out=${2:-gpurun_out/pmc_traffic}; extra=${3:-}       # extra: more bench.py flags, e.g. "--arrays 128 --frames 256"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --single-stream 0 --precision $prec > $out/$ctr.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --single-stream 0 --precision $prec $extra > $out/$ctr.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json
