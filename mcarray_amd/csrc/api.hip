@@ -83,6 +83,7 @@ struct mca_hip_ctx {
     Workspace lanes[MCA_MAX_LANES];
     int cur_lane = 0, a0 = 0;              // the workspace in use and the first array of the piece being enqueued (host side, sequential)
     long long plan_rows = 0;               // > 0: rows of the whole call while it is worked off in pieces (plan_gemm)
+    int plan_arrays = 0;                   // ... and its arrays (repair_ksplit_for)
     int n_lanes_last = 1;
     hipStream_t io_stream[3] = {}; hipEvent_t io_ev[8] = {};   // host-pointer entry points with page-locked buffers: copy in / run / copy out
     Workspace &ws() { return lanes[cur_lane]; }
@@ -395,6 +396,18 @@ bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames)
            rows >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
 }
 
+// K segments of the repair contraction: by the shape of the (whole) call only.  The tails of every array -- REPAIR_WARM + 1 rows
+// rounded up to repair units -- are always recomputed: a few arrays leave a few hundred rows, where 32 segments fill the chip;
+// 128 arrays leave thousands, where 32 partial maps per row cost more (k_repair_patch reads them all) than they buy.
+int repair_ksplit_for(const mca_hip_ctx *c, int n_arrays)
+{
+    static const int env = std::getenv("MCA_HIP_REPAIR_KSPLIT") ? std::atoi(std::getenv("MCA_HIP_REPAIR_KSPLIT")) : 0;
+    if (env > 0) return std::min(env, REPAIR_KSPLIT_MAX);
+    const long long arrays = c->plan_arrays > 0 ? c->plan_arrays : n_arrays;
+    const long long tail_rows = arrays * (REPAIR_WARM + 1 + REPAIR_GROUP);
+    return tail_rows <= 1024 ? 32 : (tail_rows <= 2560 ? 16 : 8);
+}
+
 // rows of one repair pass (the two-plane A rows of all listed groups may not fit the workspace budget at once)
 long long repair_pass_rows(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
@@ -453,7 +466,7 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
     const int rc = ensure_a(c, rows);
     set_call_planes(c, planes);
     if (rc) return rc;
-    const size_t need_cx = (size_t)repair_cx_rows(rows) * c->Dp * sizeof(float);
+    const size_t need_cx = (size_t)repair_cx_rows(rows, REPAIR_KSPLIT_MAX) * c->Dp * sizeof(float);
     if (need_cx > c->ws().cx_bytes) {
         if (c->ws().d_Cx) (void)hipFree(c->ws().d_Cx);
         c->ws().d_Cx = nullptr; c->ws().cx_bytes = 0;
@@ -1108,13 +1121,14 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
             ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
             ga.n_list = c->ws().d_nlist; ga.list0 = (int)g0;
+            ga.repair_ksplit = repair_ksplit_for(c, n_arrays);
             const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
-            const long long max_work = (pass_rows + 127) / 128 * col_tiles * REPAIR_KSPLIT;
+            const long long max_work = (pass_rows + 127) / 128 * col_tiles * ga.repair_ksplit;
             dim3 gg((unsigned)std::min<long long>(max_work, 768));
             if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
             else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
             RepairPatchArgs pp{};
-            pp.Cx = c->ws().d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles;
+            pp.Cx = c->ws().d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit;
             pp.list = c->ws().d_list; pp.n_list = c->ws().d_nlist; pp.list0 = (int)g0; pp.groups_per_array = gpa; pp.need = c->ws().d_need;
             pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames; pp.Dp = c->Dp;
             hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);
@@ -1535,7 +1549,7 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
     // on every exit -- also the early ones of HIP_TRY -- the planning override is dropped and the streams are drained
     struct Guard {
         mca_hip_ctx *c; hipStream_t s[3];
-        ~Guard() { c->plan_rows = 0; c->a0 = 0; for (hipStream_t q : s) (void)hipStreamSynchronize(q); }
+        ~Guard() { c->plan_rows = 0; c->plan_arrays = 0; c->a0 = 0; for (hipStream_t q : s) (void)hipStreamSynchronize(q); }
     } guard{c, {s_in, s_run, s_out}};
     // (with the power gate the call stays one chunk: mca_hip_copy_gate reads the flags of the whole call from one workspace)
     const int nchunk = c->cfg.use_power_floor ? 1 : std::min(n_arrays, MAXC);
@@ -1550,6 +1564,7 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
     }
     a0 = 0;
     c->plan_rows = (long long)n_arrays * n_frames;           // every chunk is planned as the whole call (bit-identical results)
+    c->plan_arrays = n_arrays;
     for (int k = 0; k < nchunk && !rc; ++k) {
         const int na = n_arrays / nchunk + (k < n_arrays % nchunk ? 1 : 0);
         HIP_TRY(c, hipStreamWaitEvent(s_run, c->io_ev[k], 0));
@@ -1572,7 +1587,7 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
         if (out_pcm && out_pinned[4]) HIP_TRY(c, hipMemcpyAsync(out_pcm + a0 * fo_, d_out + a0 * fo_, na * fo_ * 4, hipMemcpyDeviceToHost, s_out));
         a0 += na;
     }
-    c->plan_rows = 0;
+    c->plan_rows = 0; c->plan_arrays = 0;
     (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(s_run); (void)hipStreamSynchronize(s_out);
     if (rc) return rc;
     c->last_arrays = n_arrays; c->last_frames = n_frames;

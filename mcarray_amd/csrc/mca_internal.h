@@ -25,8 +25,14 @@ constexpr int SCAN_SUB = MCA_SCAN_SUB;      // frames per LDS sub-batch of k_sca
 #define MCA_SCAN_LD 8
 #endif
 constexpr int SCAN_LD = MCA_SCAN_LD;        // map rows (x split-K planes) a thread of the scan kernels keeps in flight (16 / 32 measured slower: 0.939 / 0.955 vs 0.939 ms per step)
-constexpr int REPAIR_WARM = 24;   // exact rows recomputed BEFORE a flagged frame (adaptive SRP precision): 0.8^25 = 3.8e-3 of the coarse error
-                                  // remains, i.e. ~6e-8 of the map's peak -- 30 x below the error of the three-product split itself
+#ifndef MCA_REPAIR_WARM
+#define MCA_REPAIR_WARM 16
+#endif
+constexpr int REPAIR_WARM = MCA_REPAIR_WARM;   // exact rows recomputed BEFORE a flagged frame (adaptive SRP precision): 0.8^17 = 2.3e-2 of the coarse
+                                  // error (~1.6e-5 of the map's peak) remains, i.e. ~3.6e-7 of the peak -- five times below the error of the
+                                  // three-product split itself and below the 1e-6 tie bar of the parity tests.  (Round 2 used 24 rows,
+                                  // 0.8^25: the always-recomputed tail of every array and call is what the repair pass mostly works on
+                                  // when a call has many arrays and few frames -- 128 x 256: 13.9 % of the rows with 24, 10.7 % with 16.)
 constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mode pass of a k_stft_phat workgroup
 
 struct StftPhatArgs {
@@ -83,6 +89,7 @@ struct GemmArgs {
     const void *Bt;          // fp16 steering table tiled for the 256 x 384 kernel: [plane][Kp/32][Dp][32] (a K stage of all columns is contiguous)
     // device-side row count (repair pass): rows = min(rows, (*n_list - list0) * REPAIR_GROUP); workgroups beyond it exit
     const int *n_list; int list0;
+    int repair_ksplit;       // K segments of k_srp_gemm_repair (shape-dependent, see REPAIR_KSPLIT_MAX)
     // chunk-local scan result from the contraction's epilogue (256 x 384 kernel, one map, no gate, 32-row blocks = scan chunks):
     // part[arr][chunk][d] = sum_t scan_w[t] C[t][d] = the recursion E = 0.8f E + 0.2f C run from zero over the chunk's frames
     float *part; int *nvoiced; int D, n_chunks;
@@ -118,18 +125,18 @@ struct ScanPickArgs {
     unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
 };
 
-constexpr int REPAIR_KSPLIT = 32;
-// The repair contraction runs on however many rows the coarse pass listed (a device-side count, usually a few hundred): the
-// K range is what parallelises.  It is always cut into the same REPAIR_KSPLIT segments, whatever the row count, so that an
-// exact row's value does not depend on how many other rows were listed with it (a call worked off in chunks returns the
-// same bits).  Partial maps: [REPAIR_KSPLIT][repair_plane_stride], summed in order by k_repair_patch.
-__host__ __device__ inline int repair_ksplit(int, int) { return REPAIR_KSPLIT; }
+// The repair contraction runs on however many rows the coarse pass listed (a device-side count): the K range is what
+// parallelises.  It is cut into a number of segments that depends on the SHAPE of the call only (api.hip, repair_ksplit_for:
+// 32 for a few arrays, 8 when the always-recomputed tails of many arrays make thousands of rows), never on how many rows were
+// listed, so that an exact row's value does not depend on what was listed with it (a call worked off in chunks returns the
+// same bits).  Partial maps: [ksplit][repair_plane_stride], summed in order by k_repair_patch.
+constexpr int REPAIR_KSPLIT_MAX = 32;
 __host__ __device__ inline long long repair_plane_stride(int n_rows, int Dp) { return (long long)((n_rows + 127) / 128 * 128) * Dp; }
-__host__ __device__ inline long long repair_cx_rows(long long pass_rows) { return ((pass_rows + 127) / 128 * 128) * REPAIR_KSPLIT; }
+__host__ __device__ inline long long repair_cx_rows(long long pass_rows, int ksplit) { return ((pass_rows + 127) / 128 * 128) * ksplit; }
 
 struct RepairPatchArgs {
     const float *Cx;         // [repair_ksplit][repair_plane_stride] exact rows, split-K partial maps
-    int pass_rows, col_tiles;
+    int pass_rows, col_tiles, ksplit;
     const int *list; const int *n_list; int list0, groups_per_array;
     int *need;               // the groups' test-and-set words, released here
     float *C;                // [c_planes][arrays][n_frames][Dp]: plane 0 takes the exact row, the others zeros
