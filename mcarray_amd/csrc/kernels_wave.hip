@@ -238,6 +238,13 @@ __device__ __forceinline__ void store_a_wave(float *row, unsigned voff, int cidx
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row + 2 * cidx) + 2 * voff) = v;
 }
 
+__device__ __forceinline__ unsigned or3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT>
 __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
 {
@@ -297,12 +304,10 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
             for (int pr = 0; pr < NP; ++pr) {
                 float2 z[16];
                 // a channel of exact zeros? (any set bit below the sign)
-                unsigned oa = 0, ob = 0;
+                unsigned oa = __float_as_uint(xa[0]), ob = __float_as_uint(xb[0]);
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    oa |= __float_as_uint(xa[i]) | __float_as_uint(xa[i + 1]);
-                    ob |= __float_as_uint(xb[i]) | __float_as_uint(xb[i + 1]);
-                }
+                for (int i = 1; i < 15; i += 2) { oa = or3(oa, __float_as_uint(xa[i]), __float_as_uint(xa[i + 1])); ob = or3(ob, __float_as_uint(xb[i]), __float_as_uint(xb[i + 1])); }
+                oa |= __float_as_uint(xa[15]); ob |= __float_as_uint(xb[15]);
                 const bool alive_a = __any((oa << 1) != 0), alive_b = __any((ob << 1) != 0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
@@ -312,28 +317,33 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                     load_pair(last ? f : (lastp ? frame_of(fi + 1) : f), last ? pr : (lastp ? 0 : pr + 1));
                 }, lam);
                 // z[q] = Z[lam + 64 dr16(q)];  the register of bin index s is dr16(s)
+                // The mirror Z[1024 - k] of the lane's bin k = lam + 64 s (s < 8) is the partner lane's (lane ^ 32) register 15 - s.
+                // Two v_permlane32_swap per register pair (j, j + 4), j = 8..11, leave the partner's register j in slot j + 4 and
+                // the partner's j + 4 in slot j: the mirror of bin s is read from slot mate(15 - s).  Lanes 0 and 32 are their own
+                // mirrors -- lane 32: register 15 - s, lane 0: register (16 - s) & 15 -- and put those into the same slots.
                 if (lane == 0) {
                     const float2 n = z[dr16(8)];
                     nyq[(f - f_begin) * NP + pr] = make_float2(alive_a ? n.x : 0.f, alive_b ? n.y : 0.f);
                     if (POWER) pny += (alive_a ? n.x * n.x : 0.f) + (alive_b ? n.y * n.y : 0.f);          // Nyquist: X_a = Re, X_b = Im
-                    // lane 0 is its own mirror, one register further: slot 15 - s takes register (16 - s) & 15
-                    const float2 z0 = z[dr16(0)];
+                    float2 t[16];
 #pragma unroll
-                    for (int j = 8; j < 15; ++j) z[dr16(j)] = z[dr16(j + 1)];
-                    z[dr16(15)] = z0;
-                } else if (!self) {
-                    // upper halves (s = 8..15) across the half waves: (s, s + 4) swap into each other's places and back
+                    for (int j = 0; j < 16; ++j) t[j] = z[dr16(j)];
 #pragma unroll
-                    for (int s = 8; s < 12; ++s) {
-                        float2 &u = z[dr16(s)], &w = z[dr16(s + 4)];
+                    for (int j = 8; j < 16; ++j) z[dr16(j < 12 ? j + 4 : j - 4)] = t[(j + 1) & 15];       // slot mate(j) <- register j + 1
+                } else if (self) {
+#pragma unroll
+                    for (int j = 8; j < 12; ++j) { const float2 t = z[dr16(j)]; z[dr16(j)] = z[dr16(j + 4)]; z[dr16(j + 4)] = t; }
+                } else {
+#pragma unroll
+                    for (int j = 8; j < 12; ++j) {
+                        float2 &u = z[dr16(j)], &w = z[dr16(j + 4)];
                         swap_rows32(u.x, w.x); swap_rows32(w.x, u.x);
                         swap_rows32(u.y, w.y); swap_rows32(w.y, u.y);
-                        const float2 t = u; u = w; w = t;
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const float2 zk = z[dr16(s)], zm = z[dr16(15 - s)];                                    // Z[k], Z[1024 - k]
+                    const float2 zk = z[dr16(s)], zm = z[dr16(15 - s < 12 ? 15 - s + 4 : 15 - s - 4)];      // Z[k], Z[1024 - k] (slot mate(15 - s))
                     const float2 a2 = make_float2(zk.x + zm.x, zk.y - zm.y);                               // 2 X_a
                     const float2 b2 = make_float2(zk.y + zm.y, zm.x - zk.x);                               // 2 X_b
                     float pwa, pwb;
