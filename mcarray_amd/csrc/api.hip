@@ -1203,16 +1203,23 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         while (!ft_env && wa.ft > 2 && (long long)n_arrays * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
         wa.window = c->d_window; wa.doa_bin = doa_bin; wa.table = c->d_bftab; wa.out = out_pcm;
         wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->H;
-        const int runs = (n_frames + wa.ft - 1) / wa.ft;
-        const size_t smem = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2);
-        time_begin(c, MCA_HIP_K_BEAMFORM, st);
-        const int var = std::getenv("MCA_HIP_BFW_VAR") ? std::atoi(std::getenv("MCA_HIP_BFW_VAR")) & 15 : 12;
-#define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa); \
-                            else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa); break;
         const int abl = std::getenv("MCA_HIP_BFW_ABL") ? std::atoi(std::getenv("MCA_HIP_BFW_ABL")) & 3 : 0;     // measurement only: wrong results
-        if (abl == 1) hipLaunchKernelGGL((k_beamform_wave<false, 14, 1>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa);
-        else if (abl == 2) hipLaunchKernelGGL((k_beamform_wave<false, 14, 2>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa);
-        else if (abl == 3) hipLaunchKernelGGL((k_beamform_wave<false, 14, 3>), dim3((runs + 3) / 4, n_arrays), dim3(256), smem, st, wa);
+        const int var = abl ? 14 : (std::getenv("MCA_HIP_BFW_VAR") ? std::atoi(std::getenv("MCA_HIP_BFW_VAR")) & 15 : 15);
+        // workgroups per array: 4 runs of ft frames each, or (hand-off of the overlap-add carries inside the workgroup, VAR bit 1)
+        // 4 ft - 1 frames.  With the hand-off ft is the smallest run length whose workgroups are all resident at once (two per
+        // CU: 512) -- one workgroup more than that costs a whole extra round.
+        if ((var & 2) && !ft_env) {
+            wa.ft = 2;
+            while (wa.ft < 256 && (long long)n_arrays * ((n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1)) > 512) ++wa.ft;
+        }
+        const int wgs = (var & 2) ? (n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1) : ((n_frames + wa.ft - 1) / wa.ft + 3) / 4;
+        const size_t smem = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2) + ((var & 2) ? 4 * FFT_H * sizeof(float) : 0);
+        time_begin(c, MCA_HIP_K_BEAMFORM, st);
+#define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), dim3(wgs, n_arrays), dim3(256), smem, st, wa); \
+                            else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), dim3(wgs, n_arrays), dim3(256), smem, st, wa); break;
+        if (abl == 1) hipLaunchKernelGGL((k_beamform_wave<false, 14, 1>), dim3(wgs, n_arrays), dim3(256), smem, st, wa);
+        else if (abl == 2) hipLaunchKernelGGL((k_beamform_wave<false, 14, 2>), dim3(wgs, n_arrays), dim3(256), smem, st, wa);
+        else if (abl == 3) hipLaunchKernelGGL((k_beamform_wave<false, 14, 3>), dim3(wgs, n_arrays), dim3(256), smem, st, wa);
         else
         switch (var) {
             BFW_CASE(0) BFW_CASE(1) BFW_CASE(2) BFW_CASE(3) BFW_CASE(4) BFW_CASE(5) BFW_CASE(6) BFW_CASE(7)

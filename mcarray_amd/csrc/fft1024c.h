@@ -148,10 +148,16 @@ struct F1kNoMid { __device__ __forceinline__ void operator()() const {} };
 // Per-lane constants of the transform: the three stage-B twiddles W64^(m kB), m = lane & 15.
 struct F1kLane {
     float2 wb[4];
+    float2 t1[16];     // (fft1024c OPT bit 2) the stage-A twiddles W1024^(lane q) kept in registers: no table read per transform
     __device__ __forceinline__ void init(int lane)
     {
 #pragma unroll
         for (int q = 1; q < 4; ++q) wb[q] = twiddle(((lane & 15) * q) & 63, 64, false);
+    }
+    __device__ __forceinline__ void load_t1(const float2 *tab, int lane)
+    {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t1[q] = tab[lane * 18 + q];
     }
 };
 
@@ -164,14 +170,19 @@ __device__ __forceinline__ void fft1024c(float2 (&v)[16], float2 *buf, int lane,
 {
     // row: the residue k mod 64 this lane receives (default: its own number); any permutation of the lanes reads conflict
     // free as long as every ds_read_b128 lane group sees 16 different rows mod 16
-    constexpr bool SCHED = OPT & 2;
-    // the stage's twiddles are read ahead of its butterflies
+    constexpr bool SCHED = OPT & 2, T1REG = OPT & 4;
+    // the stage's twiddles are read ahead of its butterflies (T1REG: they live in registers)
     float2 tw[16];
-    lds_read16_b128(tw, tab + lane * F1K_ROW);
-    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+    if (!T1REG) {
+        lds_read16_b128(tw, tab + lane * F1K_ROW);
+        if (SCHED) __builtin_amdgcn_sched_barrier(0);
+    }
     fft16<INV>(v);
 #pragma unroll
-    for (int p = 1; p < 16; ++p) v[p] = INV ? cmulc(v[p], tw[dr16(p)]) : cmul(v[p], tw[dr16(p)]);
+    for (int p = 1; p < 16; ++p) {
+        const float2 w = T1REG ? lc.t1[dr16(p)] : tw[dr16(p)];
+        v[p] = INV ? cmulc(v[p], w) : cmul(v[p], w);
+    }
     // register p = 4 q + r holds kA = q + 4 r: the lane row takes r
 #pragma unroll
     for (int q = 0; q < 4; ++q) transpose_rows4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);

@@ -57,131 +57,152 @@ __device__ __forceinline__ float2 win_hi(float a, float b, v2f w)
     return from_v2f(r);
 }
 
-// grid (ceil(runs / 4), arrays) x 256 threads = 4 waves, one run of p.ft frames each.  Every run also analyses the frame
-// before its first one (its second half is the overlap-add carry).  Per frame: for each channel pair the windowed samples
+// grid (workgroups per array, arrays) x 256 threads = 4 waves.  Per frame: for each channel pair the windowed samples
 // (z = (x_a, x_b) w), the 1024-point transform, W += Z T[doa bin]; then the inverse transform of W, whose real part is the
-// beamformed frame.  The run is ONE loop over its (frame, pair) steps with the same loads in every step -- the next step's
-// samples (the last step reloads its own) and this step's table row -- so that the counted waits on the row leave the
-// sample loads in flight behind the transform.  ODD: the last pair has one channel (its imaginary input is zero).
+// beamformed frame.  A wave's work is ONE loop over its (frame, pair) steps with the same loads in every step -- the next
+// step's samples (the last step reloads its own) and this step's table row, requested in the middle of the transform -- so
+// that the counted waits on the row leave the sample loads in flight behind the transform.
+//
+// Overlap-add carries (HANDOFF): a workgroup covers 4 ft - 1 consecutive frames; wave 0 takes the frame BEFORE them too (only
+// its second half counts: the carry into the workgroup's first hop) and ft - 1 frames, waves 1..3 take ft frames each.  A wave
+// does not wait for its predecessor's carry: it keeps the first half of its first frame in registers, the waves leave their
+// final carries in LDS, and after one barrier at the very end each wave adds its predecessor's carry and stores that hop.
+// One frame in 4 ft is analysed twice (without HANDOFF every wave re-analyses the frame before its run: one in ft + 1).
+// ODD: the last pair has one channel (its imaginary input is zero).  VAR: bit 0 stage-A twiddles in registers, bit 1 HANDOFF,
+// bit 2 table row requested in the middle of the transform, bit 3 scheduling barriers (A/B switches; api.hip picks one).
 #ifndef BFW_OCC
 #define BFW_OCC 2
 #endif
 template <bool ODD, int VAR, int ABL>
 __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs p)
 {
-    constexpr bool PF = VAR & 1, TMID = VAR & 4;
-    constexpr int FOPT = ((VAR >> 1) & 1) | ((VAR >> 3) & 1) << 1;
+    constexpr bool T1REG = VAR & 1, HANDOFF = VAR & 2, TMID = VAR & 4;
+    constexpr int FOPT = 1 | ((VAR >> 3) & 1) << 1 | (T1REG ? 4 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *tab = reinterpret_cast<float2 *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
+    float *xcarry = reinterpret_cast<float *>(tab + F1K_TWORDS + 4 * F1K_SCRATCH);      // HANDOFF: [4 waves][512] final carries
     f1k_table_init(tab, tid, 256);
     F1kLane lc;
     lc.init(lane);
     __syncthreads();
+    if (T1REG) lc.load_t1(tab, lane);
 
-    const int a = blockIdx.y, run = blockIdx.x * 4 + wave;
-    const int t0 = run * p.ft;
-    if (t0 >= p.n_frames) return;
-    const int t1 = min(t0 + p.ft, p.n_frames);
+    const int a = blockIdx.y;
+    int t0, t1;
+    if (HANDOFF) {
+        const int w0 = (int)blockIdx.x * (4 * p.ft - 1);                 // the workgroup's first frame
+        t0 = wave == 0 ? w0 : w0 + wave * p.ft - 1;
+        t1 = min(w0 + (wave + 1) * p.ft - 1, p.n_frames);
+    } else {
+        t0 = ((int)blockIdx.x * 4 + wave) * p.ft;
+        t1 = min(t0 + p.ft, p.n_frames);
+    }
+    const bool active = t0 < t1;
     // (Every array is cut at the same frames and the frames of a run go in order -- the overlap-add carry --, so waves that
     // start together stream the same piece of their rows.  Layouts whose row pitch is a power of two plus a little (128 arrays
     // x 257 half frames of 512 floats: 2^19 + 2^11 bytes) then put the loads of all resident waves onto the same few memory
     // channels: 0.33 instead of 0.295 ms per 32 768 frames; 64 floats of padding per row avoid it.  Shifting the run
     // boundaries per array costs an extra, mostly empty round of waves: 0.36 ms.  k_stft_phat_wave rotates its frame order.)
-    const int tfirst = t0 > 0 ? t0 - 1 : 0;
+    const bool lead_in = HANDOFF ? (wave == 0 && t0 > 0) : t0 > 0;       // this wave analyses frame t0 - 1 for its carry
+    const bool deferred = HANDOFF && wave > 0;                           // the carry into hop t0 comes from the wave before
+    const int tfirst = lead_in ? t0 - 1 : t0;
     const int NP = p.n_pairs;
+    float carry[8], first[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { carry[i] = 0.f; first[i] = 0.f; }
 
-    v2f win[8];
+    if (active) {
+        v2f win[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { win[i].x = p.window[lane + 128 * i]; win[i].y = p.window[lane + 128 * i + 64]; }
-    float carry[8];
+        for (int i = 0; i < 8; ++i) { win[i].x = p.window[lane + 128 * i]; win[i].y = p.window[lane + 128 * i + 64]; }
+        if (t0 == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) carry[i] = t0 == 0 ? p.tail_in[(long long)a * FFT_H + lane + 64 * i] : 0.f;
-
-    const float *base = p.pcm + (long long)a * p.array_stride + lane;
-    const int *bins = p.doa_bin + (long long)a * p.n_frames;
-    float xa[16], xb[16];
-    auto load_pair = [&](int t, int pr) {
-        const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)t * FFT_H;
-        const float *pb = (ODD && pr == NP - 1) ? pa : pa + p.mic_stride;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
-    };
-    float pf = 0.f;
-    if (PF) {   // the run's first frames are nowhere yet: touch all of them at once (64-byte pieces, 16 per load and channel quarter)
-        const long long span = (long long)min(4, t1 + 1 - tfirst) * FFT_H;     // samples per channel: frames tfirst .. tfirst + 2
-        for (int c = 0; c < p.M; ++c)
-            for (long long o = lane * 16; o < span; o += 64 * 16) pf += base[(long long)c * p.mic_stride + (long long)tfirst * FFT_H - lane + o];
-    }
-    load_pair(tfirst, 0);
-
-    float2 W[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
-    int t = tfirst, pr = 0;
-    const float2 *trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
-    for (;;) {
-        float2 z[16], T[16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
-        if (ODD && pr == NP - 1) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) z[i].y = 0.f;
+            for (int i = 0; i < 8; ++i) carry[i] = p.tail_in[(long long)a * FFT_H + lane + 64 * i];
         }
-        const bool last_pair = pr == NP - 1, last = last_pair && t + 1 >= t1;
-        if (!TMID) {
+        const float *base = p.pcm + (long long)a * p.array_stride + lane;
+        const int *bins = p.doa_bin + (long long)a * p.n_frames;
+        float xa[16], xb[16];
+        auto load_pair = [&](int t, int pr) {
+            const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)t * FFT_H;
+            const float *pb = (ODD && pr == NP - 1) ? pa : pa + p.mic_stride;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) T[i] = trow[pr * 1024 + 64 * dr16(i)];
+            for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
+        };
+        load_pair(tfirst, 0);
+
+        float2 W[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
+        int t = tfirst, pr = 0;
+        const float2 *trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
+        for (;;) {
+            float2 z[16], T[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
+            if (ODD && pr == NP - 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i].y = 0.f;
+            }
+            const bool last_pair = pr == NP - 1, last = last_pair && t + 1 >= t1;
+            if (!TMID) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) T[i] = trow[pr * 1024 + 64 * dr16(i)];
+                if (FOPT & 2) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(ABL & 1)) load_pair(last ? t : (last_pair ? t + 1 : t), last ? pr : (last_pair ? 0 : pr + 1));
             if (FOPT & 2) __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-            const int tn = last ? t : (last_pair ? t + 1 : t), pn = last ? pr : (last_pair ? 0 : pr + 1);
-            if (!(ABL & 1)) load_pair(tn, pn);
-            // one load that touches every 64-byte piece of this pair's new half frame two frames ahead pulls it into L2
-            // (lane -> channel lane >> 5, piece lane & 31), so that the sample loads of the next frames find it there
-            if (PF) {
-                const int tp = min(t + 2, p.n_frames - 1);
-                pf = *(base - lane + (long long)(2 * pr + ((lane >> 5) && !(ODD && last_pair))) * p.mic_stride + (long long)(tp + 1) * FFT_H + (lane & 31) * 16);
+            fft1024c<false, FOPT>(z, buf, lane, tab, lc, [&]() {
+                if (TMID) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) T[i] = (ABL & 2) ? make_float2(1e-3f * (float)(i + pr), 1e-3f) : trow[pr * 1024 + 64 * dr16(i)];
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < 16; ++i) W[i] = cmac(W[i], z[i], T[i]);
+            if (last_pair) {
+                // W[p] holds bin lane + 64 dr16(p); the inverse takes register i = bin lane + 64 i and returns sample lane + 64 dr16(p)
+                float2 y[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y[i] = W[dr16(i)];
+                fft1024c<true, FOPT>(y, buf, lane, tab, lc);
+                if (t >= t0) {
+                    if (deferred && t == t0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) first[i] = y[dr16(i)].x;
+                    } else {
+                        float *o = p.out + (long long)a * p.n_frames * FFT_H + (long long)t * FFT_H + lane;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[64 * i] = carry[i] + y[dr16(i)].x;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) carry[i] = y[dr16(i + 8)].x;
+                if (last) break;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
+                ++t; pr = 0;
+                trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
+            } else {
+                ++pr;
             }
         }
-        if (FOPT & 2) __builtin_amdgcn_sched_barrier(0);
-        // TMID: the steering row is requested in the middle of the transform (fewest live registers) and used right behind it
-        fft1024c<false, FOPT>(z, buf, lane, tab, lc, [&]() {
-            if (TMID) {
+        if (t1 == p.n_frames) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) T[i] = (ABL & 2) ? make_float2(1e-3f * (float)(i + pr), 1e-3f) : trow[pr * 1024 + 64 * dr16(i)];
-            }
-        });
-#pragma unroll
-        for (int i = 0; i < 16; ++i) W[i] = cmac(W[i], z[i], T[i]);
-        if (last_pair) {
-            // W[p] holds bin lane + 64 dr16(p); the inverse takes register i = bin lane + 64 i and returns sample lane + 64 dr16(p)
-            float2 y[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] = W[dr16(i)];
-            fft1024c<true, FOPT>(y, buf, lane, tab, lc);
-            if (t >= t0) {
-                float *o = p.out + (long long)a * p.n_frames * FFT_H + (long long)t * FFT_H + lane;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[64 * i] = carry[i] + y[dr16(i)].x;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) carry[i] = y[dr16(i + 8)].x;
-            if (last) break;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
-            ++t; pr = 0;
-            trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
-        } else {
-            ++pr;
+            for (int i = 0; i < 8; ++i) p.tail_out[(long long)a * FFT_H + lane + 64 * i] = carry[i];
         }
     }
-    if (t1 == p.n_frames) {
+    if (HANDOFF) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p.tail_out[(long long)a * FFT_H + lane + 64 * i] = carry[i];
+        for (int i = 0; i < 8; ++i) xcarry[wave * FFT_H + lane + 64 * i] = carry[i];
+        __syncthreads();
+        if (active && deferred) {
+            float *o = p.out + (long long)a * p.n_frames * FFT_H + (long long)t0 * FFT_H + lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[64 * i] = xcarry[(wave - 1) * FFT_H + lane + 64 * i] + first[i];
+        }
     }
-    if (pf == 1.2345e-38f) p.tail_out[0] = pf;     // (keeps the touching loads alive)
 }
 
 #define INST_BFW(V) template __global__ void k_beamform_wave<false, V, 0>(BeamformWaveArgs); template __global__ void k_beamform_wave<true, V, 0>(BeamformWaveArgs);
