@@ -75,6 +75,12 @@ struct mca_hip_ctx {
     double *d_micx = nullptr;
     int2 *d_pairs = nullptr;
     void *d_B = nullptr, *d_Bt = nullptr;
+    // ULA, one fp16 operand plane (the ADAPTIVE coarse pass, plain FP16), k_stft_phat_wave: the contraction index is the PRODUCT
+    // m = k * (j - i) -- pairs of spacing g at bin k steer with exp(j 2 pi k g tau_1 / N), so all (k, g) of equal product share one
+    // steering column and their PHAT sums are merged before the contraction: 1 962 instead of 3 591 complex terms per row for 8
+    // microphones (build_merged_tables)
+    bool merged = false; int n_merged = 0, Kp_m = 0;
+    void *d_Bm = nullptr, *d_Btm = nullptr; unsigned short *d_mrank = nullptr;
     float2 *d_bftab = nullptr; int bf_pairs = 0;   // k_beamform_wave: steering rows per grid angle, [D + 1][bf_pairs][1024] (built on first use)
     // stream state (double buffered: kernels read [cur], write [cur^1])
     float *d_E[2] = {nullptr, nullptr};
@@ -161,7 +167,7 @@ void free_ctx(mca_hip_ctx *c)
 {
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt); F(c->d_bftab);
+    F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt); F(c->d_bftab); F(c->d_Bm); F(c->d_Btm); F(c->d_mrank);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
     F(c->d_rstats); F(c->d_gate_state);
@@ -245,6 +251,59 @@ int build_steering_table(mca_hip_ctx *c)
     return MCA_HIP_OK;
 }
 
+// the contraction depth (elements per operand plane) of the current call: the merged index with one plane on a merged context
+int cur_kp(const mca_hip_ctx *c) { return (c->merged && c->a_planes == 1) ? c->Kp_m : c->Kp; }
+
+// Merged contraction index of the one-plane fp16 path on a uniform linear array (see mca_hip_ctx::merged).  The pairs of
+// spacing g have the delay table tau_g(d); on a ULA tau_g = g tau_1 up to the rounding of the reference's float chain
+// (doaToDelayFarFieldSamples, SteeringBeamforming.cpp:73), so exp(j 2 pi k tau_g / N) = exp(j 2 pi (k g) tau_1 / N) to ~1e-5
+// rad -- a twentieth of the fp16 rounding of the operands this path carries anyway; checked here, else no merging.  The exact
+// paths (FP32, FP16X3, the repair pass) keep the per-group index and the reference's own tables.
+int build_merged_tables(mca_hip_ctx *c)
+{
+    c->merged = false;
+    if (!c->ula || c->generic || c->n512 || (c->M != 4 && c->M != 8) || c->Dp % 64 != 0 || std::getenv("MCA_HIP_NO_MERGE") || std::getenv("MCA_HIP_STFT_WG")) return MCA_HIP_OK;
+    if (c->prec != MCA_HIP_SRP_ADAPTIVE && c->prec != MCA_HIP_SRP_FP16) return MCA_HIP_OK;
+    const int K = c->K, D = c->D, Dp = c->Dp, G = c->G;
+    const double N = 2.0 * (K - 1);
+    for (int g = 1; g < G; ++g)
+        for (int d = 0; d < D; ++d)
+            if (std::fabs((double)c->delays[(size_t)g * D + d] - (g + 1) * (double)c->delays[d]) > 1e-4) return MCA_HIP_OK;   // (pair (0, g + 1) has index g)
+    std::vector<unsigned short> rank((size_t)G * (K - 1) + 1, 0xffff);
+    std::vector<int> ms;
+    for (int g = 1; g <= G; ++g)
+        for (int k = 0; k < K; ++k) rank[(size_t)k * g] = 0;
+    for (size_t m = 0; m < rank.size(); ++m)
+        if (rank[m] == 0) { rank[m] = (unsigned short)ms.size(); ms.push_back((int)m); }
+    c->n_merged = (int)ms.size();
+    c->Kp_m = round_up(2 * c->n_merged, 32);
+    const int Kp = c->Kp_m;
+    std::vector<_Float16> B((size_t)Dp * Kp, (_Float16)0.f);
+    for (int d = 0; d < D; ++d)
+        for (int r = 0; r < c->n_merged; ++r) {
+            const double ph = 2.0 * M_PI * (double)ms[(size_t)r] * (double)c->delays[d] / N;
+            B[(size_t)d * Kp + 2 * r] = (_Float16)(float)std::cos(ph);
+            B[(size_t)d * Kp + 2 * r + 1] = (_Float16)(float)(-std::sin(ph));
+        }
+    HIP_TRY(c, hipMalloc(&c->d_Bm, B.size() * sizeof(_Float16)));
+    HIP_TRY(c, hipMemcpy(c->d_Bm, B.data(), B.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    if (Dp == 384) {
+        const int ns32 = Kp / 32;
+        std::vector<_Float16> Bt(B.size());
+        for (int sl = 0; sl < ns32; ++sl)
+            for (int d = 0; d < Dp; ++d)
+                std::memcpy(&Bt[((size_t)sl * Dp + d) * 32], &B[(size_t)d * Kp + (size_t)sl * 32], 32 * sizeof(_Float16));
+        HIP_TRY(c, hipMalloc(&c->d_Btm, Bt.size() * sizeof(_Float16)));
+        HIP_TRY(c, hipMemcpy(c->d_Btm, Bt.data(), Bt.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    }
+    rank.resize((rank.size() + 3) / 4 * 4, 0xffff);
+    HIP_TRY(c, hipMalloc((void **)&c->d_mrank, rank.size() * sizeof(unsigned short)));
+    HIP_TRY(c, hipMemcpy(c->d_mrank, rank.data(), rank.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    c->merged = true;
+    c->a_row_elems = cur_kp(c) * c->a_planes;
+    return MCA_HIP_OK;
+}
+
 void time_begin(mca_hip_ctx *c, int id, hipStream_t st)
 {
     c->timing_open = (c->timing >> id) & 1u;
@@ -290,7 +349,7 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
         // in a handful of workgroups (0.29 ms however few frames); split K until ~512 workgroups exist, keeping
         // at least 8 K steps per workgroup
         const long long wgs = (rows + 127) / 128 * (c->Dp == 64 ? 1 : c->Dp / 192);
-        const int nk = c->Kp / (c->prec == MCA_HIP_SRP_FP32 ? 16 : 32);
+        const int nk = cur_kp(c) / (c->prec == MCA_HIP_SRP_FP32 ? 16 : 32);
         long long ks = 512 / (wgs > 0 ? wgs : 1);
         if (ks > nk / 8) ks = nk / 8;
         if (ks > 16) ks = 16;
@@ -383,7 +442,7 @@ long long chunk_frames_for(const mca_hip_ctx *c, int n_arrays, int n_frames)
 }
 
 // ---- adaptive SRP precision (MCA_HIP_SRP_ADAPTIVE) ------------------------------------------------------------
-void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_row_elems = c->Kp * planes; }
+void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_row_elems = cur_kp(c) * planes; }
 
 // Does a call of this shape run coarse + repair?  The repair pass needs the list mode of k_stft_phat (1024-sample frames,
 // more than two microphones) and has a fixed cost of a few small launches, so small batches -- which are latency bound
@@ -506,21 +565,38 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
             while (!env && w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
             gw = dim3(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
         }
-        const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 4 * w.fpb * (M / 2)) * sizeof(float2);
+        const bool mg = w.mrank != nullptr && !a.list;
+        const int nrank = 2 * (M - 1) * 64 * 4 + 8, regw = mg ? std::max(F1K_SCRATCH, (w.n_merged + 63) & ~63) : F1K_SCRATCH;
+        // (the merged kernel keeps its Nyquist bins in registers: with its 15.5 KiB regions two workgroups just fit the 160 KiB of a CU)
+        const size_t smw = (size_t)(F1K_TWORDS + (mg ? nrank / 4 : 0) + 4 * regw + (mg ? 0 : 4 * w.fpb * (M / 2))) * sizeof(float2);
         const bool pl2 = a.a_planes == 2, pw = a.power != nullptr;
+#define LAUNCH_K(K)                                                                                                 \
+        do {                                                                                                         \
+            if (smw > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw)); \
+            hipLaunchKernelGGL(K, gw, dim3(256), smw, st, w);                                                        \
+        } while (0)
 #define LAUNCH_W2(MT, U, PL2, NP)                                                                                  \
         do {                                                                                                         \
-            if (pw) hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, true, NP>), gw, dim3(256), smw, st, w);   \
-            else hipLaunchKernelGGL((k_stft_phat_wave<MT, U, OutT, PL2, false, NP>), gw, dim3(256), smw, st, w);     \
+            if (pw) LAUNCH_K((k_stft_phat_wave<MT, U, OutT, PL2, true, NP, false>));                                 \
+            else LAUNCH_K((k_stft_phat_wave<MT, U, OutT, PL2, false, NP, false>));                                   \
         } while (0)
 #define LAUNCH_W(MT, U)                                                                                              \
         do {                                                                                                         \
             if constexpr (sizeof(OutT) == 2) { if (pl2) LAUNCH_W2(MT, U, true, false); else LAUNCH_W2(MT, U, false, false); } \
             else { if (a.no_phat) LAUNCH_W2(MT, U, false, true); else LAUNCH_W2(MT, U, false, false); }              \
         } while (0)
+        if constexpr (sizeof(OutT) == 2) {
+            if (mg) {          // merged contraction index: ULA, one plane
+                if (M == 8) { if (pw) LAUNCH_K((k_stft_phat_wave<8, true, OutT, false, true, false, true>)); else LAUNCH_K((k_stft_phat_wave<8, true, OutT, false, false, false, true>)); }
+                else { if (pw) LAUNCH_K((k_stft_phat_wave<4, true, OutT, false, true, false, true>)); else LAUNCH_K((k_stft_phat_wave<4, true, OutT, false, false, false, true>)); }
+                HIP_TRY(c, hipGetLastError());
+                return MCA_HIP_OK;
+            }
+        }
         if (M == 8 && ula) LAUNCH_W(8, true); else if (M == 8) LAUNCH_W(8, false);
         else if (ula) LAUNCH_W(4, true); else LAUNCH_W(4, false);
 #undef LAUNCH_W2
+#undef LAUNCH_K
 #undef LAUNCH_W
         HIP_TRY(c, hipGetLastError());
         return MCA_HIP_OK;
@@ -727,7 +803,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
     }
-    if (c->stream_ok && (rc = build_steering_table(c))) { g_create_error = c->err; free_ctx(c); return rc; }
+    if (c->stream_ok && ((rc = build_steering_table(c)) || (rc = build_merged_tables(c)))) { g_create_error = c->err; free_ctx(c); return rc; }
     if ((rc = init_last_state(c, nullptr))) { g_create_error = c->err; free_ctx(c); return rc; }
     *out = c;
     return MCA_HIP_OK;
@@ -925,6 +1001,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         while (sa.fpb > 1 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 256) sa.fpb >>= 1;
         sa.power = c->cfg.use_power_floor ? c->ws().d_power : nullptr; sa.total_frames = n_frames;
         sa.window = c->d_window; sa.A = a_buf(c); sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = c->a_planes;
+        if (c->merged && c->a_planes == 1) { sa.mrank = c->d_mrank; sa.n_merged = c->n_merged; }
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         sa.no_phat = c->cfg.gcc_weighting == MCA_HIP_GCC_NONE ? 1 : 0;
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
@@ -985,9 +1062,10 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         if (rc) return rc;
 
         GemmArgs ga{};
-        ga.A = a_buf(c); ga.B = c->d_B; ga.C = c->ws().d_C; ga.Bt = c->d_Bt;
+        const bool mg = c->merged && c->a_planes == 1;
+        ga.A = a_buf(c); ga.B = mg ? c->d_Bm : c->d_B; ga.C = c->ws().d_C; ga.Bt = mg ? c->d_Btm : c->d_Bt;
         ga.rows = n_arrays * nf; ga.chunk_frames = nf; ga.total_frames = n_frames; ga.frame0 = f0;
-        ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
+        ga.Kp = cur_kp(c); ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems;
         ga.c_plane_elems = (long long)n_arrays * n_frames * c->Dp;
         if (fused_partial) {
             ga.part = c->ws().d_part; ga.nvoiced = c->ws().d_nv; ga.D = c->D; ga.n_chunks = n_frames / SCAN_CHUNK;

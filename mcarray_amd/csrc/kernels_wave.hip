@@ -266,16 +266,41 @@ __device__ __forceinline__ unsigned or3(unsigned a, unsigned b, unsigned c)
     return r;
 }
 
-template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT>
+typedef __attribute__((address_space(3))) float lds_float_t;
+
+// MERGE (ULA, one fp16 plane): the contraction index is the product m = k (j - i) -- all (bin, spacing) combinations of equal
+// product share one steering column (api.hip, build_merged_tables), so their PHAT sums are added up before they are stored:
+// the lane's 8 x (M - 1) sums go into the wave's LDS region (the transform's scratch, free by then) with ds_add_f32 at
+// rank[m] -- every instruction hits 64 different words and the instructions of a wave execute in order, so the sums are
+// formed in a fixed order --, and the region is read back as the row: n_merged instead of (M - 1) * 513 complex values.
+template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT, bool MERGE>
 __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
 {
+    static_assert(!MERGE || (ULA && !PL2 && !NOPHAT && sizeof(OutT) == 2), "the merged index serves the one-plane fp16 rows of a ULA");
     constexpr int NP = MT / 2, NOUT = PairOut<MT, ULA>::N;
+    constexpr int NRANK = 2 * (MT - 1) * 64 * 4 + 8;                              // u16 entries of the offset table (+ the Nyquist bin's)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *tab = reinterpret_cast<float2 *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
-    float2 *nyq = tab + F1K_TWORDS + 4 * F1K_SCRATCH + wave * (p.fpb * NP);      // [fpb][NP] Z_p[512] of the run's frames
+    // LDS: twiddles | MERGE: rank table | per wave: transform scratch (MERGE: also the merged sums, whichever is larger) | Nyquist bins
+    const unsigned short *rankl = reinterpret_cast<const unsigned short *>(tab + F1K_TWORDS);
+    const int nmp = MERGE ? (p.n_merged + 63) & ~63 : 0;                           // merged sums, rounded up to whole wave rows
+    const int regw = MERGE ? max(F1K_SCRATCH, nmp) : F1K_SCRATCH;                  // float2 words per wave
+    float2 *wbase = tab + F1K_TWORDS + (MERGE ? NRANK / 4 : 0);
+    float2 *buf = wbase + wave * regw;
+    float2 *nyq = wbase + 4 * regw + wave * (p.fpb * NP);                         // [fpb][NP] Z_p[512] of the run's frames (not MERGE)
     f1k_table_init(tab, tid, 256);
+    if (MERGE) {
+        // per lane, spacing g and half h: the region offsets (in words) of its four products k g, k = lam + 64 (4 h + s):
+        // [2 (g - 1) + h][lane][4] u16 -- one ds_read_b64 per batch; behind them rank[512 g], the Nyquist bin's
+        unsigned short *ot = reinterpret_cast<unsigned short *>(tab + F1K_TWORDS);
+        for (int e = tid; e < 2 * (MT - 1) * 64 * 4; e += 256) {
+            const int s4 = e & 3, ln = (e >> 2) & 63, gh = e >> 8, g = (gh >> 1) + 1, h = gh & 1;
+            const int lm = ln <= 32 ? ln : 96 - ln;
+            ot[e] = p.mrank[(lm + 64 * (4 * h + s4)) * g];
+        }
+        if (tid < MT - 1) ot[2 * (MT - 1) * 64 * 4 + tid] = p.mrank[512 * (tid + 1)];
+    }
     F1kLane lc;
     lc.init(lane);
     __syncthreads();
@@ -319,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         load_pair(frame_of(0), 0);
         for (int fi = 0; fi < nfr; ++fi) {
             const int f = frame_of(fi);
-            float2 Xh[MT][8];
+            float2 Xh[MT][8], zn[NP];
             float pall = 0.f, pdc = 0.f, pny = 0.f;
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
@@ -342,9 +367,10 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                 // Two v_permlane32_swap per register pair (j, j + 4), j = 8..11, leave the partner's register j in slot j + 4 and
                 // the partner's j + 4 in slot j: the mirror of bin s is read from slot mate(15 - s).  Lanes 0 and 32 are their own
                 // mirrors -- lane 32: register 15 - s, lane 0: register (16 - s) & 15 -- and put those into the same slots.
+                if (MERGE) zn[pr] = make_float2(alive_a ? z[dr16(8)].x : 0.f, alive_b ? z[dr16(8)].y : 0.f);     // (lane 0's is the Nyquist bin)
                 if (lane == 0) {
                     const float2 n = z[dr16(8)];
-                    nyq[(f - f_begin) * NP + pr] = make_float2(alive_a ? n.x : 0.f, alive_b ? n.y : 0.f);
+                    if (!MERGE) nyq[(f - f_begin) * NP + pr] = make_float2(alive_a ? n.x : 0.f, alive_b ? n.y : 0.f);
                     if (POWER) pny += (alive_a ? n.x * n.x : 0.f) + (alive_b ? n.y * n.y : 0.f);          // Nyquist: X_a = Re, X_b = Im
                     float2 t[16];
 #pragma unroll
@@ -378,14 +404,65 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                 }
             }
             OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f) * (long long)p.a_row_elems;
+            if (MERGE) {
+                // One spacing g at a time: the products k g of a lane's eight bins -- of all lanes' bins -- are all different for a
+                // fixed g, so the eight read-add-write sequences of a batch never touch a word twice; batches follow each other in
+                // program order (the LDS executes a wave's instructions in order).  (ds_add_f32 would do the same without the
+                // batches, but runs at one lane every ~2.5 cycles: 1.5 ms per 32 768 frames instead of 0.27.)
+                float2 *S = buf;
+                for (int j = lane; j < nmp; j += 64) S[j] = make_float2(0.f, 0.f);
+                wave_lds_fence();
+                float xn[MT];                                                     // lane 0: the Nyquist bin (real: X_a = Re Z, X_b = Im Z), whitened
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                float2 r[MT], out[NOUT];
+                for (int pr = 0; pr < NP; ++pr) {
+                    float pw;
+                    xn[2 * pr] = whiten4(make_float2(2.f * zn[pr].x, 0.f), pw).x;
+                    xn[2 * pr + 1] = whiten4(make_float2(2.f * zn[pr].y, 0.f), pw).x;
+                }
+                const uint2 *offt = reinterpret_cast<const uint2 *>(rankl) + lane;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) r[m] = Xh[m][s];
-                pair_products<MT, ULA>(r, out);
+                for (int g = 1; g < MT; ++g) {
 #pragma unroll
-                for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, voff, g * KG + 64 * s, out[g], p.Kp);
+                    for (int h = 0; h < 2; ++h) {                                 // four bins at a time (registers)
+                        const uint2 o4 = offt[(2 * (g - 1) + h) * 64];
+                        const unsigned off[4] = {o4.x & 0xffffu, o4.x >> 16, o4.y & 0xffffu, o4.y >> 16};
+                        float2 acc[4], cur[4];
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) {
+                            acc[s2] = make_float2(0.f, 0.f);
+#pragma unroll
+                            for (int i = 0; i + g < MT; ++i) acc[s2] = cmacc(acc[s2], Xh[i][4 * h + s2], Xh[i + g][4 * h + s2]);
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) cur[s2] = S[off[s2]];
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) S[off[s2]] = cadd(cur[s2], acc[s2]);
+                    }
+                    if (lane == 0) {
+                        float an = 0.f;
+#pragma unroll
+                        for (int i = 0; i + g < MT; ++i) an = fmaf(xn[i], xn[i + g], an);
+                        const unsigned on = rankl[2 * (MT - 1) * 64 * 4 + g - 1];
+                        S[on].x += an;
+                    }
+                    wave_lds_fence();
+                }
+                for (int j = lane; j < p.n_merged; j += 64) {
+                    const float2 v = S[j];
+                    const float2_t vv = {v.x, v.y};
+                    reinterpret_cast<half2_t *>(arow)[j] = __builtin_convertvector(vv, half2_t);
+                }
+                wave_lds_fence();                                                  // (the next frame's transform reuses the region)
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    float2 r[MT], out[NOUT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) r[m] = Xh[m][s];
+                    pair_products<MT, ULA>(r, out);
+#pragma unroll
+                    for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, voff, g * KG + 64 * s, out[g], p.Kp);
+                }
             }
             if (POWER) {
                 // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2 over the channels, / M;
@@ -398,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         }
         // Nyquist bins of the run: lane = frame
         wave_lds_fence();
-        if (lane < f_end - f_begin) {
+        if (!MERGE && lane < f_end - f_begin) {
             float2 xn[MT], out[NOUT];
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
@@ -416,10 +493,14 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
     }
 }
 
-#define INST_SPW1(MT, ULA, T, PL2, NP) template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, false, NP>(StftPhatArgs); \
-                                       template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, true, NP>(StftPhatArgs);
+#define INST_SPW1(MT, ULA, T, PL2, NP) template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, false, NP, false>(StftPhatArgs); \
+                                       template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, true, NP, false>(StftPhatArgs);
 #define INST_SPW(MT, ULA) INST_SPW1(MT, ULA, _Float16, false, false) INST_SPW1(MT, ULA, _Float16, true, false) INST_SPW1(MT, ULA, float, false, false) \
                           INST_SPW1(MT, ULA, float, false, true)
 INST_SPW(8, true) INST_SPW(8, false) INST_SPW(4, true) INST_SPW(4, false)
+template __global__ void k_stft_phat_wave<8, true, _Float16, false, false, false, true>(StftPhatArgs);
+template __global__ void k_stft_phat_wave<8, true, _Float16, false, true, false, true>(StftPhatArgs);
+template __global__ void k_stft_phat_wave<4, true, _Float16, false, false, false, true>(StftPhatArgs);
+template __global__ void k_stft_phat_wave<4, true, _Float16, false, true, false, true>(StftPhatArgs);
 
 }  // namespace mca

@@ -52,6 +52,8 @@ struct StftPhatArgs {
     // list mode (k_stft_phat only; the repair pass of the adaptive SRP precision): workgroup b takes the REPAIR_GROUP frames of
     // list[list0 + b] = array * groups_per_array + group and writes A rows b * REPAIR_GROUP ...; b >= *n_list - list0 exits
     const int *list; const int *n_list; int list0, list_cap, groups_per_array;   // list_cap: groups of this pass at most
+    const unsigned short *mrank; int n_merged;   // k_stft_phat_wave, merged index (ULA, one fp16 plane): rank of the product m = k (j - i)
+                             // among the n_merged distinct ones, [(M - 1) * 512 + 1]; NULL: per-group index g * 513 + k
     int no_phat;             // 1: gcc_weighting NONE -- the pair products of the spectra themselves (k_stft_phat_wave, fp32 rows only)
 };
 
