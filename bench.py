@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0
 PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0, "adaptive": 2500.0}   # dense MFMA peaks, same guide
 PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2, "adaptive": 3}
 ROW_PAD = 64                                           # floats of padding behind every channel row of the synthetic input (synth_batch)
-PROFILE_TAG = "r02"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
+PROFILE_TAG = "r03"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
 
 
 def synth_batch(xs, seeds, n_frames, device, noise=0.01):
@@ -120,11 +120,13 @@ def traffic_from_profiles(roof, dom, precision, shape_matches):
     run -- a --pmc pass serialises the kernels and cannot share a process with the timed loop."""
     tj = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_TAG, precision))
     if os.path.exists(tj) and shape_matches:
-        kk = json.load(open(tj))["kernels"].get(dom)
-        if kk:   # gfx950 correction: FETCH_SIZE reports half of a wide coalesced read stream
-            roof["traffic"] = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0
-            roof["traffic_unit"] = ("bytes per step of this kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes; in the adaptive mode "
-                                    "k_stft_phat's figure includes its second, list-mode launch of the repair pass: ~3 %)")
+        kernels = json.load(open(tj))["kernels"]
+        # timing group -> kernel of the committed summary (round 3: the wave-per-run kernels serve the bench shape)
+        kk = kernels.get({"k_stft_phat": "k_stft_phat_wave", "k_beamform_ola": "k_beamform_wave"}.get(dom, dom)) or kernels.get(dom)
+        if kk:   # gfx950: FETCH_SIZE reports half of a WIDE coalesced read stream; the summary carries the factor per kernel
+            roof["traffic"] = kk.get("hbm_bytes_per_step", (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0)
+            roof["traffic_unit"] = ("bytes per step of this kernel (rocprofv3 FETCH_SIZE x fetch_factor + WRITE_SIZE, separate PMC passes; in the "
+                                    "adaptive mode the analysis kernel's figure includes its second, list-mode launch of the repair pass: ~3 %)")
             roof["traffic_source"] = "profiles/%s_pmc_traffic_%s.json (committed PMC passes of the same command on an MI355X; not this run)" % (PROFILE_TAG, precision)
 
 
@@ -252,7 +254,7 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
                                     "sample": "one array per thread, %d frames each, %.1f s wall" % (nfa, dt_all)}
         if world == 1 and args.single_stream:
             # the literal BASELINE configs[2]: ONE 8-mic array, 4096 frames batched per call (a batch this small is bound by the
-            # dependent chain of its kernels, not by throughput; an ADAPTIVE context runs it as plain FP16X3)
+            # dependent chain of its ~10 kernels, not by throughput; an ADAPTIVE context takes its adaptive path from 4096 rows)
             c1 = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=1, device=local_rank)
             F1 = 4096
             c1.reserve(1, F1)
@@ -272,7 +274,7 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f32 (SRP operands %s)" % args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] geometry (8-mic ULA 0.04 m, 48 kHz, N=1024, hop 512, 361 angles, "
-                                   "1 source, no power floor), %d arrays x %d frames per GPU per step" % (A, F),
+                                   "1 source, no power floor), %d arrays x %d frames per GPU per step; channel rows padded by %d floats" % (A, F, ROW_PAD),
                        "arrays_per_gpu": A, "frames_per_array": F, "srp_precision": args.precision,
                        "parallelism": "arrays sharded over %d GPU(s), all_gather of DOA bins+prob%s" % (world, " + gather of the beamformed audio to rank 0" if args.gather_audio else ""),
                        "single_stream_4096": single},

@@ -50,7 +50,7 @@ typedef enum {
     MCA_HIP_SRP_ADAPTIVE = 3 /* fp16 coarse scan of every frame + exact repair: the frames whose peak pick is sensitive to the
                                 fp16 error (and the rows their energy depends on) are recomputed with the FP16X3 split and
                                 picked again, so the DOA bins are those of FP16X3 at about the cost of FP16.  Applies to large
-                                batches (>= 8192 frames per call) on the 1024-sample path with more than two microphones, with
+                                batches (>= 4096 frames per call) on the 1024-sample path with more than two microphones, with
                                 or without the power gate; every other call of such a context runs as FP16X3.  The optional
                                 energy map keeps fp16 accuracy on unrepaired frames. */
 } mca_hip_srp_precision;

@@ -112,7 +112,7 @@ struct mca_hip_ctx {
     unsigned long long *d_rstats = nullptr;
     unsigned long long adapt_frames_total = 0;
     float tau_en = 0.f;            // normalised energies closer than this cannot be ordered from the coarse map
-    long long adapt_min_rows = 8192;
+    long long adapt_min_rows = 4096;        // (round 2: 8192; with the merged index the coarse contraction of 4096 rows takes 26 us against 81 + 12 us of the three-product one: the literal BASELINE configs[2] call -- 1 array x 4096 frames -- runs 0.194 instead of 0.199 ms)
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
     double *d_fr = nullptr; size_t fr_elems = 0;
@@ -276,7 +276,7 @@ int build_merged_tables(mca_hip_ctx *c)
     for (size_t m = 0; m < rank.size(); ++m)
         if (rank[m] == 0) { rank[m] = (unsigned short)ms.size(); ms.push_back((int)m); }
     c->n_merged = (int)ms.size();
-    c->Kp_m = round_up(2 * c->n_merged, 32);
+    c->Kp_m = round_up(2 * ((c->n_merged + 63) & ~63), 32);       // (whole wave rows: the analysis kernel stores its LDS region as it stands, zeros behind n_merged)
     const int Kp = c->Kp_m;
     std::vector<_Float16> B((size_t)Dp * Kp, (_Float16)0.f);
     for (int d = 0; d < D; ++d)

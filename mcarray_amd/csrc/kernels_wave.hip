@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                 // program order (the LDS executes a wave's instructions in order).  (ds_add_f32 would do the same without the
                 // batches, but runs at one lane every ~2.5 cycles: 1.5 ms per 32 768 frames instead of 0.27.)
                 float2 *S = buf;
-                for (int j = lane; j < nmp; j += 64) S[j] = make_float2(0.f, 0.f);
+                for (int j = lane; j < nmp / 2; j += 64) reinterpret_cast<float4 *>(S)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 wave_lds_fence();
                 float xn[MT];                                                     // lane 0: the Nyquist bin (real: X_a = Re Z, X_b = Im Z), whitened
 #pragma unroll
@@ -447,10 +447,14 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                     }
                     wave_lds_fence();
                 }
-                for (int j = lane; j < p.n_merged; j += 64) {
-                    const float2 v = S[j];
-                    const float2_t vv = {v.x, v.y};
-                    reinterpret_cast<half2_t *>(arow)[j] = __builtin_convertvector(vv, half2_t);
+                // the row: two merged sums (16 bytes of the region, 8 bytes of fp16) per lane and step; the entries behind
+                // n_merged are zero and fall into the row's padding
+                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                typedef float float4_t __attribute__((ext_vector_type(4)));
+                for (int j = lane; j < nmp / 2; j += 64) {
+                    const float4 v = reinterpret_cast<const float4 *>(S)[j];
+                    const float4_t vv = {v.x, v.y, v.z, v.w};
+                    reinterpret_cast<half4_t *>(arow)[j] = __builtin_convertvector(vv, half4_t);
                 }
                 wave_lds_fence();                                                  // (the next frame's transform reuses the region)
             } else {

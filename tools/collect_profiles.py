@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -36,19 +36,29 @@ for prec in ("adaptive", "fp16x3", "fp16", "fp32"):
         raw = json.load(open(tj))
         out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `python3 bench.py "
                          "--steps 3 --warmup 1 --cpu-frames 0 --precision %s` (tools/pmc_traffic.sh), MI355X" % prec,
-               "correction": "gfx950: FETCH_SIZE counts exactly half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM "
-                             "section): hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
-               "workload": "8 arrays x 4096 frames per step; values are per STEP (a kernel that runs twice per step -- k_stft_phat in "
-                           "the adaptive mode: all frames, then the listed repair groups -- has both launches added up)", "kernels": {}}
+               "correction": "gfx950: FETCH_SIZE counts exactly half of a WIDE coalesced read stream (16 B per lane: MI355X_MICROARCH.md, HBM "
+                             "section) -- the contraction (LDS-DMA, 16 B per lane), the scan and repair kernels: hbm_bytes = (2*FETCH_SIZE + "
+                             "WRITE_SIZE) * 1024.  The wave-per-run kernels of round 3 (k_stft_phat_wave, k_beamform_wave) load 4 B per "
+                             "lane; calibrated on their known input -- 0.537 GB of PCM per step, every sample fetched from HBM once, the "
+                             "overlapping half frame served by L2 -- FETCH_SIZE reads 0.52-0.55 GB there, i.e. the bytes themselves: "
+                             "factor 1 for those two (fetch_factor below)",
+               "workload": "8 arrays x 4096 frames per step; values are per STEP (a kernel that runs twice per step -- k_stft_phat_wave "
+                           "in the adaptive mode: all frames, then the listed repair groups -- has both launches added up)", "kernels": {}}
         steps = {c: max(1, min(v[c]["dispatches"] for v in raw.values() if c in v)) for c in ("FETCH_SIZE", "WRITE_SIZE")}
         tot = 0.0
         for k, v in raw.items():
-            e = {"kernel": k, "dispatches_per_step": v["FETCH_SIZE"]["dispatches"] / steps["FETCH_SIZE"],
-                 "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"]["sum"] / steps["FETCH_SIZE"],
-                 "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"]["sum"] / steps["WRITE_SIZE"]}
-            e["hbm_bytes_per_step"] = (2.0 * e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"]) * 1024.0
-            tot += e["hbm_bytes_per_step"]
-            out["kernels"][short(k)] = e
+            name = short(k)
+            factor = 1.0 if name in ("k_stft_phat_wave", "k_beamform_wave", "k_bf_table") else 2.0
+            e = out["kernels"].setdefault(name, {"kernel": name, "instantiations": [], "dispatches_per_step": 0.0, "FETCH_SIZE_KB_per_launch": 0.0,
+                                                 "WRITE_SIZE_KB_per_launch": 0.0, "fetch_factor": factor, "hbm_bytes_per_step": 0.0})
+            e["instantiations"].append(k)
+            e["dispatches_per_step"] += v["FETCH_SIZE"]["dispatches"] / steps["FETCH_SIZE"]
+            f_kb, w_kb = v["FETCH_SIZE"]["sum"] / steps["FETCH_SIZE"], v["WRITE_SIZE"]["sum"] / steps["WRITE_SIZE"]
+            e["FETCH_SIZE_KB_per_launch"] += f_kb          # (per step, all launches of the step added up)
+            e["WRITE_SIZE_KB_per_launch"] += w_kb
+            b = (factor * f_kb + w_kb) * 1024.0
+            e["hbm_bytes_per_step"] += b
+            tot += b
         out["total_hbm_bytes_per_step"] = tot
         out["algorithmic_bytes_per_step"] = 18440 * 32768
         json.dump(out, open(os.path.join(P, "%s_pmc_traffic_%s.json" % (tag, prec)), "w"), indent=1)
@@ -60,7 +70,7 @@ if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
     if lines:
         open(os.path.join(P, "%s_bench_mvdr.json" % tag), "w").write(lines[-1])
-for name in ("adaptive_check.json", "precision_report.json", "host_path.log"):
+for name in ("adaptive_check.json", "precision_report.json", "host_path.log", "bench_128x256.json", "bench_single_stream.json", "shapes.log", "gputest.log"):
     src = os.path.join(G, "final", name)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(P, "%s_%s" % (tag, name)))

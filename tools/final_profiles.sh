@@ -1,5 +1,5 @@
 # Round profiles: bench lines, rocprofv3 kernel stats, PMC traffic / SQ counters, adaptive-precision check, host path.
-# usage (GPU box, from the repo root): bash tools/final_profiles.sh ; then python tools/collect_profiles.py r02 here
+# usage (GPU box, from the repo root): bash tools/final_profiles.sh ; then python tools/collect_profiles.py r03 here
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 for p in adaptive fp16x3; do
@@ -7,6 +7,9 @@ for p in adaptive fp16x3; do
   python3 tools/summarize_rocprof.py gpurun_out/final/rocprof_$p gpurun_out/final/kernel_stats_$p.csv > /dev/null
 done
 timeout 900 python bench.py > gpurun_out/final/bench_adaptive.log 2>&1
+# BASELINE configs[4]'s per-GPU shape (128 arrays x 256 frames) in the shipped default
+timeout 300 python bench.py --arrays 128 --frames 256 --cpu-frames 0 --single-stream 0 > gpurun_out/final/bench_128x256.log 2>&1
+grep "^{" gpurun_out/final/bench_128x256.log | tail -1 > gpurun_out/final/bench_128x256.json
 timeout 900 python bench.py --precision fp16x3 --cpu-frames 0 > gpurun_out/final/bench_fp16x3.log 2>&1
 timeout 900 python bench.py --precision fp16 --cpu-frames 0 > gpurun_out/final/bench_fp16.log 2>&1
 # BASELINE configs[3]: the MVDR path (256 streams x 64 frames, 16 microphones)
