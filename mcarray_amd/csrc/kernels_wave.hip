@@ -420,6 +420,8 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                     xn[2 * pr + 1] = whiten4(make_float2(2.f * zn[pr].y, 0.f), pw).x;
                 }
                 const uint2 *offt = reinterpret_cast<const uint2 *>(rankl) + lane;
+                // (no fence between the batches: the LDS executes a wave's instructions in order and the compiler keeps the
+                // order of accesses to S that may alias; the offsets of the next batch can be read ahead)
 #pragma unroll
                 for (int g = 1; g < MT; ++g) {
 #pragma unroll
@@ -438,15 +440,23 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
 #pragma unroll
                         for (int s2 = 0; s2 < 4; ++s2) S[off[s2]] = cadd(cur[s2], acc[s2]);
                     }
-                    if (lane == 0) {
-                        float an = 0.f;
-#pragma unroll
-                        for (int i = 0; i + g < MT; ++i) an = fmaf(xn[i], xn[i + g], an);
-                        const unsigned on = rankl[2 * (MT - 1) * 64 * 4 + g - 1];
-                        S[on].x += an;
-                    }
-                    wave_lds_fence();
                 }
+                if (lane == 0) {                                                  // the Nyquist bin: m = 512 g, one word per spacing
+                    float an[MT - 1], cn[MT - 1];
+                    unsigned on[MT - 1];
+#pragma unroll
+                    for (int g = 1; g < MT; ++g) {
+                        an[g - 1] = 0.f;
+#pragma unroll
+                        for (int i = 0; i + g < MT; ++i) an[g - 1] = fmaf(xn[i], xn[i + g], an[g - 1]);
+                        on[g - 1] = rankl[2 * (MT - 1) * 64 * 4 + g - 1];
+                    }
+#pragma unroll
+                    for (int g = 0; g < MT - 1; ++g) cn[g] = S[on[g]].x;
+#pragma unroll
+                    for (int g = 0; g < MT - 1; ++g) S[on[g]].x = cn[g] + an[g];
+                }
+                wave_lds_fence();
                 // the row: two merged sums (16 bytes of the region, 8 bytes of fp16) per lane and step; the entries behind
                 // n_merged are zero and fall into the row's padding
                 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
