@@ -247,18 +247,39 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     sa.phi = c->d_phi; sa.trace = c->d_trace; sa.Y = Y;
     sa.n_streams = n_streams;
     const int Q = (c->M + 3) / 4;                                                     // row slots per lane
-    const dim3 sgrid((unsigned)(((long long)n_streams * c->K + 63) / 64));
-    t_begin(c, 1, st);
+    auto launch_solve = [&](long long pid0, long long n_prob, int pieces) {
+        sa.pid0 = pid0; sa.n_prob = n_prob; sa.pieces = pieces;
+        const dim3 sgrid((unsigned)((n_prob + 63) / 64 * pieces));
 #define SOLVE(QQ)                                                                                          \
     do {                                                                                                   \
         if (c->M == 4 * (QQ)) hipLaunchKernelGGL((k_mvdr_solve<QQ, true>), sgrid, dim3(256), 0, st, sa);   \
         else hipLaunchKernelGGL((k_mvdr_solve<QQ, false>), sgrid, dim3(256), 0, st, sa);                   \
     } while (0)
-    if (Q == 1) SOLVE(1);
-    else if (Q == 2) SOLVE(2);
-    else if (Q == 3) SOLVE(3);
-    else SOLVE(4);
+        if (Q == 1) SOLVE(1);
+        else if (Q == 2) SOLVE(2);
+        else if (Q == 3) SOLVE(3);
+        else SOLVE(4);
 #undef SOLVE
+    };
+    // 512 workgroups are resident (two per CU at 253 VGPRs) and all take the same time: the workgroups behind the last whole
+    // round (256 streams x 513 bins: 4 of 2052) would hold the GPU for a round of their own.  They go in a second launch,
+    // cut along the FRAMES into pieces that each repeat the (cheap) covariance recursion of the frames before their own.
+    static const int env_pieces = std::getenv("MCA_HIP_MVDR_PIECES") ? std::atoi(std::getenv("MCA_HIP_MVDR_PIECES")) : -1;   // A/B switch
+    const long long n_prob = (long long)n_streams * c->K, n_wg = (n_prob + 63) / 64;
+    const long long rem_wg = n_wg % 512;
+    int pieces = 1;
+    if (n_wg > 512 && rem_wg > 0 && rem_wg <= 128) {
+        while (pieces < 8 && rem_wg * pieces * 2 <= 512 && n_frames / (pieces * 2) >= 4) pieces *= 2;
+    }
+    if (env_pieces >= 0) pieces = env_pieces == 0 ? 1 : std::min(std::max(env_pieces, 1), n_frames);
+    t_begin(c, 1, st);
+    if (pieces > 1 && n_wg > 512) {
+        const long long main_prob = (n_wg - rem_wg) * 64;
+        launch_solve(0, main_prob, 1);
+        launch_solve(main_prob, n_prob - main_prob, pieces);
+    } else {
+        launch_solve(0, n_prob, 1);
+    }
     t_end(c, st);
 
     if (out_pcm) {

@@ -145,8 +145,10 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
     constexpr int NE = 2 * Q * (Q + 1);          // row slot q holds 4 (q + 1) entries, starting at 2 q (q + 1)
     const int tid = threadIdx.x, l = tid & 3;
     const int M = p.M, K = p.K, F = p.n_frames;
-    const long long total = (long long)p.n_streams * K;
-    const long long pid = (long long)blockIdx.x * 64 + (tid >> 2);
+    const int piece = (int)(blockIdx.x % (unsigned)p.pieces);
+    const int t_first = (int)((long long)piece * F / p.pieces), t_last = (int)((long long)(piece + 1) * F / p.pieces);   // frames this workgroup solves
+    const long long total = p.pid0 + p.n_prob;
+    const long long pid = p.pid0 + (long long)(blockIdx.x / (unsigned)p.pieces) * 64 + (tid >> 2);
     const bool pv = pid < total;
     const long long pc = pv ? pid : total - 1;   // surplus quads shadow the last problem and store nothing
     const int a = (int)(pc / K), k = (int)(pc - (long long)a * K);
@@ -173,14 +175,14 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
     float2 xn[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) xn[q] = (FULL || 4 * q + l < M) ? X[4 * q] : make_float2(0.f, 0.f);
-    for (int t = 0; t < F; ++t) {
+    for (int t = 0; t < t_last; ++t) {
         float2 x[Q], d[Q], rd[Q], rx[Q];
         float dsum[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const bool rv = FULL || 4 * q + l < M;
             x[q] = xn[q];
-            if (t + 1 < F && rv) xn[q] = X[(long long)(t + 1) * fstride + 4 * q];
+            if (t + 1 < t_last && rv) xn[q] = X[(long long)(t + 1) * fstride + 4 * q];
             // steering d_i = exp(-j k s_i), s_i = 2 pi fs/N/c x_i cos(DOA + pi/2), from the factored tables of the analysis
             const float2 *tq = T + ((long long)t * M + (rv ? 4 * q + l : 0)) * nph;
             d[q] = rv ? cmul(tq[0], tq[lo_off]) : make_float2(0.f, 0.f);
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
                 }
         }
         tr = fmaf(al, tr, oma * e);
+        if (t < t_first) continue;               // (an earlier piece solves this frame)
         const float delta = p.loading_over_m * tr;
 
         float2 num = make_float2(0.f, 0.f);
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
         }
         if (l == 0 && pv) yo[(long long)t * K] = y;
     }
-    if (pv) {
+    if (pv && t_last == F) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int i = 4 * q + l;

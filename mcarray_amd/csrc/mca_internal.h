@@ -315,6 +315,11 @@ struct MvdrAnalyseArgs {
 };
 
 struct MvdrSolveArgs {
+    // A launch covers the problems pid0 .. pid0 + n_prob - 1 (problem = stream * K + bin), `pieces` workgroups per 64 problems:
+    // piece j solves the frames [j F / pieces, (j + 1) F / pieces) after running the covariance recursion alone -- the same
+    // operations in the same order, so the same bits -- over the frames before them; the last piece stores the state.
+    long long pid0, n_prob;
+    int pieces;
     const float2 *X;          // [streams][n_frames][K][M]
     const float2 *T;          // [streams][n_frames][M][nhi + 32] factored steering phasors (MvdrAnalyseArgs)
     int n_streams, n_frames, K, M;

@@ -94,6 +94,35 @@ def test_mvdr_matches_golden(golden_dir, name):
     assert np.abs(bf.covariance(0)[::64] - g["phi_last"]).max() <= COV_TOL * np.abs(g["phi_last"]).max()
 
 
+def test_mvdr_tail_workgroups_cut_along_the_frames_match_oracle():
+    """Calls of more than 512 solve workgroups (here 64 streams x 513 bins / 64 = 513) put the workgroups behind the last whole
+    round into a second launch cut along the frames, each piece repeating the covariance recursion of the frames before its own
+    (api_mvdr.hip): spectra (the last bins on their own as well), audio and the covariance of sampled streams -- the last
+    stream is the one in the tail -- against the oracle, over two calls."""
+    fs, N, F, A = 16000, 1024, 10, 64
+    xs = synth.REEM_C
+    base = np.stack([_scene(xs, fs, N, 2 * F, a) for a in range(3)])
+    pick = np.arange(A) % 3
+    pcm = base[pick]
+    doa = (np.deg2rad(20.0 - 30 * pick)[:, None] + 0.01 * np.arange(2 * F)[None, :]).astype(np.float32)
+    hop = N // 2
+    bf = api.MvdrBeamformer(fs, xs, N, max_streams=A)
+    r1 = bf.process(pcm[:, :, :(F + 1) * hop].copy(), doa[:, :F].copy(), want_spec=True)
+    r2 = bf.process(pcm[:, :, F * hop:].copy(), doa[:, F:].copy(), want_spec=True)
+    spec = np.concatenate([r1["spec"], r2["spec"]], axis=1)
+    out = np.concatenate([r1["out"], r2["out"]], axis=1)
+    for a in (0, 31, 63):
+        og = po.MVDR(fs, N, xs)
+        o = og.stream(pcm[a].astype(np.float64), doa[a].astype(np.float64), want_spec=True)
+        sp = _ospec(o)
+        assert np.abs(spec[a] - sp).max() <= SPEC_TOL * np.abs(sp).max(), a
+        assert np.abs(spec[a][:, -64:] - sp[:, -64:]).max() <= SPEC_TOL * np.abs(sp).max(), a
+        assert np.abs(out[a] - o["out"]).max() <= AUDIO_TOL * np.abs(o["out"]).max(), a
+        assert np.abs(bf.covariance(a) - og.covariance()).max() <= COV_TOL * np.abs(og.covariance()).max(), a
+    # streams with the same input give the same bits wherever they sit in the batch
+    assert np.array_equal(spec[0], spec[3]) and np.array_equal(out[1], out[61])
+
+
 def test_mvdr_chunked_calls_equal_one_call():
     """The state (covariances, traces, overlap-add tail) carried between calls reproduces a single long call bit for bit."""
     fs, N, F = 48000, 1024, 48
