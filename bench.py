@@ -267,6 +267,12 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             e1 = timed_loop(lambda: c1.process_frames_dev(p1, F1, b1, r1, q1, None, o1, stream=stream), lambda: None, n1, 5, False, None, dev)
             single = {"value": F1 * n1 / e1, "unit": "frames/s", "ms_per_call": e1 / n1 * 1e3, "calls": n1,
                       "workload": "1 array x 4096 frames per call (BASELINE configs[2] as written)"}
+            # the same call with its buffers fixed once and replayed as a HIP graph (mca_hip_graph_create / _launch: the
+            # real-time mode of the C ABI; same kernels, same results, one driver call per chunk)
+            g1 = c1.graph_create(p1, F1, b1, r1, q1, None, o1)
+            eg = timed_loop(lambda: g1.launch(stream=stream), lambda: None, n1, 5, False, None, dev)
+            single["graph_replay"] = {"value": F1 * n1 / eg, "unit": "frames/s", "ms_per_call": eg / n1 * 1e3, "calls": n1}
+            g1.close()
             c1.close()
         line = {
             "metric": "STFT frames/sec, 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum beamform @48kHz/1024-pt",

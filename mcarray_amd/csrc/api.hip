@@ -492,7 +492,7 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
     if (nc > c->ws().adapt_chunks) {
         if (c->ws().d_chunk_from) (void)hipFree(c->ws().d_chunk_from);
         c->ws().d_chunk_from = nullptr; c->ws().adapt_chunks = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->ws().d_chunk_from, nc * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_chunk_from, 2 * nc * 4));   // + the list of the chunks that hold a flagged frame
         HIP_TRY(c, hipMemset(c->ws().d_chunk_from, 0x7f, nc * 4));       // "no flagged frame"; kept so by k_scan_repick
         HIP_TRY(c, hipDeviceSynchronize());
         c->ws().adapt_chunks = nc; ++c->ws_gen;
@@ -514,8 +514,8 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
         c->ws().lastv_arrays = n_arrays; ++c->ws_gen;
     }
     if (!c->ws().d_nlist) {
-        HIP_TRY(c, hipMalloc((void **)&c->ws().d_nlist, 4));
-        HIP_TRY(c, hipMemset(c->ws().d_nlist, 0, 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_nlist, 8));              // listed repair units, listed chunks
+        HIP_TRY(c, hipMemset(c->ws().d_nlist, 0, 8));
         HIP_TRY(c, hipDeviceSynchronize());
         ++c->ws_gen;
     }
@@ -1152,6 +1152,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (adaptive) {
         pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
         pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_from = c->ws().d_chunk_from; pa.last_vchunk = c->ws().d_last_vchunk; pa.stats = c->d_rstats;
+        pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;
     }
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
@@ -1217,7 +1218,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         do {                                                                                                                        \
             if (smem4 > 64 * 1024)      /* grids finer than 0.45 degrees: Dp >= 512 */                                              \
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_repick<PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)); \
-            hipLaunchKernelGGL((k_scan_repick<PL>), g3, dim3(std::max(nthr, 512)), smem4, st, pa);                                  \
+            hipLaunchKernelGGL((k_scan_repick<PL>), dim3((unsigned)std::min<long long>((long long)pa.n_chunks * n_arrays, 256)), dim3(std::max(nthr, 512)), smem4, st, pa); \
         } while (0)
         if (ppl == 2) LAUNCH_REPICK(2); else if (ppl == 6) LAUNCH_REPICK(6); else LAUNCH_REPICK(8);
 #undef LAUNCH_REPICK

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
     // grid (arrays, slices of 64 delays): one wave per slice spreads the strided loads over many CUs (17.7 -> 16 us; four waves
     // per slice fetching side by side into LDS with one of them composing measured 19.6 us: the composition wants registers)
     const int tl = threadIdx.x, d = blockIdx.y * blockDim.x + tl, a = blockIdx.x;
-    if (p.mode == 1 && a == 0 && d == 0) *p.n_list = 0;              // adaptive SRP precision: the repair list starts empty
+    if (p.mode == 1 && a == 0 && d == 0) { *p.n_list = 0; *p.n_clist = 0; }   // adaptive SRP precision: the repair lists start empty
     if (tl == 0) s_lv = -1;
     for (int n = tl; n <= SCAN_CHUNK; n += blockDim.x) {
         float g = 1.f;
@@ -638,7 +638,8 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 }
                 if (lane == 0) {
                     // the second pick of this chunk restarts from the (coarse) start value of the chunk that holds the earliest of those rows
-                    atomicMin(&p.chunk_from[(long long)a * p.n_chunks + blockIdx.x], u_min / p.chunk);
+                    const int ci = a * p.n_chunks + (int)blockIdx.x;
+                    if (atomicMin(&p.chunk_from[ci], u_min / p.chunk) >= p.n_chunks) p.clist[atomicAdd(p.n_clist, 1)] = ci;   // the chunk's first flagged frame
                     atomicAdd(&p.stats[0], 1ull);
                 }
             }
@@ -656,7 +657,8 @@ template __global__ void k_scan_pick<8, 1>(ScanPickArgs);
 // --------------------------------------------------------------------------------------
 // k_scan_repick / k_repair_patch -- adaptive SRP precision: the second pick of the flagged frames on the exact rows
 // --------------------------------------------------------------------------------------
-// k_scan_repick: grid (chunks, arrays); only the chunks that hold a flagged frame run (chunk_from < n_chunks).  After the
+// k_scan_repick: a fixed, moderate grid walks the list of the chunks that hold a flagged frame (a grid of all chunks spends
+// ~25 ns per empty workgroup: 29 us for 1 024 chunks of which 40 are listed, 7 us for 128).  After the
 // flagged frames' rows and the REPAIR_WARM advancing rows before them were recomputed with the three-product split and patched
 // into C, the recursion restarts from the (coarse) start value of the chunk that holds the earliest of those rows -- this
 // chunk or the one before it without the gate, possibly further back across a silence with it -- and walks the patched map,
@@ -673,18 +675,20 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     __shared__ int s_bin[REPICK_B * MCA_MAX_SOURCES];
     __shared__ float s_val[REPICK_B * MCA_MAX_SOURCES];
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
-    const int a = blockIdx.y, D = p.D, Dl = p.Dp + 8, S = p.S;
-    const long long ci = (long long)a * p.n_chunks + blockIdx.x;
-    const int c_from = p.chunk_from[ci];
-    if (c_from > (int)blockIdx.x) return;
-    const unsigned char *fl = p.flags + (long long)a * p.n_frames;
-    const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
-    const int t_start = blockIdx.x * p.chunk;
-    const int t_end = min(t_start + p.chunk, p.n_frames);
+    const int D = p.D, Dl = p.Dp + 8, S = p.S;
     const bool act = d < D;
     const float mu = p.mu, omu = p.one_minus_mu;
-    const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     const float mn = -15.f * (float)p.P, nd = -2.f * mn, nr = p.inv_norm;
+    const int n_listed = *p.n_clist;
+    for (int li = blockIdx.x; li < n_listed; li += gridDim.x) {
+    const int ci = p.clist[li];
+    const int a = ci / p.n_chunks, chunk = ci - a * p.n_chunks;
+    const int c_from = p.chunk_from[ci];
+    const unsigned char *fl = p.flags + (long long)a * p.n_frames;
+    const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
+    const int t_start = chunk * p.chunk;
+    const int t_end = min(t_start + p.chunk, p.n_frames);
+    const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     float E = act ? p.e_start[((long long)a * p.n_chunks + c_from) * D + d] : 0.f;
     for (int tb = c_from * p.chunk; tb < t_end; tb += REPICK_B) {
         const int te = min(tb + REPICK_B, t_end);
@@ -725,8 +729,10 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
             __syncthreads();
         }
     }
-    if (act && (int)blockIdx.x == p.last_vchunk[a]) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
+    if (act && chunk == p.last_vchunk[a]) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
+    __syncthreads();                                                        // (every thread has read chunk_from[ci])
     if (d == 0) p.chunk_from[ci] = 0x7f7f7f7f;                              // consumed: no flagged frame
+    }
 }
 template __global__ void k_scan_repick<2>(ScanPickArgs);
 template __global__ void k_scan_repick<6>(ScanPickArgs);

@@ -123,6 +123,7 @@ struct ScanPickArgs {
     int *list;               // [arrays * groups_per_array] groups whose rows are recomputed, in order of arrival
     int *n_list;             // [1] their number (reset by k_scan_carry)
     int *chunk_from;         // [arrays][n_chunks] chunk the second pick of this chunk restarts from, >= n_chunks: no flagged frame (reset by k_scan_repick)
+    int *clist; int *n_clist;     // [arrays * n_chunks], [1]: the chunks that hold a flagged frame, in order of arrival (k_scan_repick walks them; reset by k_scan_carry)
     int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
     unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
 };

@@ -11,13 +11,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcarray_amd import api, synth  # noqa: E402
 
 
-def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10):
+def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10, gate=False):
     xs = {2: synth.BINAURAL, 4: synth.REEM_C, 8: synth.ULA8, 16: synth.ULA16}[M]
     dev = torch.device("cuda", 0)
     hop = N // 2
     g = torch.Generator(device=dev); g.manual_seed(1)
     pcm = (torch.randn(A, M, (F + 1) * hop, device=dev, generator=g) * 0.1).contiguous()
-    ctx = api.Context(fs, xs, N, step, S, srp_precision=prec, max_arrays=A)
+    ctx = api.Context(fs, xs, N, step, S, srp_precision=prec, max_arrays=A, use_power_floor=gate)
     doa_bin = torch.empty(A, F, S, dtype=torch.int32, device=dev)
     doa_rad = torch.empty(A, F, S, dtype=torch.float32, device=dev)
     prob = torch.empty(A, F, S, dtype=torch.float32, device=dev)
@@ -33,8 +33,8 @@ def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     kt = {name: round(ctx.get_timing(kid)[1] / max(ctx.get_timing(kid)[0], 1), 3) for kid, name in api.KERNEL_NAMES.items() if ctx.get_timing(kid)[0]}
-    print("M=%2d fs=%6d N=%4d D=%3d S=%d  %3d arrays x %5d frames: %6.2f M frames/s  %.3f ms/step  %s" %
-          (M, fs, N, ctx.D, S, A, F, A * F / dt / 1e6, dt * 1e3, kt))
+    print("M=%2d fs=%6d N=%4d D=%3d S=%d%s  %3d arrays x %5d frames: %6.2f M frames/s  %.3f ms/step  %s" %
+          (M, fs, N, ctx.D, S, " gate" if gate else "", A, F, A * F / dt / 1e6, dt * 1e3, kt))
     ctx.close()
 
 
@@ -63,6 +63,11 @@ def run_two_channel():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "two":
         run_two_channel()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gate":          # the reference's default usePowerFloor, in the bench's precision
+        for gate in (False, True):
+            run(8, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, gate=gate, steps=30)
+            run(4, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, gate=gate, steps=30)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sources":
         for S in (1, 2, 3, 4):
