@@ -112,6 +112,16 @@ struct mca_hip_ctx {
     unsigned long long *d_rstats = nullptr;
     unsigned long long adapt_frames_total = 0;
     float tau_en = 0.f;            // normalised energies closer than this cannot be ordered from the coarse map
+    // ADAPTIVE backs off to plain FP16X3 (the arithmetic its repair pass reproduces) while most rows need the repair -- noise
+    // only, silence: every pick is a near tie and coarse + repair of everything costs twice the direct exact pass.  The last
+    // kernel of an adaptive call leaves its running totals in page-locked memory; the next calls read them when they have arrived
+    // (no synchronisation) and suspend the mode for fb_backoff eligible calls, then probe again with one adaptive call.
+    bool fb_enabled = true, adapt_suspended = false, capturing = false;
+    int fb_left = 0, fb_backoff = 8, fb_state = 0;      // (adapt_policy_begin)
+    unsigned long long fb_probe_seq = 0;
+    unsigned long long *h_probe = nullptr;              // [3] flagged frames, listed repair units, sequence number of the call
+    unsigned long long fb_calls = 0, fb_seq_seen = 0, fb_groups_prev = 0, fb_frames_prev = 0;
+    unsigned long long fb_frames_ring[64] = {};         // adapt_frames_total after adaptive call number i + 1
     long long adapt_min_rows = 4096;        // (round 2: 8192; with the merged index the coarse contraction of 4096 rows takes 26 us against 81 + 12 us of the three-product one: the literal BASELINE configs[2] call -- 1 array x 4096 frames -- runs 0.194 instead of 0.199 ms)
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
@@ -171,6 +181,7 @@ void free_ctx(mca_hip_ctx *c)
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
     F(c->d_rstats); F(c->d_gate_state);
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
     for (Workspace &w : c->lanes) w.release();
     for (auto &e : c->io_ev) if (e) (void)hipEventDestroy(e);
     for (auto &q : c->io_stream) if (q) (void)hipStreamDestroy(q);
@@ -448,11 +459,55 @@ void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_ro
 // more than two microphones) and has a fixed cost of a few small launches, so small batches -- which are latency bound
 // whatever the precision -- run as plain FP16X3, which is what the repair pass reproduces.  (Gated streams do take the
 // adaptive path: the planning wave lists the last 25 VOICED rows behind a flagged frame)
-bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames)
+bool adaptive_shape(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     const long long rows = c->plan_rows > 0 ? c->plan_rows : (long long)n_arrays * n_frames;     // (see plan_gemm)
     return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 &&
            rows >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
+}
+bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames) { return adaptive_shape(c, n_arrays, n_frames) && !c->adapt_suspended; }
+
+// Called once at the top of an eager stream call (not per piece of a call, not while a graph is recorded): reads what the
+// adaptive calls that have finished by now reported and decides whether this call runs coarse + repair or plain FP16X3.
+//   NORMAL     adaptive; a report of more than 30 % of the rows recomputed since the last one suspends the mode for fb_backoff
+//              eligible calls (8, doubling up to 256 while the probes keep reporting that)
+//   SUSPENDED  plain FP16X3, counting down; then ONE adaptive call probes
+//   WAITING    plain FP16X3 until the probe's report is in (a caller that queues many calls ahead gets it late): heavy again ->
+//              SUSPENDED, else NORMAL
+// Which call a report reaches depends on timing, so the switch can move by a call from run to run; both modes return the exact
+// path's bins (MCA_HIP_ADAPT_FALLBACK=0 pins the mode).
+void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
+{
+    if (!c->fb_enabled || c->capturing || !c->h_probe || !adaptive_shape(c, n_arrays, n_frames)) return;
+    bool fresh = false, heavy = false;
+    const unsigned long long seq = __atomic_load_n(&c->h_probe[2], __ATOMIC_ACQUIRE);
+    if (seq > c->fb_seq_seen && seq <= c->fb_calls && c->fb_calls - seq < 64) {
+        const unsigned long long groups = __atomic_load_n(&c->h_probe[1], __ATOMIC_RELAXED), frames = c->fb_frames_ring[(seq - 1) % 64];
+        const bool fwd = groups >= c->fb_groups_prev && frames > c->fb_frames_prev;      // (the totals restart with mca_hip_reset_timing)
+        const unsigned long long dg = fwd ? groups - c->fb_groups_prev : 0, df = fwd ? frames - c->fb_frames_prev : 0;
+        c->fb_seq_seen = seq; c->fb_groups_prev = groups; c->fb_frames_prev = frames;
+        fresh = df > 0;
+        heavy = fresh && dg * REPAIR_GROUP * 100 > df * 30;
+    }
+    auto suspend = [&]() {
+        c->fb_state = 1; c->adapt_suspended = true;
+        c->fb_left = c->fb_backoff - 1;                                                   // (this call is the first of them)
+        c->fb_backoff = std::min(c->fb_backoff * 2, 256);
+    };
+    switch (c->fb_state) {
+    case 0:
+        if (heavy) suspend(); else if (fresh) c->fb_backoff = 8;
+        break;
+    case 1:
+        if (--c->fb_left < 0) { c->fb_state = 2; c->adapt_suspended = false; c->fb_probe_seq = c->fb_calls + 1; }   // this call probes
+        break;
+    default:
+        c->adapt_suspended = true;
+        if (fresh && seq >= c->fb_probe_seq) {
+            if (heavy) suspend(); else { c->fb_state = 0; c->adapt_suspended = false; c->fb_backoff = 8; }
+        }
+        break;
+    }
 }
 
 // K segments of the repair contraction: by the shape of the (whole) call only.  The tails of every array -- REPAIR_WARM + 1 rows
@@ -768,6 +823,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         const double scale = std::getenv("MCA_HIP_ADAPT_TAU_SCALE") ? std::atof(std::getenv("MCA_HIP_ADAPT_TAU_SCALE")) : 1.0;
         c->tau_en = (float)(scale * 8.0 * std::sqrt(2.0) * sigma_c / (30.0 * c->P));
         if (std::getenv("MCA_HIP_ADAPT_MIN_ROWS")) c->adapt_min_rows = std::atoll(std::getenv("MCA_HIP_ADAPT_MIN_ROWS"));
+        if (std::getenv("MCA_HIP_ADAPT_FALLBACK")) c->fb_enabled = std::atoi(std::getenv("MCA_HIP_ADAPT_FALLBACK")) != 0;
     }
 
     int rc = MCA_HIP_OK;
@@ -802,6 +858,10 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
+    }
+    if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->fb_enabled) {
+        if (hipHostMalloc((void **)&c->h_probe, 32, hipHostMallocDefault) == hipSuccess) std::memset(c->h_probe, 0, 32);
+        else { c->h_probe = nullptr; (void)hipGetLastError(); }                    // (no page-locked memory: the mode never backs off)
     }
     if (c->stream_ok && ((rc = build_steering_table(c)) || (rc = build_merged_tables(c)))) { g_create_error = c->err; free_ctx(c); return rc; }
     if ((rc = init_last_state(c, nullptr))) { g_create_error = c->err; free_ctx(c); return rc; }
@@ -855,6 +915,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
         HIP_TRY(c, hipMemsetAsync(c->d_vdone[i], 0, na * 8, st));
     }
     HIP_TRY(c, hipMemsetAsync(c->d_silence, 0, na * 4, st));
+    c->adapt_suspended = false; c->fb_state = 0; c->fb_left = 0; c->fb_backoff = 8;     // new streams: the adaptive mode starts afresh
     // the self-cleaning words of the adaptive path (a call that failed half way may have left some set)
     for (Workspace &w : c->lanes) {
         if (w.d_need) HIP_TRY(c, hipMemsetAsync(w.d_need, 0, w.adapt_groups * 4, st));
@@ -1153,6 +1214,10 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
         pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_from = c->ws().d_chunk_from; pa.last_vchunk = c->ws().d_last_vchunk; pa.stats = c->d_rstats;
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;
+        if (c->h_probe && !c->capturing) {
+            c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
+            pa.probe = c->h_probe; pa.probe_seq = ++c->fb_calls;
+        }
     }
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
@@ -1381,6 +1446,7 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     if (rc) return rc;
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
     c->n_lanes_last = 1; c->cur_lane = 0; c->a0 = 0;
+    adapt_policy_begin(c, n_arrays, n_frames);
     rc = localise_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, (hipStream_t)stream);
     if (rc) return rc;
     c->last_arrays = n_arrays; c->last_frames = n_frames;
@@ -1430,6 +1496,7 @@ int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array
     if (!out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev/out_pcm_dev is NULL");
     if ((rc = ensure_bf_table(c))) return rc;
     c->n_lanes_last = 1; c->cur_lane = 0; c->a0 = 0;
+    adapt_policy_begin(c, n_arrays, n_frames);
     rc = localise_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, (hipStream_t)stream);
     if (!rc) rc = separate_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, (hipStream_t)stream, doa_bin);
     if (rc) return rc;
@@ -1493,6 +1560,9 @@ static int graph_record(mca_hip_graph *g, int idx)
     const unsigned timing = c->timing;
     const unsigned long long adapt_frames = c->adapt_frames_total;
     c->timing = 0;                              // event pairs belong to eager calls
+    const bool suspended = c->adapt_suspended;
+    c->adapt_suspended = false; c->capturing = true;   // a recording is the mode's own kernels, whatever the eager calls do at the moment
+    struct Restore { mca_hip_ctx *c; bool s; ~Restore() { c->adapt_suspended = s; c->capturing = false; } } restore{c, suspended};
     HIP_TRY(c, hipStreamBeginCapture(g->cap, hipStreamCaptureModeRelaxed));
     int rc = mca_hip_localise_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_bin, g->doa_rad,
                                          g->prob, g->energy, g->cap);
@@ -1531,7 +1601,7 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
         if (rc) return rc;
     }
     HIP_TRY(c, hipGraphLaunch(g->exec[idx], (hipStream_t)stream));
-    if (adaptive_applies(c, g->n_arrays, g->n_frames)) c->adapt_frames_total += (unsigned long long)g->n_arrays * g->n_frames;   // (a recording counts nothing)
+    if (adaptive_shape(c, g->n_arrays, g->n_frames)) c->adapt_frames_total += (unsigned long long)g->n_arrays * g->n_frames;   // (a recording counts nothing)
     c->e_cur ^= 1;                              // as the eager calls do
     if (g->out_pcm) c->tail_cur ^= 1;
     c->last_arrays = g->n_arrays; c->last_frames = g->n_frames;
@@ -1649,6 +1719,7 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
         a0 += na;
     }
     a0 = 0;
+    adapt_policy_begin(c, n_arrays, n_frames);
     c->plan_rows = (long long)n_arrays * n_frames;           // every chunk is planned as the whole call (bit-identical results)
     c->plan_arrays = n_arrays;
     for (int k = 0; k < nchunk && !rc; ++k) {
@@ -1981,6 +2052,7 @@ int mca_hip_reset_timing(mca_hip_ctx *c)
     for (int i = 0; i < MCA_HIP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_launches[i] = 0; }
     if (c->d_rstats) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipMemset(c->d_rstats, 0, 16)); }
     c->adapt_frames_total = 0;
+    c->fb_groups_prev = 0; c->fb_frames_prev = 0; c->fb_seq_seen = c->fb_calls;   // (the reports in flight belong to the old totals)
     return rc;
 }
 

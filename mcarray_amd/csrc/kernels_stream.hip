@@ -680,6 +680,13 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     const float mu = p.mu, omu = p.one_minus_mu;
     const float mn = -15.f * (float)p.P, nd = -2.f * mn, nr = p.inv_norm;
     const int n_listed = *p.n_clist;
+    if (p.probe && blockIdx.x == 0 && d == 0) {
+        // how much this call had to repair, for the host's choice between this mode and plain FP16X3 for later calls: page-locked
+        // host memory, the sequence number last
+        p.probe[0] = p.stats[0]; p.probe[1] = p.stats[1];
+        __threadfence_system();
+        __hip_atomic_store(&p.probe[2], p.probe_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (int li = blockIdx.x; li < n_listed; li += gridDim.x) {
     const int ci = p.clist[li];
     const int a = ci / p.n_chunks, chunk = ci - a * p.n_chunks;

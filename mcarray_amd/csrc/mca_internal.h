@@ -124,6 +124,8 @@ struct ScanPickArgs {
     int *n_list;             // [1] their number (reset by k_scan_carry)
     int *chunk_from;         // [arrays][n_chunks] chunk the second pick of this chunk restarts from, >= n_chunks: no flagged frame (reset by k_scan_repick)
     int *clist; int *n_clist;     // [arrays * n_chunks], [1]: the chunks that hold a flagged frame, in order of arrival (k_scan_repick walks them; reset by k_scan_carry)
+    unsigned long long *probe;    // host-mapped [3] or NULL: k_scan_repick leaves stats[0], stats[1] and probe_seq there (api.hip: adapt_policy_begin)
+    unsigned long long probe_seq;
     int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
     unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
 };

@@ -19,6 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+@pytest.fixture(autouse=True)
+def no_back_off(monkeypatch):
+    monkeypatch.setenv("MCA_HIP_ADAPT_FALLBACK", "0")        # read by mca_hip_create: these tests are about coarse + repair itself
+
+
 @pytest.fixture
 def force_small(monkeypatch):
     monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "256")       # read by mca_hip_create: adaptive also for small batches
@@ -48,6 +53,39 @@ def test_adaptive_matches_oracle(force_small, xs, step, S, thetas):
         if not ties:
             assert np.abs(r["out"][a] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
     ctx.close()
+
+
+def test_adaptive_backs_off_to_fp16x3_while_most_rows_need_the_repair(force_small, monkeypatch):
+    """Noise only: every pick is a near tie, every frame is flagged, and coarse + repair of everything costs twice the direct
+    exact pass.  The last kernel of an adaptive call reports its totals through page-locked memory; the calls after it run as
+    plain FP16X3 (no adaptive frames counted) for 8 calls, then one call probes again.  The bins stay the exact path's."""
+    monkeypatch.setenv("MCA_HIP_ADAPT_FALLBACK", "1")
+    fs, N, F, A = 48000, 1024, 256, 1
+    xs = synth.ULA8
+    rng = np.random.default_rng(5)
+    n_calls = 11
+    pcm = (0.1 * rng.standard_normal((A, len(xs), (n_calls * F + 1) * 512))).astype(np.float32)
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+    ref = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16X3, max_arrays=A)
+    ctx.reset_timing()
+    counted, bins, rbins = [], [], []
+    for i in range(n_calls):
+        chunk = pcm[:, :, i * F * 512:((i + 1) * F + 1) * 512]
+        bins.append(ctx.process_frames_host(chunk)["bin"])      # (synchronous: the report of call i is there before call i + 1)
+        rbins.append(ref.process_frames_host(chunk)["bin"])
+        counted.append(ctx.repair_stats()["frames"])
+    # call 0 adaptive, calls 1..8 suspended, call 9 probes (adaptive again), call 10 suspended (for 16 calls)
+    assert counted[0] == A * F and counted[8] == counted[0], counted
+    assert counted[9] == 2 * A * F and counted[10] == counted[9], counted
+    st = ctx.repair_stats()
+    assert st["recomputed"] > 0.3 * st["frames"], st
+    got, want = np.concatenate(bins, axis=1), np.concatenate(rbins, axis=1)
+    # suspended calls ARE the FP16X3 path on the same state: the adaptive calls hand over an exact state, so the two contexts
+    # can only part on exact-level ties (noise only: there are some)
+    assert np.mean(got != want) < 0.02, np.mean(got != want)
+    o = po.ssl_stream(fs, N, xs, pcm[0].astype(np.float64), 1, 0.5, want_map=True)
+    _assert_bins(got[0], o["bin"], o["energy"], ctx.P, max_ties=int(0.02 * n_calls * F))
+    ctx.close(); ref.close()
 
 
 def test_adaptive_context_runs_small_and_gated_calls_as_fp16x3():

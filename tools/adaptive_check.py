@@ -4,6 +4,8 @@ IDENTICAL (the adaptive mode recomputes exactly the frames whose pick is sensiti
 the plain fp16 mode on the same data, the flagged / recomputed fractions, and how the measured fp16 error of the normalised
 energy compares with the decision margin tau the sensitivity test assumes.
 usage (GPU box): python tools/adaptive_check.py [cases] [seed] > profiles/rNN_adaptive_check.json"""
+import os
+os.environ.setdefault("MCA_HIP_ADAPT_FALLBACK", "0")      # the check is about coarse + repair itself: no backing off to FP16X3
 import json
 import os
 import sys

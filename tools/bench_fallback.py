@@ -1,0 +1,41 @@
+"""The ADAPTIVE mode on input where nearly every frame needs the repair (independent white noise per channel, no source, no
+power gate), with and without its back-off to plain FP16X3 (MCA_HIP_ADAPT_FALLBACK, api.hip: adapt_policy_begin), next to
+FP16X3 itself.  The host waits for every call before it enqueues the next one -- a caller that queues many calls ahead gets
+the reports late and backs off later.  usage (GPU box): python tools/bench_fallback.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcarray_amd import api, synth  # noqa: E402
+
+
+def run(prec, fallback, steps=60, A=8, F=4096):
+    os.environ["MCA_HIP_ADAPT_FALLBACK"] = "1" if fallback else "0"
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    pcm = (torch.randn(A, 8, (F + 1) * 512, device=dev, generator=g) * 0.1).contiguous()
+    ctx = api.Context(48000, synth.ULA8, 1024, 0.5, 1, srp_precision=prec, max_arrays=A)
+    b = torch.empty(A, F, 1, dtype=torch.int32, device=dev); d = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+    pr = torch.empty(A, F, 1, dtype=torch.float32, device=dev); o = torch.empty(A, 1, F * 512, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        ctx.process_frames_dev(pcm, F, b, d, pr, None, o)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.process_frames_dev(pcm, F, b, d, pr, None, o)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = ctx.repair_stats() if prec == api.SRP_ADAPTIVE else None
+    print("%-9s back-off %-3s: %.3f ms per call of %d x %d frames (%.1f M frames/s)%s" % (
+        {api.SRP_ADAPTIVE: "adaptive", api.SRP_FP16X3: "fp16x3"}[prec], "on" if fallback else "off", dt * 1e3, A, F, A * F / dt / 1e6,
+        "  adaptive frames %d of %d" % (st["frames"], (steps + 2) * A * F) if st else ""), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    run(api.SRP_FP16X3, False)
+    run(api.SRP_ADAPTIVE, False)
+    run(api.SRP_ADAPTIVE, True)
