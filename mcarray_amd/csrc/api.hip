@@ -122,6 +122,7 @@ struct mca_hip_ctx {
     unsigned long long *h_probe = nullptr;              // [3] flagged frames, listed repair units, sequence number of the call
     unsigned long long fb_calls = 0, fb_seq_seen = 0, fb_groups_prev = 0, fb_frames_prev = 0;
     unsigned long long fb_frames_ring[64] = {};         // adapt_frames_total after adaptive call number i + 1
+    int adapt_max_sources = 1;
     long long adapt_min_rows = 4096;        // (round 2: 8192; with the merged index the coarse contraction of 4096 rows takes 26 us against 81 + 12 us of the three-product one: the literal BASELINE configs[2] call -- 1 array x 4096 frames -- runs 0.194 instead of 0.199 ms)
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
@@ -462,7 +463,10 @@ void set_call_planes(mca_hip_ctx *c, int planes) { c->a_planes = planes; c->a_ro
 bool adaptive_shape(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     const long long rows = c->plan_rows > 0 ? c->plan_rows : (long long)n_arrays * n_frames;     // (see plan_gemm)
-    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 &&
+    // (more than one source: the S-th pick is a weak peak more often than not -- a second source, or noise when fewer than S
+    // are active -- and a third to all of the frames are flagged: 8 x 4096 frames with S = 2 / 3 / 4 real sources spend 0.89 / 1.60 /
+    // 1.76 ms in the repair pass, more than the 0.3 ms the coarse contraction saves; MCA_HIP_ADAPT_MAX_SOURCES lifts the limit)
+    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 && c->S <= c->adapt_max_sources &&
            rows >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
 }
 bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames) { return adaptive_shape(c, n_arrays, n_frames) && !c->adapt_suspended; }
@@ -824,6 +828,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         c->tau_en = (float)(scale * 8.0 * std::sqrt(2.0) * sigma_c / (30.0 * c->P));
         if (std::getenv("MCA_HIP_ADAPT_MIN_ROWS")) c->adapt_min_rows = std::atoll(std::getenv("MCA_HIP_ADAPT_MIN_ROWS"));
         if (std::getenv("MCA_HIP_ADAPT_FALLBACK")) c->fb_enabled = std::atoi(std::getenv("MCA_HIP_ADAPT_FALLBACK")) != 0;
+        if (std::getenv("MCA_HIP_ADAPT_MAX_SOURCES")) c->adapt_max_sources = std::atoi(std::getenv("MCA_HIP_ADAPT_MAX_SOURCES"));
     }
 
     int rc = MCA_HIP_OK;
@@ -1310,12 +1315,12 @@ int mca_hip_get_repair_stats(mca_hip_ctx *c, unsigned long long *frames, unsigne
     return MCA_HIP_OK;
 }
 
-// the wave-per-run beamformer (k_beamform_wave) serves one source on the 1024-sample path when the caller's DOAs are grid
+// the wave-per-run beamformer (k_beamform_wave) serves the 1024-sample path (one grid row of workgroups per source) when the caller's DOAs are grid
 // bins (the localiser's own picks); everything else stays on k_beamform_ola / _512 / _gen
 static bool wave_beamformer_applies(const mca_hip_ctx *c)
 {
     const bool off = std::getenv("MCA_HIP_BF_OLA") != nullptr;      // A/B switch for measurements
-    return !off && !c->generic && !c->n512 && c->S == 1 && c->M >= 2 && c->M <= MCA_MAX_MICS;
+    return !off && !c->generic && !c->n512 && c->S <= 2 && c->M >= 2 && c->M <= MCA_MAX_MICS;   // (S = 3, 4: k_beamform_ola shares the forward transforms: 0.54 / 0.64 vs 0.54 / 0.69 ms)
 }
 
 // steering rows of every grid angle (+ the initial DOA): allocated and built once, outside any capture
@@ -1339,14 +1344,14 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (doa_bin && c->d_bftab && wave_beamformer_applies(c)) {
         BeamformWaveArgs wa{};
         wa.pcm = pcm; wa.array_stride = array_stride; wa.mic_stride = mic_stride;
-        wa.M = c->M; wa.n_pairs = c->bf_pairs; wa.n_frames = n_frames;
+        wa.M = c->M; wa.n_pairs = c->bf_pairs; wa.n_frames = n_frames; wa.S = c->S;
         // frames per run (one wave each; every run re-analyses one extra frame for its overlap-add carry): long runs are
         // cheaper per frame, short ones fill the chip -- two waves per SIMD want 2048 runs
         const int ft_env = std::getenv("MCA_HIP_BFW_FT") ? std::atoi(std::getenv("MCA_HIP_BFW_FT")) : 0;
         wa.ft = ft_env > 0 ? ft_env : 16;
-        while (!ft_env && wa.ft > 2 && (long long)n_arrays * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
+        while (!ft_env && wa.ft > 2 && (long long)n_arrays * c->S * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
         wa.window = c->d_window; wa.doa_bin = doa_bin; wa.table = c->d_bftab; wa.out = out_pcm;
-        wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->H;
+        wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->S * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->S * c->H;
         const int abl = std::getenv("MCA_HIP_BFW_ABL") ? std::atoi(std::getenv("MCA_HIP_BFW_ABL")) & 3 : 0;     // measurement only: wrong results
         const int var = abl ? 14 : (std::getenv("MCA_HIP_BFW_VAR") ? std::atoi(std::getenv("MCA_HIP_BFW_VAR")) & 15 : 15);
         // workgroups per array: 4 runs of ft frames each, or (hand-off of the overlap-add carries inside the workgroup, VAR bit 1)
@@ -1354,16 +1359,16 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         // CU: 512) -- one workgroup more than that costs a whole extra round.
         if ((var & 2) && !ft_env) {
             wa.ft = 2;
-            while (wa.ft < 256 && (long long)n_arrays * ((n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1)) > 512) ++wa.ft;
+            while (wa.ft < 256 && (long long)n_arrays * c->S * ((n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1)) > 512) ++wa.ft;
         }
         const int wgs = (var & 2) ? (n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1) : ((n_frames + wa.ft - 1) / wa.ft + 3) / 4;
         const size_t smem = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2) + ((var & 2) ? 4 * FFT_H * sizeof(float) : 0);
         time_begin(c, MCA_HIP_K_BEAMFORM, st);
-#define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), dim3(wgs, n_arrays), dim3(256), smem, st, wa); \
-                            else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), dim3(wgs, n_arrays), dim3(256), smem, st, wa); break;
-        if (abl == 1) hipLaunchKernelGGL((k_beamform_wave<false, 14, 1>), dim3(wgs, n_arrays), dim3(256), smem, st, wa);
-        else if (abl == 2) hipLaunchKernelGGL((k_beamform_wave<false, 14, 2>), dim3(wgs, n_arrays), dim3(256), smem, st, wa);
-        else if (abl == 3) hipLaunchKernelGGL((k_beamform_wave<false, 14, 3>), dim3(wgs, n_arrays), dim3(256), smem, st, wa);
+#define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa); \
+                            else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa); break;
+        if (abl == 1) hipLaunchKernelGGL((k_beamform_wave<false, 14, 1>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);
+        else if (abl == 2) hipLaunchKernelGGL((k_beamform_wave<false, 14, 2>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);
+        else if (abl == 3) hipLaunchKernelGGL((k_beamform_wave<false, 14, 3>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);
         else
         switch (var) {
             BFW_CASE(0) BFW_CASE(1) BFW_CASE(2) BFW_CASE(3) BFW_CASE(4) BFW_CASE(5) BFW_CASE(6) BFW_CASE(7)

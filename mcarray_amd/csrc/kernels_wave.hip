@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
     if (T1REG) lc.load_t1(tab, lane);
 
     const int a = blockIdx.y;
+    const long long as = (long long)a * p.S + blockIdx.z;                // (array, source): output channel, overlap-add carry
     int t0, t1;
     if (HANDOFF) {
         const int w0 = (int)blockIdx.x * (4 * p.ft - 1);                 // the workgroup's first frame
@@ -119,10 +120,10 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
         for (int i = 0; i < 8; ++i) { win[i].x = p.window[lane + 128 * i]; win[i].y = p.window[lane + 128 * i + 64]; }
         if (t0 == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) carry[i] = p.tail_in[(long long)a * FFT_H + lane + 64 * i];
+            for (int i = 0; i < 8; ++i) carry[i] = p.tail_in[as * FFT_H + lane + 64 * i];
         }
         const float *base = p.pcm + (long long)a * p.array_stride + lane;
-        const int *bins = p.doa_bin + (long long)a * p.n_frames;
+        const int *bins = p.doa_bin + (long long)a * p.n_frames * p.S + blockIdx.z;     // [frame][source]
         float xa[16], xb[16];
         auto load_pair = [&](int t, int pr) {
             const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)t * FFT_H;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
 #pragma unroll
         for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
         int t = tfirst, pr = 0;
-        const float2 *trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
+        const float2 *trow = p.table + ((long long)(bins[(long long)t * p.S] + 1) * NP) * 1024 + lane;
         for (;;) {
             float2 z[16], T[16];
 #pragma unroll
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
 #pragma unroll
                         for (int i = 0; i < 8; ++i) first[i] = y[dr16(i)].x;
                     } else {
-                        float *o = p.out + (long long)a * p.n_frames * FFT_H + (long long)t * FFT_H + lane;
+                        float *o = p.out + as * p.n_frames * FFT_H + (long long)t * FFT_H + lane;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) o[64 * i] = carry[i] + y[dr16(i)].x;
                     }
@@ -183,14 +184,14 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
 #pragma unroll
                 for (int i = 0; i < 16; ++i) W[i] = make_float2(0.f, 0.f);
                 ++t; pr = 0;
-                trow = p.table + ((long long)(bins[t] + 1) * NP) * 1024 + lane;
+                trow = p.table + ((long long)(bins[(long long)t * p.S] + 1) * NP) * 1024 + lane;
             } else {
                 ++pr;
             }
         }
         if (t1 == p.n_frames) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) p.tail_out[(long long)a * FFT_H + lane + 64 * i] = carry[i];
+            for (int i = 0; i < 8; ++i) p.tail_out[as * FFT_H + lane + 64 * i] = carry[i];
         }
     }
     if (HANDOFF) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
         for (int i = 0; i < 8; ++i) xcarry[wave * FFT_H + lane + 64 * i] = carry[i];
         __syncthreads();
         if (active && deferred) {
-            float *o = p.out + (long long)a * p.n_frames * FFT_H + (long long)t0 * FFT_H + lane;
+            float *o = p.out + as * p.n_frames * FFT_H + (long long)t0 * FFT_H + lane;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[64 * i] = xcarry[(wave - 1) * FFT_H + lane + 64 * i] + first[i];
         }

@@ -189,12 +189,12 @@ struct BeamformArgs {
 struct BeamformWaveArgs {
     const float *pcm;
     long long array_stride, mic_stride;
-    int M, n_pairs, n_frames, ft;
+    int M, n_pairs, n_frames, ft, S;   // S sources: blockIdx.z, each steered by its own column of doa_bin
     const float *window;     // [1024] periodic Hann
-    const int *doa_bin;      // [arrays][n_frames] grid index of the frame's DOA, -1: the initial _currentDOA = 0
+    const int *doa_bin;      // [arrays][n_frames][S] grid index of the frame's DOA, -1: the initial _currentDOA = 0
     const float2 *table;     // [D + 1][n_pairs][1024] (P_a - j P_b) / (M N) per steering angle (k_bf_table)
-    float *out;              // [arrays][n_frames*hop]
-    const float *tail_in;    // [arrays][hop] overlap-add carry at entry
+    float *out;              // [arrays][S][n_frames*hop]
+    const float *tail_in;    // [arrays][S][hop] overlap-add carry at entry
     float *tail_out;         // at exit
 };
 

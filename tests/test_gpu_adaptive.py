@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 @pytest.fixture(autouse=True)
 def no_back_off(monkeypatch):
     monkeypatch.setenv("MCA_HIP_ADAPT_FALLBACK", "0")        # read by mca_hip_create: these tests are about coarse + repair itself
+    monkeypatch.setenv("MCA_HIP_ADAPT_MAX_SOURCES", "4")     # ... also with several sources (by default such contexts run as FP16X3)
 
 
 @pytest.fixture

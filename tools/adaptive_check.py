@@ -6,6 +6,7 @@ energy compares with the decision margin tau the sensitivity test assumes.
 usage (GPU box): python tools/adaptive_check.py [cases] [seed] > profiles/rNN_adaptive_check.json"""
 import os
 os.environ.setdefault("MCA_HIP_ADAPT_FALLBACK", "0")      # the check is about coarse + repair itself: no backing off to FP16X3
+os.environ.setdefault("MCA_HIP_ADAPT_MAX_SOURCES", "4")   # ... with any number of sources
 import json
 import os
 import sys

@@ -11,12 +11,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcarray_amd import api, synth  # noqa: E402
 
 
-def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10, gate=False):
+def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10, gate=False, sources=False):
     xs = {2: synth.BINAURAL, 4: synth.REEM_C, 8: synth.ULA8, 16: synth.ULA16}[M]
     dev = torch.device("cuda", 0)
     hop = N // 2
     g = torch.Generator(device=dev); g.manual_seed(1)
-    pcm = (torch.randn(A, M, (F + 1) * hop, device=dev, generator=g) * 0.1).contiguous()
+    if sources:         # S far-field white sources per array (bench.py's generator, 48 kHz / 1024 only) instead of noise alone
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        pcm = sum(bench.synth_batch(xs, [1000 * s_ + a for a in range(A)], F, dev)[0] for s_ in range(S))[:, :, :(F + 1) * hop].contiguous()
+    else:
+        pcm = (torch.randn(A, M, (F + 1) * hop, device=dev, generator=g) * 0.1).contiguous()
     ctx = api.Context(fs, xs, N, step, S, srp_precision=prec, max_arrays=A, use_power_floor=gate)
     doa_bin = torch.empty(A, F, S, dtype=torch.int32, device=dev)
     doa_rad = torch.empty(A, F, S, dtype=torch.float32, device=dev)
@@ -71,7 +76,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sources":
         for S in (1, 2, 3, 4):
-            run(8, 48000, 1024, 0.5, 8, 4096, S=S)
+            run(8, 48000, 1024, 0.5, 8, 4096, S=S, sources=True, prec=api.SRP_ADAPTIVE, steps=30)
         sys.exit(0)
     run(8, 48000, 1024, 0.5, 8, 4096)
     run(8, 48000, 1024, 5.0, 8, 4096)

@@ -13,6 +13,7 @@ from oracle import pyoracle as po  # noqa: E402
 import parity_helpers  # noqa: E402
 
 os.environ.setdefault("MCA_HIP_ADAPT_FALLBACK", "0")     # the sweep is about coarse + repair itself: no backing off to FP16X3
+os.environ.setdefault("MCA_HIP_ADAPT_MAX_SOURCES", "4")   # ... with any number of sources
 os.environ.setdefault("MCA_HIP_ADAPT_MIN_ROWS", "128")      # let the adaptive mode run on the small batches the oracle can follow
 TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: 2e-4}
 # a DOA-bin difference is CLASSIFIED if the oracle's own pick on that frame is fragile under perturbations of this size of the
