@@ -593,7 +593,11 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 if (lane < S) s_bin[tl * MCA_MAX_SOURCES + lane] = -1;
                 continue;
             }
+#ifdef MCA_ABL_PICK      /* measurement only: wrong results */
+            const bool sens = false; if (lane < S) { s_bin[tl * MCA_MAX_SOURCES + lane] = 5; s_val[tl * MCA_MAX_SOURCES + lane] = sEn[tl * Dl + lane]; }
+#else
             const bool sens = wave_pick_pl<MODE == 1, PL>(sEn + tl * Dl, D, S, p.tau, s_bin + tl * MCA_MAX_SOURCES, s_val + tl * MCA_MAX_SOURCES, lane);
+#endif
             if (MODE == 1 && lane == 0 && (sens || t == t_force)) atomicOr(&s_flagmask, 1u << tl);
         }
         __syncthreads();
