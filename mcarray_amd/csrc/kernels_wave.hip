@@ -469,12 +469,22 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
             } else {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    float2 r[MT], out[NOUT];
+                    if constexpr (ULA) {
+                        float2 r[MT], out[NOUT];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) r[m] = Xh[m][s];
-                    pair_products<MT, ULA>(r, out);
+                        for (int m = 0; m < MT; ++m) r[m] = Xh[m][s];
+                        pair_products<MT, ULA>(r, out);
 #pragma unroll
-                    for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, voff, g * KG + 64 * s, out[g], p.Kp);
+                        for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, voff, g * KG + 64 * s, out[g], p.Kp);
+                    } else {
+                        // one product per pair: formed and stored one at a time (28 of them held together next to the 128
+                        // registers of spectra spilled 8 ... 42 registers)
+                        int pi = 0;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = i + 1; j < MT; ++j) { store_a_wave<PL2>(arow, voff, pi * KG + 64 * s, cmulc(Xh[i][s], Xh[j][s]), p.Kp); ++pi; }
+                    }
                 }
             }
             if (POWER) {
