@@ -50,9 +50,12 @@ typedef enum {
     MCA_HIP_SRP_ADAPTIVE = 3 /* fp16 coarse scan of every frame + exact repair: the frames whose peak pick is sensitive to the
                                 fp16 error (and the rows their energy depends on) are recomputed with the FP16X3 split and
                                 picked again, so the DOA bins are those of FP16X3 at about the cost of FP16.  Applies to large
-                                batches (>= 4096 frames per call) on the 1024-sample path with more than two microphones, with
-                                or without the power gate; every other call of such a context runs as FP16X3.  The optional
-                                energy map keeps fp16 accuracy on unrepaired frames. */
+                                batches (>= 4096 frames per call) on the 1024-sample path with more than two microphones and
+                                ONE source (with several, the S-th pick is a near tie too often), with or without the power
+                                gate; every other call of such a context runs as FP16X3 -- as do its calls while most rows
+                                need the repair (noise only, silence: the context backs off by itself and probes again
+                                later; MCA_HIP_ADAPT_FALLBACK=0 in the environment pins the mode).  The optional energy map
+                                keeps fp16 accuracy on unrepaired frames. */
 } mca_hip_srp_precision;
 
 /* Weighting of the generalised cross-correlation inside dsp::GeneralisedCrossCorrelation::calculateCorrelationsForPrecomputedTauMatrix
@@ -159,7 +162,7 @@ int mca_hip_separate_frames_dev(mca_hip_ctx *ctx, const float *pcm_dev, long lon
 /* The same with the grid bins behind the angles: doa_bin_dev[a][t][s] as written by
  * mca_hip_localise_frames_dev (-1 = no frame has fired yet, the initial _currentDOA = 0,
  * BeamformingSeparationAndLocalisation.cpp:51), doa_rad_dev = the grid angles of those bins.  With
- * one source on the 1024-sample path the steering phasors then come from a per-angle table built
+ * one or two sources on the 1024-sample path the steering phasors then come from a per-angle table built
  * once per context (no sincos per frame); other configurations run as mca_hip_separate_frames_dev. */
 int mca_hip_separate_frames_bins_dev(mca_hip_ctx *ctx, const float *pcm_dev, long long array_stride,
                                      long long mic_stride, int n_arrays, int n_frames,
