@@ -573,8 +573,8 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
         c->ws().lastv_arrays = n_arrays; ++c->ws_gen;
     }
     if (!c->ws().d_nlist) {
-        HIP_TRY(c, hipMalloc((void **)&c->ws().d_nlist, 8));              // listed repair units, listed chunks
-        HIP_TRY(c, hipMemset(c->ws().d_nlist, 0, 8));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_nlist, 16));             // listed repair units | listed chunks, workgroups of k_scan_repick done
+        HIP_TRY(c, hipMemset(c->ws().d_nlist, 0, 16));
         HIP_TRY(c, hipDeviceSynchronize());
         ++c->ws_gen;
     }
@@ -925,6 +925,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     for (Workspace &w : c->lanes) {
         if (w.d_need) HIP_TRY(c, hipMemsetAsync(w.d_need, 0, w.adapt_groups * 4, st));
         if (w.d_chunk_from) HIP_TRY(c, hipMemsetAsync(w.d_chunk_from, 0x7f, w.adapt_chunks * 4, st));
+        if (w.d_nlist) HIP_TRY(c, hipMemsetAsync(w.d_nlist, 0, 16, st));
     }
     c->gcc2_frames_done = 0;
     return init_last_state(c, st);
@@ -1218,7 +1219,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (adaptive) {
         pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
         pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_from = c->ws().d_chunk_from; pa.last_vchunk = c->ws().d_last_vchunk; pa.stats = c->d_rstats;
-        pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;
+        pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
             c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
             pa.probe = c->h_probe; pa.probe_seq = ++c->fb_calls;
@@ -1227,7 +1228,11 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     const int nthr = round_up(c->D, 64);
     dim3 g3(pa.n_chunks, n_arrays);
     if (!c->ws().partial_done) hipLaunchKernelGGL(k_scan_partial, g3, dim3(round_up(c->Dp / 4, 64)), 0, st, pa);   // a thread per four delays
-    hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays, nthr / 64), dim3(64), 0, st, pa);   // one wave per 64 delays
+    // ungated calls: k_scan_pick composes its chunk's start value itself (the chunks further back than four have decayed below the
+    // last bit); with the gate a chunk may hold no advancing frame at all and the composition runs over all of them, in order
+    static const bool no_lookback = std::getenv("MCA_HIP_SCAN_CARRY") != nullptr;    // A/B switch for measurements
+    pa.lookback = (!gate && !no_lookback) ? 4 : 0;
+    if (!pa.lookback) hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays, nthr / 64), dim3(64), 0, st, pa);   // one wave per 64 delays
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
     const int ppl = c->D - 2 <= 128 ? 2 : c->D - 2 <= 384 ? 6 : 8;            // positions per lane of the peak pick
 #define LAUNCH_PICK(PL, MODE)                                                                                                       \

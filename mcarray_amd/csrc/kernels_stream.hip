@@ -554,10 +554,38 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
     const unsigned char *vc = p.voiced ? p.voiced + (long long)a * p.n_frames : nullptr;
     const float mn = -15.f * (float)p.P, nd = -2.f * mn, nr = p.inv_norm;
-    float E = act ? p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d] : 0.f;
+    float E = 0.f;
+    if (p.lookback > 0) {
+        // E at the start of this chunk from the chunk-local results b_j (the recursion run from zero inside chunk j, k_scan_partial or
+        // the contraction's epilogue) of the chunks before it: E_c = g E_{c-1} + b_{c-1}, g = 0.8f^32 -- the composition k_scan_carry
+        // runs over all chunks of an array in order, cut off `lookback` chunks back (or at the array's state at entry)
+        constexpr int LB = 4;
+        if (act) {
+            const int c = blockIdx.x, j0 = max(0, c - LB);
+            float g = 1.f;
+            for (int i = 0; i < p.chunk; ++i) g *= mu;                                   // (as k_scan_carry's table)
+            const float *pp = p.part + (long long)a * p.n_chunks * D + d;
+            float b[LB];
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                const int j = min(j0 + i, p.n_chunks - 1);
+                b[i] = pp[(long long)j * D];
+                if (p.part_planes == 2) b[i] += pp[(long long)j * D + p.part_plane_stride];   // the contraction's two K halves, half 0 first
+            }
+            E = j0 == 0 ? p.state_in[(long long)a * D + d] : 0.f;
+#pragma unroll
+            for (int i = 0; i < LB; ++i)
+                if (j0 + i < c) E = g * E + b[i];
+            p.e_start[((long long)a * p.n_chunks + c) * D + d] = E;                       // (k_scan_repick restarts from it)
+        }
+    } else if (act) {
+        E = p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d];
+    }
+    const int last_vchunk = p.lookback > 0 ? p.n_chunks - 1 : (MODE == 1 ? p.last_vchunk[a] : -1);
+    if (MODE == 1 && p.lookback > 0 && (int)blockIdx.x == p.n_chunks - 1 && d == 0) p.last_vchunk[a] = p.n_chunks - 1;
     // MODE 1: the array's last frame that advances the recursion (this chunk holds it) is always repaired
     int t_force = -1;
-    if (MODE == 1 && (int)blockIdx.x == p.last_vchunk[a]) {
+    if (MODE == 1 && (int)blockIdx.x == last_vchunk) {
         const int u = t_start + lane;
         const unsigned long long m = __ballot(u < t_end && (!vc || vc[u] != 0));
         if (m) t_force = t_start + 63 - __clzll((long long)m);
@@ -650,6 +678,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         }
         __syncthreads();
     }
+    if (p.lookback > 0 && act && (int)blockIdx.x == p.n_chunks - 1) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143)
 }
 template __global__ void k_scan_pick<2, 0>(ScanPickArgs);
 template __global__ void k_scan_pick<6, 0>(ScanPickArgs);
@@ -743,6 +772,12 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     if (act && chunk == p.last_vchunk[a]) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
     __syncthreads();                                                        // (every thread has read chunk_from[ci])
     if (d == 0) p.chunk_from[ci] = 0x7f7f7f7f;                              // consumed: no flagged frame
+    }
+    // the last workgroup to get here leaves both lists of the repair pass empty for the next call (every reader of n_list ran
+    // before this kernel, every reader of n_clist is a workgroup of it that has counted itself in)
+    if (d == 0) {
+        __threadfence();
+        if (atomicAdd(p.n_clist + 1, 1) == (int)gridDim.x - 1) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
     }
 }
 template __global__ void k_scan_repick<2>(ScanPickArgs);

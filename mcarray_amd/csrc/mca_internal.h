@@ -123,7 +123,9 @@ struct ScanPickArgs {
     int *list;               // [arrays * groups_per_array] groups whose rows are recomputed, in order of arrival
     int *n_list;             // [1] their number (reset by k_scan_carry)
     int *chunk_from;         // [arrays][n_chunks] chunk the second pick of this chunk restarts from, >= n_chunks: no flagged frame (reset by k_scan_repick)
-    int *clist; int *n_clist;     // [arrays * n_chunks], [1]: the chunks that hold a flagged frame, in order of arrival (k_scan_repick walks them; reset by k_scan_carry)
+    int *clist; int *n_clist;     // [arrays * n_chunks], [2] (the second word counts the workgroups of k_scan_repick that are done: the last one empties both lists): the chunks that hold a flagged frame, in order of arrival (k_scan_repick walks them; reset by k_scan_carry)
+    int lookback;                 // > 0 (ungated calls): no k_scan_carry -- k_scan_pick composes the start value of its chunk from the chunk-local
+                                  // results of the `lookback` chunks before it (0.8^32 per chunk: the fifth chunk back is 3e-16 of it) and stores it
     unsigned long long *probe;    // host-mapped [3] or NULL: k_scan_repick leaves stats[0], stats[1] and probe_seq there (api.hip: adapt_policy_begin)
     unsigned long long probe_seq;
     int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
