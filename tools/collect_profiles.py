@@ -72,7 +72,7 @@ if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
     if lines:
         open(os.path.join(P, "%s_bench_mvdr.json" % tag), "w").write(lines[-1])
-for name in ("adaptive_check.json", "precision_report.json", "host_path.log", "bench_128x256.json", "bench_single_stream.json", "shapes.log", "gputest.log"):
+for name in ("adaptive_check.json", "precision_report.json", "host_path.log", "bench_128x256.json", "bench_single_stream.json", "shapes.log", "gputest.log", "fallback.log"):
     src = os.path.join(G, "final", name)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(P, "%s_%s" % (tag, name)))

@@ -21,5 +21,8 @@ bash tools/pmc_sq.sh adaptive gpurun_out/pmc_sq > gpurun_out/final/pmc_sq.log 2>
 timeout 600 python tools/adaptive_check.py 40 2026 > gpurun_out/final/adaptive_check.json 2> gpurun_out/final/adaptive_check.log
 timeout 600 python tools/precision_report.py > gpurun_out/final/precision_report.json 2> gpurun_out/final/precision_report.log
 timeout 300 python tools/host_path_rate.py > gpurun_out/final/host_path.log 2>&1
+# the ADAPTIVE mode on noise-only input with and without its back-off; other shapes; several sources; the power gate
+python tools/bench_fallback.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/fallback.log
+(python tools/bench_shapes.py; python tools/bench_shapes.py sources; python tools/bench_shapes.py gate) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/shapes.log
 tail -c 400 gpurun_out/final/bench_adaptive.log
 cat gpurun_out/final/kernel_stats_adaptive.csv
