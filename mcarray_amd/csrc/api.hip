@@ -1289,11 +1289,12 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         }
         set_call_planes(c, 1);
         const size_t smem4 = (size_t)32 * (c->Dp + 8) * sizeof(float);
+        static const int repick_grid = std::getenv("MCA_HIP_REPICK_GRID") ? std::max(1, std::atoi(std::getenv("MCA_HIP_REPICK_GRID"))) : 256;   // A/B switch
 #define LAUNCH_REPICK(PL)                                                                                                           \
         do {                                                                                                                        \
             if (smem4 > 64 * 1024)      /* grids finer than 0.45 degrees: Dp >= 512 */                                              \
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_repick<PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)); \
-            hipLaunchKernelGGL((k_scan_repick<PL>), dim3((unsigned)std::min<long long>((long long)pa.n_chunks * n_arrays, 256)), dim3(std::max(nthr, 512)), smem4, st, pa); \
+            hipLaunchKernelGGL((k_scan_repick<PL>), dim3((unsigned)std::min<long long>((long long)pa.n_chunks * n_arrays, repick_grid)), dim3(std::max(nthr, 512)), smem4, st, pa); \
         } while (0)
         if (ppl == 2) LAUNCH_REPICK(2); else if (ppl == 6) LAUNCH_REPICK(6); else LAUNCH_REPICK(8);
 #undef LAUNCH_REPICK

@@ -729,18 +729,11 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     const int t_start = chunk * p.chunk;
     const int t_end = min(t_start + p.chunk, p.n_frames);
     const float *C = p.C + (long long)a * p.n_frames * p.Dp;
-    float E = act ? p.e_start[((long long)a * p.n_chunks + c_from) * D + d] : 0.f;
-    for (int tb = c_from * p.chunk; tb < t_end; tb += REPICK_B) {
-        const int te = min(tb + REPICK_B, t_end);
-        // per batch: which frames advance the recursion (all without the gate), which are picked again (flagged, this chunk only);
-        // every wave works the two masks out for itself from one byte per lane
-        const int u = tb + (lane & 31);
-        const unsigned vm = (unsigned)__ballot(lane < 32 && u < te && (!vc || vc[u] != 0));
-        const unsigned bm = tb >= t_start ? (unsigned)__ballot(lane < 32 && u < te && fl[u] != 0) : 0u;
+    float E = 0.f;
+    // one batch of <= 32 frames from tb on: the recursion over the rows c32 (advancing frames: mask vm), then the second pick of the
+    // flagged frames of this chunk (mask bm), one wave per frame
+    auto batch = [&](int tb, int te, unsigned vm, unsigned bm, const float (&c32)[REPICK_B]) {
         if (act) {
-            float c32[REPICK_B];
-#pragma unroll
-            for (int i = 0; i < REPICK_B; ++i) c32[i] = csum(C, (long long)min(tb + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
 #pragma unroll
             for (int i = 0; i < REPICK_B; ++i) {
                 const int t = tb + i;
@@ -767,6 +760,45 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
                 }
             }
             __syncthreads();
+        }
+    };
+    if (!vc && p.chunk == REPICK_B) {
+        // Without the gate the walk starts in this chunk or in the one before it (REPAIR_WARM < chunk): both start values and the
+        // rows of both chunks are requested before c_from is looked at -- two rounds of loads less on the critical path of a kernel
+        // that is nothing but dependent loads (list -> chunk_from -> start value -> rows -> rows -> pick)
+        const int cprev = max(chunk - 1, 0), te = t_end;
+        const int u = t_start + (lane & 31);
+        const unsigned bm = (unsigned)__ballot(lane < 32 && u < te && fl[u] != 0);
+        float r0[REPICK_B], r1[REPICK_B];
+        if (act) {
+            const float e1 = p.e_start[((long long)a * p.n_chunks + chunk) * D + d], e0 = p.e_start[((long long)a * p.n_chunks + cprev) * D + d];
+#pragma unroll
+            for (int i = 0; i < REPICK_B; ++i) r0[i] = csum(C, (long long)(cprev * REPICK_B + i) * p.Dp + d, p.c_planes, p.c_plane_stride);
+#pragma unroll
+            for (int i = 0; i < REPICK_B; ++i) r1[i] = csum(C, (long long)min(t_start + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+            E = e1;
+            if (c_from < chunk) {
+                E = e0;
+#pragma unroll
+                for (int i = 0; i < REPICK_B; ++i) E = iir_step(mu, E, omu, r0[i]);     // (a whole chunk: it is not the array's last)
+            }
+        }
+        batch(t_start, te, 0xffffffffu, bm, r1);
+    } else {
+        if (act) E = p.e_start[((long long)a * p.n_chunks + c_from) * D + d];
+        for (int tb = c_from * p.chunk; tb < t_end; tb += REPICK_B) {
+            const int te = min(tb + REPICK_B, t_end);
+            // per batch: which frames advance the recursion (all without the gate), which are picked again (flagged, this chunk only);
+            // every wave works the two masks out for itself from one byte per lane
+            const int u = tb + (lane & 31);
+            const unsigned vm = (unsigned)__ballot(lane < 32 && u < te && (!vc || vc[u] != 0));
+            const unsigned bm = tb >= t_start ? (unsigned)__ballot(lane < 32 && u < te && fl[u] != 0) : 0u;
+            float c32[REPICK_B];
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < REPICK_B; ++i) c32[i] = csum(C, (long long)min(tb + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+            }
+            batch(tb, te, vm, bm, c32);
         }
     }
     if (act && chunk == p.last_vchunk[a]) p.state_out[(long long)a * D + d] = E;   // _prevEnergyInDOA (:143), exact
