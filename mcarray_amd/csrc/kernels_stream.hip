@@ -291,6 +291,29 @@ __device__ __forceinline__ float csum(const float *C, long long o, int planes, l
     for (int pl = 1; pl < planes; ++pl) v += C[o + pl * stride];
     return v;
 }
+// The same for N rows at once.  Through csum a row's sum is a loop of unknown length that waits for every load before the
+// next one goes out -- N rows "in flight" were N round trips in a row.  Here all loads of a plane go out together; one and
+// two planes (every large batch: the contraction's two K halves) are straight-line code.
+template <int N, typename Row>
+__device__ __forceinline__ void csum_rows(float (&v)[N], const float *C, Row row_offset, int planes, long long stride)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = C[row_offset(i)];
+    if (planes >= 2) {
+        float w[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) w[i] = C[row_offset(i) + stride];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += w[i];
+    }
+    for (int pl = 2; pl < planes; ++pl) {
+        float w[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) w[i] = C[row_offset(i) + pl * stride];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += w[i];
+    }
+}
 
 // Folds the partial maps of a deep split-K contraction (small batches: up to 16 maps) into map 0, plane 0
 // first, four elements per thread; the scan kernels then read one map.  n4 = elements / 4.
@@ -329,13 +352,13 @@ __global__ __launch_bounds__(256) void k_scan_partial(ScanPickArgs p)
         for (int t0 = t_start; t0 < t_end; t0 += LD) {
             float4 r[LD];
 #pragma unroll
-            for (int i = 0; i < LD; ++i) {
-                const long long o = (long long)min(t0 + i, t_end - 1) * p.Dp + d0;
-                r[i] = *reinterpret_cast<const float4 *>(C + o);
-                for (int pl = 1; pl < p.c_planes; ++pl) {          // the partial maps of a split-K contraction, plane 0 first
-                    const float4 w = *reinterpret_cast<const float4 *>(C + o + pl * p.c_plane_stride);
-                    r[i].x += w.x; r[i].y += w.y; r[i].z += w.z; r[i].w += w.w;
-                }
+            for (int i = 0; i < LD; ++i) r[i] = *reinterpret_cast<const float4 *>(C + (long long)min(t0 + i, t_end - 1) * p.Dp + d0);
+            for (int pl = 1; pl < p.c_planes; ++pl) {              // the partial maps of a split-K contraction, plane 0 first; a plane's loads together
+                float4 w[LD];
+#pragma unroll
+                for (int i = 0; i < LD; ++i) w[i] = *reinterpret_cast<const float4 *>(C + (long long)min(t0 + i, t_end - 1) * p.Dp + d0 + pl * p.c_plane_stride);
+#pragma unroll
+                for (int i = 0; i < LD; ++i) { r[i].x += w[i].x; r[i].y += w[i].y; r[i].z += w[i].z; r[i].w += w[i].w; }
             }
 #pragma unroll
             for (int i = 0; i < LD; ++i)
@@ -600,8 +623,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 #pragma unroll
                     for (int i = 0; i < SCAN_LD; ++i) c8[i] = C[(long long)min(t0 + i, te - 1) * p.Dp + d];
                 } else {
-#pragma unroll
-                    for (int i = 0; i < SCAN_LD; ++i) c8[i] = csum(C, (long long)min(t0 + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+                    csum_rows(c8, C, [&](int i) { return (long long)min(t0 + i, te - 1) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
                 }
 #pragma unroll
                 for (int i = 0; i < SCAN_LD; ++i) {
@@ -772,10 +794,8 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
         float r0[REPICK_B], r1[REPICK_B];
         if (act) {
             const float e1 = p.e_start[((long long)a * p.n_chunks + chunk) * D + d], e0 = p.e_start[((long long)a * p.n_chunks + cprev) * D + d];
-#pragma unroll
-            for (int i = 0; i < REPICK_B; ++i) r0[i] = csum(C, (long long)(cprev * REPICK_B + i) * p.Dp + d, p.c_planes, p.c_plane_stride);
-#pragma unroll
-            for (int i = 0; i < REPICK_B; ++i) r1[i] = csum(C, (long long)min(t_start + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+            csum_rows(r0, C, [&](int i) { return (long long)(cprev * REPICK_B + i) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
+            csum_rows(r1, C, [&](int i) { return (long long)min(t_start + i, te - 1) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
             E = e1;
             if (c_from < chunk) {
                 E = e0;
@@ -795,8 +815,7 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
             const unsigned bm = tb >= t_start ? (unsigned)__ballot(lane < 32 && u < te && fl[u] != 0) : 0u;
             float c32[REPICK_B];
             if (act) {
-#pragma unroll
-                for (int i = 0; i < REPICK_B; ++i) c32[i] = csum(C, (long long)min(tb + i, te - 1) * p.Dp + d, p.c_planes, p.c_plane_stride);
+                csum_rows(c32, C, [&](int i) { return (long long)min(tb + i, te - 1) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
             }
             batch(tb, te, vm, bm, c32);
         }
@@ -1467,11 +1486,7 @@ __global__ __launch_bounds__(256) void k_gcc2_scan(Gcc2ScanArgs p)
         float c = warm_start == 0 ? p.corr_in[(long long)a * D + d] : 0.f;
         for (int t0 = warm_start; t0 < t_end; t0 += 8) {                  // 8 independent loads in flight, then the serial recursion
             float r8[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int j = min(t0 + i, t_end - 1);
-                r8[i] = csum(C, (long long)(vi ? vi[j] : j) * p.Dp + d, p.c_planes, p.c_plane_stride);
-            }
+            csum_rows(r8, C, [&](int i) { const int j = min(t0 + i, t_end - 1); return (long long)(vi ? vi[j] : j) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int t = t0 + i;
