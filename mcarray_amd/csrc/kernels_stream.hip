@@ -360,9 +360,11 @@ __global__ __launch_bounds__(256) void k_scan_partial(ScanPickArgs p)
 #pragma unroll
                 for (int i = 0; i < LD; ++i) { r[i].x += w[i].x; r[i].y += w[i].y; r[i].z += w[i].z; r[i].w += w[i].w; }
             }
+            // (the gate flags of the batch as a mask, one byte per lane: a load of vc[t] inside the recursion is a round trip per step)
+            const unsigned vm = (unsigned)__ballot((int)(threadIdx.x & 63) < LD && t0 + (int)(threadIdx.x & 63) < t_end && (!vc || vc[t0 + (threadIdx.x & 63)] != 0));
 #pragma unroll
             for (int i = 0; i < LD; ++i)
-                if (t0 + i < t_end && (!vc || vc[t0 + i])) {
+                if ((vm >> i) & 1u) {
                     b.x = iir_step(p.mu, b.x, p.one_minus_mu, r[i].x); b.y = iir_step(p.mu, b.y, p.one_minus_mu, r[i].y);
                     b.z = iir_step(p.mu, b.z, p.one_minus_mu, r[i].z); b.w = iir_step(p.mu, b.w, p.one_minus_mu, r[i].w);
                     ++nv;
@@ -616,20 +618,26 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
         if (d == 0) s_flagmask = 0u;
+        // the batch's frames that passed the power gate (all without it), one bit each: every wave works the mask out for itself
+        // from one byte per lane (a load of vc[t] inside the recursion made every step of it a round trip to memory)
+        const unsigned vmask = (unsigned)__ballot(lane < 32 && ts + (lane & 31) < te && (!vc || vc[ts + (lane & 31)] != 0));
         if (act) {
-            for (int t0 = ts; t0 < te; t0 += SCAN_LD) {
-                float c8[SCAN_LD];
+            auto load_rows = [&](float (&c8)[SCAN_LD], int t0) {
                 if (p.c_planes == 1) {
 #pragma unroll
                     for (int i = 0; i < SCAN_LD; ++i) c8[i] = C[(long long)min(t0 + i, te - 1) * p.Dp + d];
                 } else {
                     csum_rows(c8, C, [&](int i) { return (long long)min(t0 + i, te - 1) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
                 }
+            };
+            for (int t0 = ts; t0 < te; t0 += SCAN_LD) {       // (requesting the next rows before these are used measured the same: 42 us)
+                float c8[SCAN_LD];
+                load_rows(c8, t0);
 #pragma unroll
                 for (int i = 0; i < SCAN_LD; ++i) {
                     const int t = t0 + i;
                     if (t < te) {
-                        if (!vc || vc[t]) E = iir_step(mu, E, omu, c8[i]);            // :134-140
+                        if ((vmask >> (t - ts)) & 1u) E = iir_step(mu, E, omu, c8[i]);   // :134-140
                         if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
                         sEn[(t - ts) * Dl + d] = normalised_energy(E, mn, nd, nr);   // :155-156
                     }
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         __syncthreads();
         for (int tl = wave; tl < te - ts; tl += nwaves) {
             const int t = ts + tl;
-            if (vc && !vc[t]) {                                         // gated out: selectDOA is not reached (:87)
+            if (!((vmask >> tl) & 1u)) {                                // gated out: selectDOA is not reached (:87)
                 if (lane < S) s_bin[tl * MCA_MAX_SOURCES + lane] = -1;
                 continue;
             }
