@@ -290,6 +290,10 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
     float2 *wbase = tab + F1K_TWORDS + (MERGE ? NRANK / 4 : 0);
     float2 *buf = wbase + wave * regw;
     float2 *nyq = wbase + 4 * regw + wave * (p.fpb * NP);                         // [fpb][NP] Z_p[512] of the run's frames (not MERGE)
+    // list mode: the length of the list and this workgroup's first entry are requested before the tables are built (the barrier
+    // below would hold the loads back: three dependent round trips -- length, entry, samples -- in front of a single frame per wave)
+    const int n_list_now = p.list ? *p.n_list : 0;
+    const int e_first = (p.list && p.list0 + (int)blockIdx.x < n_list_now) ? p.list[p.list0 + (int)blockIdx.x] : 0;
     f1k_table_init(tab, tid, 256);
     if (MERGE) {
         // per lane, spacing g and half h: the region offsets (in words) of its four products k g, k = lam + 64 (4 h + s):
@@ -314,13 +318,13 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
 
     // regular mode: wave w of workgroup b takes the run of p.fpb frames number 4 b + w.  List mode (repair pass of the adaptive
     // SRP precision): workgroup b walks the listed groups of REPAIR_GROUP = 4 frames, wave w takes frame w of a group.
-    const int li_end = p.list ? min(*p.n_list, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
+    const int li_end = p.list ? min(n_list_now, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
     for (int li = p.list ? p.list0 + (int)blockIdx.x : 0; li < li_end; li += li_step) {
         int a = blockIdx.y;
         int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
         long long row_base = (long long)a * p.n_frames;     // A row of frame f = row_base + f
         if (p.list) {
-            const int e = p.list[li];
+            const int e = li == p.list0 + (int)blockIdx.x ? e_first : p.list[li];
             a = e / p.groups_per_array;
             const int g_begin = (e - a * p.groups_per_array) * REPAIR_GROUP;
             row_base = (long long)(li - p.list0) * REPAIR_GROUP - g_begin;
