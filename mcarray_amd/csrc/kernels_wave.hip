@@ -269,6 +269,21 @@ __device__ __forceinline__ unsigned or3(unsigned a, unsigned b, unsigned c)
 
 typedef __attribute__((address_space(3))) float lds_float_t;
 
+// sum over the 64 lanes on v_add_f32 with a DPP source operand (quad swaps, row rotations, the two cross-row broadcasts of gfx9);
+// taken from lane 63, uniform.  (A DPP read needs two wait states after the vector write of its source.)
+__device__ __forceinline__ float wave_sum64(float v)
+{
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // MERGE (ULA, one fp16 plane): the contraction index is the product m = k (j - i) -- all (bin, spacing) combinations of equal
 // product share one steering column (api.hip, build_merged_tables), so their PHAT sums are added up before they are stored:
 // the lane's 8 x (M - 1) sums go into the wave's LDS region (the transform's scratch, free by then) with ds_add_f32 at
@@ -495,9 +510,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
                 // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2 over the channels, / M, w = 2 except
                 // DC and Nyquist: the sum over the full spectrum, = N sum_n (w[n] x[n])^2 (Parseval) -- taken from the windowed
                 // samples, where it costs 16 instructions per pair and no register across the transforms
-                float pacc = ptime.x + ptime.y;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) pacc += __shfl_xor(pacc, off);
+                const float pacc = wave_sum64(ptime.x + ptime.y);                    // (six DPP adds: the shuffles were six round trips through the LDS crossbar)
                 if (lane == 0) p.power[(long long)a * p.total_frames + p.frame0 + f] = pacc / (float)FFT_N / (float)MT;
             }
         }
