@@ -1230,7 +1230,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (!c->ws().partial_done) hipLaunchKernelGGL(k_scan_partial, g3, dim3(round_up(c->Dp / 4, 64)), 0, st, pa);   // a thread per four delays
     // ungated calls: k_scan_pick composes its chunk's start value itself (the chunks further back than four have decayed below the
     // last bit); with the gate a chunk may hold no advancing frame at all and the composition runs over all of them, in order
-    static const bool no_lookback = std::getenv("MCA_HIP_SCAN_CARRY") != nullptr;    // A/B switch for measurements
+    const bool no_lookback = std::getenv("MCA_HIP_SCAN_CARRY") != nullptr;           // A/B switch for measurements and tests (read per call)
     pa.lookback = (!gate && !no_lookback) ? 4 : 0;
     if (!pa.lookback) hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays, nthr / 64), dim3(64), 0, st, pa);   // one wave per 64 delays
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);

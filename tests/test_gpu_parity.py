@@ -167,6 +167,35 @@ def test_frame_api_other_fft_size():
     np.testing.assert_allclose(y, yo, rtol=0, atol=1e-10 * np.abs(yo).max())
 
 
+@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_ADAPTIVE])
+def test_chunk_start_values_by_look_back_equal_the_carry_pass(monkeypatch, prec):
+    """Ungated calls let every pick workgroup compose the start value of its 32-frame chunk from the chunk-local results of the four
+    chunks before it (0.8^32 per chunk: the fifth back is 3e-16 of it) instead of running k_scan_carry over all chunks in order
+    (MCA_HIP_SCAN_CARRY=1): same bins, energies equal to the last bits, over two calls, with a loud source that stops (the case in
+    which a dropped term would show first)."""
+    fs, N, F, A = 48000, 1024, 1280, 3
+    xs = synth.ULA8
+    monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "256")     # (read by mca_hip_create: the adaptive case runs coarse + repair at this size)
+    monkeypatch.setenv("MCA_HIP_ADAPT_FALLBACK", "0")
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-55.0 + 50 * a), fs, (F + 1) * N // 2, 300 + a, snr_db=15.0) for a in range(A)])
+    pcm[:, :, (F // 2) * 512:] *= 1e-3                       # the energy falls by 60 dB in the middle of the stream
+    res = {}
+    for carry in (False, True):
+        if carry:
+            monkeypatch.setenv("MCA_HIP_SCAN_CARRY", "1")
+        else:
+            monkeypatch.delenv("MCA_HIP_SCAN_CARRY", raising=False)
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=prec, max_arrays=A)
+        cut = 700
+        ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * 512], want_energy=True)
+        rb = ctx.process_frames_host(pcm[:, :, cut * 512:], want_energy=True)
+        res[carry] = {k: np.concatenate([ra[k], rb[k]], axis=1) for k in ("bin", "energy")}
+        ctx.close()
+    assert np.array_equal(res[False]["bin"], res[True]["bin"])
+    scale = np.abs(res[True]["energy"]).max(axis=2, keepdims=True) + 1e-30
+    assert (np.abs(res[False]["energy"] - res[True]["energy"]) / scale).max() <= 4e-7
+
+
 def test_state_carries_across_calls():
     # E_prev (SteeringBeamforming.h:69) and the overlap-add tail continue across process() calls
     fs, N, F = 48000, 1024, 48
