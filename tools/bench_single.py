@@ -1,3 +1,5 @@
+"""Per-call time and per-kernel times (the library's hipEvent brackets) of small stream calls in the adaptive precision: the
+literal BASELINE configs[2] call (1 array x 4096 frames), 2 x 4096 and 1 x 8192.  usage (GPU box): python tools/bench_single.py"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from mcarray_amd import api, synth

@@ -1,3 +1,5 @@
+"""Per-kernel average / minimum duration and grid of the mca:: kernels in a rocprofv3 results database.
+usage: rocprofv3 --kernel-trace --stats -d DIR -o NAME -- python3 bench.py ... ; python tools/rocprof_agg.py DIR/NAME_results.db"""
 import sqlite3,re,collections,sys
 db=sqlite3.connect(sys.argv[1])
 rows=list(db.execute("select name, duration, grid_x, grid_y, workgroup_x from kernels"))
