@@ -178,15 +178,24 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
     for (int t = 0; t < t_last; ++t) {
         float2 x[Q], d[Q], rd[Q], rx[Q];
         float dsum[Q];
+        // All loads of the frame go out together and without branches (the next frame's spectra: the last frame reloads its own), THEN
+        // the steering products are formed.  With the load, the product and the conditional prefetch of one row slot after the
+        // other, every slot waited for its own round trip to memory -- and for the "prefetch" issued just before it: four round
+        // trips in a row at the top of every frame of every problem.
+        float2 th[Q], tl[Q];
+        const long long tn = (long long)min(t + 1, t_last - 1) * fstride;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const bool rv = FULL || 4 * q + l < M;
-            x[q] = xn[q];
-            if (t + 1 < t_last && rv) xn[q] = X[(long long)(t + 1) * fstride + 4 * q];
             // steering d_i = exp(-j k s_i), s_i = 2 pi fs/N/c x_i cos(DOA + pi/2), from the factored tables of the analysis
             const float2 *tq = T + ((long long)t * M + (rv ? 4 * q + l : 0)) * nph;
-            d[q] = rv ? cmul(tq[0], tq[lo_off]) : make_float2(0.f, 0.f);
+            th[q] = tq[0]; tl[q] = tq[lo_off];
+            x[q] = xn[q];
         }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) xn[q] = (FULL || 4 * q + l < M) ? X[tn + 4 * q] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) d[q] = (FULL || 4 * q + l < M) ? cmul(th[q], tl[q]) : make_float2(0.f, 0.f);
         // Phi <- alpha Phi + (1 - alpha) x x^H (the rows of this lane), tr <- alpha tr + (1 - alpha) |x|^2
         float e = 0.f;
 #pragma unroll
