@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0
 PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0, "adaptive": 2500.0}   # dense MFMA peaks, same guide
 PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2, "adaptive": 3}
 ROW_PAD = 64                                           # floats of padding behind every channel row of the synthetic input (synth_batch)
-PROFILE_TAG = "r03"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
+PROFILE_TAG = "r04"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
 
 
 def synth_batch(xs, seeds, n_frames, device, noise=0.01):
@@ -89,10 +89,12 @@ def cpu_baseline_all_cores(pcm_host_arrays, n_frames):
     return cores * n_frames / dt, dt, cores
 
 
-def timed_loop(step, drain, steps, warmup, use_dist, dist, dev, before_timed=None):
+def timed_loop(step, drain, steps, warmup, use_dist, dist, dev, before_timed=None, after_first_warmup=None):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
-    for _ in range(warmup):
+    for i in range(warmup):
         step()
+        if i == 0 and after_first_warmup:
+            after_first_warmup()
     drain()
     torch.cuda.synchronize()
     if before_timed:
@@ -115,19 +117,132 @@ def timed_loop(step, drain, steps, warmup, use_dist, dist, dev, before_timed=Non
     return elapsed
 
 
-def traffic_from_profiles(roof, dom, precision, shape_matches):
-    """HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh): NOT measured in this
-    run -- a --pmc pass serialises the kernels and cannot share a process with the timed loop."""
-    tj = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_TAG, precision))
-    if os.path.exists(tj) and shape_matches:
+def traffic_table(precision, shape_matches):
+    """HBM bytes per step and kernel group from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh): NOT measured in this run --
+    a --pmc pass serialises the kernels and cannot share a process with the timed loop.  Newest committed round first."""
+    if not shape_matches:
+        return {}, None
+    for tag in (PROFILE_TAG, "r03"):
+        tj = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (tag, precision))
+        if not os.path.exists(tj):
+            continue
         kernels = json.load(open(tj))["kernels"]
-        # timing group -> kernel of the committed summary (round 3: the wave-per-run kernels serve the bench shape)
-        kk = kernels.get({"k_stft_phat": "k_stft_phat_wave", "k_beamform_ola": "k_beamform_wave"}.get(dom, dom)) or kernels.get(dom)
-        if kk:   # gfx950: FETCH_SIZE reports half of a WIDE coalesced read stream; the summary carries the factor per kernel
-            roof["traffic"] = kk.get("hbm_bytes_per_step", (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0)
-            roof["traffic_unit"] = ("bytes per step of this kernel (rocprofv3 FETCH_SIZE x fetch_factor + WRITE_SIZE, separate PMC passes; in the "
-                                    "adaptive mode the analysis kernel's figure includes its second, list-mode launch of the repair pass: ~3 %)")
-            roof["traffic_source"] = "profiles/%s_pmc_traffic_%s.json (committed PMC passes of the same command on an MI355X; not this run)" % (PROFILE_TAG, precision)
+        out = {}
+        # timing group -> kernels of the committed summary (the wave-per-run kernels serve the bench shape)
+        groups = {"k_stft_phat": ("k_stft_phat_wave", "k_stft_phat"), "k_beamform_ola": ("k_beamform_wave", "k_beamform_ola"),
+                  "k_srp_gemm": ("k_srp_gemm_f16_v3", "k_srp_gemm_f16_v2", "k_srp_gemm_f16", "k_srp_gemm_f32", "k_srp_gemm"),
+                  "k_scan_pick": ("k_scan_pick",), "repair": ("k_srp_gemm_repair", "k_repair_patch", "k_scan_repick")}
+        for grp, names in groups.items():
+            tot, seen = 0.0, False
+            for nm in names:
+                kk = kernels.get(nm)
+                if kk:   # gfx950: FETCH_SIZE reports half of a WIDE coalesced read stream; the summary carries the factor per kernel
+                    tot += kk.get("hbm_bytes_per_step", (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0)
+                    seen = True
+                    if grp != "repair":
+                        break
+            if seen:
+                out[grp] = tot
+        return out, "profiles/%s_pmc_traffic_%s.json (committed PMC passes of the same command on an MI355X; not this run)" % (tag, precision)
+    return {}, None
+
+
+
+def das_single_stream(pcm, theta, dev, stream, local_rank, calls):
+    """BASELINE configs[1]: ONE 8-microphone stream through the delay-and-sum beamformer alone (48 kHz, 1024-point STFT), steered by a
+    caller-given angle -- the caller modelled on the reference's mcabeamf (src/programs/mcabeamf.cpp:77-122; Beamformer.cpp:51-71).
+    Offline: 936 frames (10 s) per call.  Live: the same stream chunk by chunk, every chunk ONE HIP-graph launch (mca_hip_graph_*,
+    doa_bin NULL = separation only), latency = launch to results on the stream, host-timed with a synchronisation per chunk."""
+    from mcarray_amd import api, synth
+    F1 = 936
+    das_bytes = M * HOP * 4 + HOP * 4                              # SURVEY 8d: DAS-only 18 432 B per frame
+    c1 = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=api.SRP_FP16, max_arrays=1, device=local_rank)
+    p1 = pcm[:1, :, :(F1 + 1) * HOP].contiguous()
+    ang = float(theta[0])
+    rad = torch.full((1, F1, 1), ang, dtype=torch.float32, device=dev)
+    grid = torch.from_numpy(c1.doa_grid()).to(dev)
+    gbin = torch.full((1, F1, 1), int(torch.argmin((grid - ang).abs())), dtype=torch.int32, device=dev)
+    grad = grid[gbin.long()].to(torch.float32).contiguous()
+    out = torch.empty(1, 1, F1 * HOP, dtype=torch.float32, device=dev)
+    n1 = max(10, min(calls, 100))
+    res = {"workload": "BASELINE configs[1]: 1 array (8-mic ULA), delay-and-sum only (localise = False), caller-given DOA %.2f deg, 48 kHz, N=1024" % np.degrees(ang),
+           "algorithmic_bytes_per_frame": das_bytes}
+    for key, kw, r_ in (("offline_any_angle", dict(bins_are_grid=False), rad), ("offline_grid_angle", dict(bins_are_grid=True), grad)):
+        e = timed_loop(lambda: c1.process_frames_dev(p1, F1, gbin, r_, None, None, out, stream=stream, localise=False, separate=True, **kw),
+                       lambda: None, n1, 5, False, None, dev)
+        fps = F1 * n1 / e
+        res[key] = {"value": fps, "unit": "frames/s", "ms_per_call": e / n1 * 1e3, "frames_per_call": F1, "calls": n1,
+                    "hbm_roofline_frac": fps * das_bytes / 1e9 / HBM_PEAK_GBPS, "realtime_factor": fps * HOP / FS,
+                    "kernel": "k_beamform_wave (steering rows of the grid angle)" if kw["bins_are_grid"] else "k_beamform_ola (phasors of any angle)"}
+    lat = {}
+    for fch in (1, 8):
+        pc = pcm[:1, :, :(fch + 1) * HOP].contiguous()
+        rc_ = torch.full((1, fch, 1), ang, dtype=torch.float32, device=dev)
+        oc = torch.empty(1, 1, fch * HOP, dtype=torch.float32, device=dev)
+        g = c1.graph_create(pc, fch, None, rc_, None, None, oc)
+        for _ in range(10):
+            g.launch(stream=stream)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            g.launch(stream=stream)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        # back to back (no synchronisation per chunk): the device-side cost of a chunk
+        t0 = time.perf_counter()
+        for _ in range(200):
+            g.launch(stream=stream)
+        torch.cuda.synchronize()
+        bb = (time.perf_counter() - t0) / 200
+        lat["F=%d" % fch] = {"median_ms": ts[len(ts) // 2] * 1e3, "p95_ms": ts[int(len(ts) * 0.95)] * 1e3, "back_to_back_ms": bb * 1e3,
+                             "chunk_audio_ms": fch * HOP / FS * 1e3, "hbm_roofline_frac_back_to_back": fch * das_bytes / bb / 1e9 / HBM_PEAK_GBPS}
+        g.close()
+    res["graph_chunk_latency"] = lat
+    res["graph_chunk_latency_note"] = ("one separation-only HIP graph launch per chunk + torch.cuda.synchronize(), host clock, 200 chunks; a chunk of F frames "
+                                      "carries F x 10.67 ms of audio; launch-bound (SURVEY 8d: config 2 is latency-, not bandwidth-bound)")
+    c1.close()
+    return res
+
+
+def repair_spread(args, dev, stream, local_rank, headline_ms):
+    """How much the step time of the ADAPTIVE precision depends on the CONTENT (how many frames are near ties) and on the shape (every
+    array's last rows are always recomputed): the same path on other seed sets / shapes, outside the timed region (VERDICT r3 #4)."""
+    from mcarray_amd import api, synth
+    from mcarray_amd import dist as mdist
+    cases = (("bench seeds, 8 x 4096 (the headline input again, fresh context)", 8, 4096, [mdist.array_seed(0x5EED0000, g) for g in range(8)], True),
+             ("seeds 0..7, 8 x 4096, rows not padded (tools/bench_shapes.py sources, S = 1)", 8, 4096, list(range(8)), False),
+             ("bench seeds, 128 x 256 (BASELINE configs[4]'s per-GPU shape)", 128, 256, [mdist.array_seed(0x5EED0000, g) for g in range(128)], True))
+    out = []
+    for name, A, F, seeds, pad in cases:
+        ctx = api.Context(FS, synth.ULA8, NFFT, STEP_DEG, 1, srp_precision=PREC[args.precision], max_arrays=A, device=local_rank)
+        ctx.reserve(A, F)
+        pcm = synth_batch(synth.ULA8, seeds, F, dev)[0]
+        if not pad:
+            pcm = pcm[:, :, :(F + 1) * HOP].contiguous()
+        b = torch.empty(A, F, 1, dtype=torch.int32, device=dev)
+        r = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+        q = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+        o = torch.empty(A, 1, F * HOP, dtype=torch.float32, device=dev)
+        call = lambda: ctx.process_frames_dev(pcm, F, b, r, q, None, o, stream=stream)
+        n = 20
+        e = timed_loop(call, lambda: None, n, 5, False, None, dev)
+        ctx.set_timing_kernels([api.K_REPAIR])
+        ctx.reset_timing()
+        for _ in range(10):
+            call()
+        torch.cuda.synchronize()
+        nl, ms = ctx.get_timing(api.K_REPAIR)
+        rs = ctx.repair_stats() if args.precision == "adaptive" else {"frames": 0, "flagged": 0, "recomputed": 0}
+        ctx.set_timing(False)
+        ms_step = e / n * 1e3 * (8 * 4096) / (A * F)
+        out.append({"input": name, "arrays": A, "frames": F, "value": A * F * n / e, "unit": "frames/s", "ms_per_32768_frames": ms_step,
+                    "vs_headline": headline_ms / ms_step, "repair_ms": ms / max(1, nl), "flagged_fraction": rs["flagged"] / max(1, rs["frames"]),
+                    "recomputed_fraction": rs["recomputed"] / max(1, rs["frames"])})
+        ctx.close()
+        del pcm, b, r, q, o
+    return out
 
 
 def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
@@ -164,24 +279,35 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             kt[name] = {"launches": n, "avg_ms": (ms / n if n else 0.0), "total_ms": ms}
         return kt
 
-    # Every event pair costs the stream ~1.5 us (measured: all six kernel groups bracketed = +2.5 % on the step).  The warm-up
-    # steps run with all groups bracketed and name the dominant kernel; the timed region brackets that kernel only (the
-    # roofline's duration is measured live inside the timed region); the per-kernel table comes from a pass after it.
-    dom_state = {"id": api.K_STFT_PHAT}
+    # Every event pair costs the stream ~1.5 us (measured: all six kernel groups bracketed = +2.5 % on the step), so the timed region
+    # brackets TWO kernel groups only: the two that led -- by their AVERAGE launch -- in the warm-up steps behind the first (the
+    # first step of a process pays module loads and hipFuncSetAttribute inside the brackets: with --warmup 5 that one-off once
+    # outweighed five launches of the analysis kernel in the totals and named k_scan_pick).  With fewer than two warm-up
+    # steps the two are the FFT kernels.  The per-kernel table comes from a pass after the timed region; the dominant kernel is
+    # named from THAT table's averages, and its roofline duration is the timed region's own if it was one of the two bracketed.
+    armed = {"ids": [api.K_STFT_PHAT, api.K_BEAMFORM], "how": "default (fewer than two warm-up steps)"}
+
+    def after_first_warmup():
+        if not args.no_kernel_timing and args.warmup >= 2:
+            torch.cuda.synchronize()
+            ctx.set_timing(True)
+            ctx.reset_timing()
 
     def arm():
         if args.no_kernel_timing:
             ctx.set_timing(False)
         else:
-            if args.warmup > 0:
+            if args.warmup >= 2:
                 wt = read_timing()
-                name = max(wt, key=lambda k: wt[k]["total_ms"])
-                dom_state["id"] = [k for k, v in api.KERNEL_NAMES.items() if v == name][0]
-            ctx.set_timing_kernels([dom_state["id"]])
+                top = sorted((k for k in wt if wt[k]["launches"]), key=lambda k: -wt[k]["avg_ms"])[:2]
+                if len(top) == 2:
+                    armed["ids"] = [[k for k, v in api.KERNEL_NAMES.items() if v == name][0] for name in top]
+                    armed["how"] = "largest average launch over warm-up steps 2..%d" % args.warmup
+            ctx.set_timing_kernels(armed["ids"])
         ctx.reset_timing()
 
-    ctx.set_timing(not args.no_kernel_timing)
-    elapsed = timed_loop(step, xg.drain, args.steps, args.warmup, use_dist, dist, dev, arm)
+    ctx.set_timing(False)
+    elapsed = timed_loop(step, xg.drain, args.steps, args.warmup, use_dist, dist, dev, arm, after_first_warmup)
     ctx.set_timing(False)
     last = state["last"]
     last_bin = xg.doa_buffers(last)[0]
@@ -191,9 +317,8 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             print(json.dumps({"value": value, "ms_per_step": elapsed / args.steps * 1e3, "note": "A/B run without kernel timing"}))
         return None
 
-    # the dominant kernel's launches of the timed region, bracketed with hipEvents on the launch stream by the library
-    dom = api.KERNEL_NAMES[dom_state["id"]]
-    kt_dom = read_timing()[dom]
+    # the bracketed kernels' launches of the timed region (hipEvents on the launch stream, recorded by the library)
+    kt_timed = {api.KERNEL_NAMES[i]: read_timing()[api.KERNEL_NAMES[i]] for i in armed["ids"]}
     repair = None
     if args.precision == "adaptive":
         rs = ctx.repair_stats()
@@ -209,21 +334,52 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
     torch.cuda.synchronize()
     kt = read_timing()
     ctx.set_timing(False)
-    kt[dom] = kt_dom
-    # (a large call can run as several lanes: every kernel is then launched once per lane on its share of the arrays)
-    frames_per_launch = A * F * args.steps / max(1, kt[dom]["launches"])
-    if dom == "k_srp_gemm":
-        # algorithmic flops of this kernel per frame: real contraction [G*2K] x D, G = 7 delay groups of the ULA
-        flops = 2.0 * ctx.G * 2 * K * D * frames_per_launch
-        ach = flops / (kt[dom]["avg_ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None}
-    else:
-        per_frame = {"k_stft_phat": M * HOP * 4, "k_beamform_ola": M * HOP * 4 + HOP * 4, "k_scan_pick": D * 4 + 8}.get(dom, D * 4 + 8)
-        ach = per_frame * frames_per_launch / (kt[dom]["avg_ms"] * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_frame": per_frame}
-    traffic_from_profiles(roof, dom, args.precision, A == 8 and F == 4096)
+    for name, v in kt_timed.items():
+        if v["launches"]:
+            kt[name] = dict(v, measured_in="timed region")
+    # roofline of every kernel group: algorithmic bytes (per frame) or flops over its average launch
+    per_frame_bytes = {"k_stft_phat": M * HOP * 4,                # PCM in, every fp32 sample once
+                       "k_beamform_ola": M * HOP * 4 + HOP * 4,   # PCM in + beamformed audio out
+                       "k_scan_pick": D * 4 + 8}                  # one map row in, DOA bin + prob out
+    tr_table, tr_src = traffic_table(args.precision, A == 8 and F == 4096)
+    by_kernel = []
+    for name, v in kt.items():
+        if not v["launches"]:
+            continue
+        # (a large call can run as several lanes: every kernel is then launched once per lane on its share of the arrays)
+        steps_seen = args.steps if v.get("measured_in") == "timed region" else table_steps
+        frames_per_launch = A * F * steps_seen / v["launches"]
+        e = {"kernel": name, "avg_ms": v["avg_ms"], "launches": v["launches"], "measured_in": v.get("measured_in", "table pass of %d steps after the timed region" % table_steps)}
+        if name == "k_srp_gemm":
+            # algorithmic flops of this kernel per frame: real contraction [G*2K] x D, G = 7 delay groups of the ULA
+            flops = 2.0 * ctx.G * 2 * K * D * frames_per_launch
+            ach = flops / (v["avg_ms"] * 1e-3) / 1e12
+            e.update(bound="mfma", achieved=ach, peak=PEAK_TFLOPS[args.precision], unit="TFLOP/s", frac=ach / PEAK_TFLOPS[args.precision],
+                     algorithmic_flops_per_frame=2.0 * ctx.G * 2 * K * D)
+        elif name in per_frame_bytes:
+            ach = per_frame_bytes[name] * frames_per_launch / (v["avg_ms"] * 1e-3) / 1e9
+            e.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_frame=per_frame_bytes[name])
+        else:
+            e.update(bound=None, achieved=None, peak=None, unit=None, frac=None,
+                     note="no algorithmic bytes of its own: the exact recomputation of the flagged rows is overhead of the adaptive precision")
+        e["traffic"] = tr_table.get(name)
+        if e["traffic"] is not None and e.get("algorithmic_bytes_per_frame"):
+            e["traffic_ratio"] = e["traffic"] / (e["algorithmic_bytes_per_frame"] * A * F)
+        by_kernel.append(e)
+    by_kernel.sort(key=lambda e: -e["avg_ms"])
+    dom_e = by_kernel[0]
+    dom = dom_e["kernel"]
+    roof = {"kernel": dom, "bound": dom_e["bound"], "achieved": dom_e["achieved"], "peak": dom_e["peak"], "unit": dom_e["unit"], "frac": dom_e["frac"],
+            "traffic": dom_e["traffic"], "avg_ms": dom_e["avg_ms"], "measured_in": dom_e["measured_in"],
+            "chosen_by": "largest average launch in the per-kernel table (first steps of the process excluded)",
+            "bracketed_in_timed_region": [api.KERNEL_NAMES[i] for i in armed["ids"]], "bracket_choice": armed["how"]}
+    for k_ in ("algorithmic_bytes_per_frame", "algorithmic_flops_per_frame", "traffic_ratio"):
+        if k_ in dom_e:
+            roof[k_] = dom_e[k_]
+    if roof["traffic"] is not None:
+        roof["traffic_unit"] = ("bytes per step of this kernel (rocprofv3 FETCH_SIZE x fetch_factor + WRITE_SIZE, separate PMC passes; in the "
+                                "adaptive mode the analysis kernel's figure includes its second, list-mode launch of the repair pass: ~3 %)")
+        roof["traffic_source"] = tr_src
     # the whole path against the same roofline: `frac` above is the dominant kernel's own share (its algorithmic bytes over its
     # own duration); the per-kernel byte definitions double-count the PCM (both FFT kernels read all M channels: 16 384 B each
     # of the path's 18 440 B per frame), so the kernels' fractions do not add up to the path's
@@ -234,7 +390,7 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
 
     line = None
     if rank == 0:
-        cpu = single = None
+        cpu = single = das = mvdr = spread = None
         if world == 1 and args.cpu_frames > 0:
             nf = min(args.cpu_frames, F)
             fps, dt, ref = cpu_baseline(pcm[0].cpu().numpy(), nf)
@@ -274,6 +430,16 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             single["graph_replay"] = {"value": F1 * n1 / eg, "unit": "frames/s", "ms_per_call": eg / n1 * 1e3, "calls": n1}
             g1.close()
             c1.close()
+        if world == 1 and args.extras:
+            das = das_single_stream(pcm if F >= 936 else synth_batch(synth.ULA8, [0x5EED0000], 936, dev)[0], theta, dev, stream, local_rank, args.steps)
+            spread = repair_spread(args, dev, stream, local_rank, elapsed / args.steps * 1e3)
+            # BASELINE configs[3] in the same record (its own bench line: --config mvdr)
+            import copy
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.cpu_frames = max(10, min(args.steps, 30)), 5, (2048 if args.cpu_frames > 0 else 0)
+            ml = run_mvdr(a2, 1, 0, local_rank, dev, False, None)
+            mvdr = {k_: ml[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "algorithmic_GBps", "hbm_roofline_frac", "kernels", "roofline", "cpu_baseline")}
+            mvdr["workload"] = ml["config"]["workload"]
         line = {
             "metric": "STFT frames/sec, 8-mic GCC-PHAT + SRP-PHAT(361) + delay-and-sum beamform @48kHz/1024-pt",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,12 +449,12 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
                                    "1 source, no power floor), %d arrays x %d frames per GPU per step; channel rows padded by %d floats" % (A, F, ROW_PAD),
                        "arrays_per_gpu": A, "frames_per_array": F, "srp_precision": args.precision,
                        "parallelism": "arrays sharded over %d GPU(s), all_gather of DOA bins+prob%s" % (world, " + gather of the beamformed audio to rank 0" if args.gather_audio else ""),
-                       "single_stream_4096": single},
+                       "single_stream_4096": single, "das_single_stream": das, "mvdr_256x64": mvdr},
             "algorithmic_GBps": value * BYTES_PER_FRAME / 1e9,
             "hbm_roofline_frac": value * BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world),
-            "kernels": kt, "roofline": roof, "cpu_baseline": cpu, "repair": repair,
-            "kernels_note": "hipEvent pairs on the launch stream: %s (the roofline kernel) over the timed region, the other groups in a "
-                            "pass of %d steps after it (bracketing all of them inside the timed region costs ~2.5 %%)" % (dom, table_steps),
+            "kernels": kt, "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "repair": repair, "repair_spread": spread,
+            "kernels_note": "hipEvent pairs on the launch stream: %s over the timed region, the other groups in a "
+                            "pass of %d steps after it (bracketing all of them inside the timed region costs ~2.5 %%)" % (" and ".join(kt_timed), table_steps),
             "exchange": {"backend": dist.get_backend() if use_dist else None, "gather_audio": bool(args.gather_audio),
                          "bytes_per_step_per_rank": 8 * A * F + (4 * A * F * HOP if args.gather_audio else 0)},
         }
@@ -394,6 +560,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=4096, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle on all host cores, one array per process (0 = skip)")
     ap.add_argument("--single-stream", type=int, default=1, help="also time the literal configs[2] call: 1 array x 4096 frames (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="also report configs[1] (delay-and-sum single stream), configs[3] (MVDR 256 x 64) and the "
+                    "content spread of the repair pass in the same line, outside the timed region (0 = skip)")
     ap.add_argument("--gather-audio", action="store_true",
                     help="N > 1: also gather the beamformed audio (2 KB per frame) to rank 0 every step (BASELINE configs[4]: 'RCCL gather of DOA/output')")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the kernels with HIP events (A/B of the event overhead)")

@@ -54,7 +54,7 @@ typedef enum {
                                 ONE source (with several, the S-th pick is a near tie too often), with or without the power
                                 gate; every other call of such a context runs as FP16X3 -- as do its calls while most rows
                                 need the repair (noise only, silence: the context backs off by itself and probes again
-                                later; MCA_HIP_ADAPT_FALLBACK=0 in the environment pins the mode).  The optional energy map
+                                later; mca_hip_config.adaptive_fallback = OFF pins the mode).  The optional energy map
                                 keeps fp16 accuracy on unrepaired frames. */
 } mca_hip_srp_precision;
 
@@ -93,7 +93,21 @@ typedef struct {
     int max_arrays;            /* number of independent arrays whose state the context holds (>= 1) */
     int gcc_weighting;         /* mca_hip_gcc_weighting; 0 = PHAT.  (Appended in round 3: a struct_size that ends before this
                                   field is accepted and means PHAT.) */
+    /* Appended in round 4 (a struct_size that ends before them is accepted; zero = the default of each): */
+    int adaptive_fallback;     /* mca_hip_adaptive_fallback.  MCA_HIP_SRP_ADAPTIVE only.  0 = AUTO: the context backs off to
+                                  FP16X3 by itself while most rows need the repair (noise only, silence) and probes again later;
+                                  WHICH call switches depends on when the GPU's report reaches the host, so two runs of the
+                                  same input may differ in the last bits of the energies around a switch.  1 = OFF: the mode is
+                                  pinned -- every eligible call runs coarse + repair, and two runs of the same calls return
+                                  the same bits in every output. */
+    int adaptive_min_rows;     /* ADAPTIVE: calls of fewer rows (arrays x frames) run as FP16X3; 0 = 4096 */
+    int adaptive_max_sources;  /* ADAPTIVE: contexts with more sources run as FP16X3; 0 = 1 */
+    int scan_carry;            /* 1: the chunk start values of the energy recursion always come from the serial carry pass
+                                  (k_scan_carry) instead of the four-chunk look-back of ungated PHAT calls; results agree to the
+                                  last bits (tests cross-check the two) */
 } mca_hip_config;
+
+typedef enum { MCA_HIP_ADAPT_FALLBACK_AUTO = 0, MCA_HIP_ADAPT_FALLBACK_OFF = 1 } mca_hip_adaptive_fallback;
 
 /* ---- page-locked host memory ---------------------------------------------- */
 /* Thin wrappers over hipHostMalloc / hipHostFree / hipHostRegister / hipHostUnregister so that a caller of the host-pointer
@@ -217,7 +231,8 @@ int mca_hip_get_energy(mca_hip_ctx *ctx, double *out);
  * A caller that hands over a stream chunk by chunk (SourceSeparationAndLocalisation::process() on a live input,
  * mcabeamf.cpp:112; BASELINE configs[1]) is bound by the launches of a call, not by its kernels: one frame is 18 KB.
  * mca_hip_graph_create fixes the shape and the device buffers of a mca_hip_process_frames_dev call (out_pcm_dev NULL:
- * of a mca_hip_localise_frames_dev call); mca_hip_graph_launch replays the kernels of that call as ONE graph launch on
+ * of a mca_hip_localise_frames_dev call; doa_bin_dev NULL: of a mca_hip_separate_frames_dev call, the delay-and-sum stage
+ * alone at the caller's angles in doa_rad_dev); mca_hip_graph_launch replays the kernels of that call as ONE graph launch on
  * whatever the caller has put into pcm_dev since the last launch, continuing the context state exactly like the plain
  * call (results are bit-identical).  The graphs (one per parity of the double-buffered state) are recorded on first
  * use; recording executes nothing.  Plain stream calls and graph launches on the same context may be mixed. */

@@ -32,6 +32,10 @@ class Config(C.Structure):
         ("srp_precision", C.c_int),
         ("max_arrays", C.c_int),
         ("gcc_weighting", C.c_int),
+        ("adaptive_fallback", C.c_int),
+        ("adaptive_min_rows", C.c_int),
+        ("adaptive_max_sources", C.c_int),
+        ("scan_carry", C.c_int),
     ]
 
 

@@ -54,7 +54,8 @@ class Context:
     """Owns one mca_hip_ctx (the state of max_arrays independent module objects)."""
 
     def __init__(self, sample_rate, mic_positions, fft_size=1024, doa_step_deg=5.0, n_sources=1, use_power_floor=False,
-                 srp_precision=SRP_FP32, max_arrays=1, device=0, gcc_weighting=GCC_PHAT):
+                 srp_precision=SRP_FP32, max_arrays=1, device=0, gcc_weighting=GCC_PHAT, adaptive_fallback=True,
+                 adaptive_min_rows=0, adaptive_max_sources=0, scan_carry=False):
         self._lib = _lib.load()
         self.xyz = _xyz(mic_positions)
         self.M = len(self.xyz)
@@ -76,6 +77,10 @@ class Context:
         cfg.srp_precision = srp_precision
         cfg.max_arrays = max_arrays
         cfg.gcc_weighting = gcc_weighting
+        cfg.adaptive_fallback = 0 if adaptive_fallback else 1      # mca_hip_adaptive_fallback: AUTO / OFF (OFF: bit-reproducible runs)
+        cfg.adaptive_min_rows = adaptive_min_rows
+        cfg.adaptive_max_sources = adaptive_max_sources
+        cfg.scan_carry = int(scan_carry)
         h = C.c_void_p()
         rc = self._lib.mca_hip_create(C.byref(cfg), C.byref(h))
         if rc != 0:

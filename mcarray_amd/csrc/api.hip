@@ -6,6 +6,7 @@
 #include "../../include/mcarray_hip.h"
 #include "fft1024c.h"
 #include "kernels.h"
+#include "knobs.h"
 #include "stage.h"
 
 #include <cmath>
@@ -28,6 +29,27 @@ struct TimedEvent { int id; hipEvent_t a, b; };
 struct mca_hip_graph;
 
 #define MCA_MAX_LANES 1
+
+// ---- switches --------------------------------------------------------------------------------------------------------------
+// Read ONCE, by mca_hip_create, into the context: nothing on a call path reads the environment.  The product switches are fields of
+// mca_hip_config (adaptive_fallback, adaptive_min_rows, adaptive_max_sources, scan_carry) with an environment override for tests and
+// tools that reach a context only through a wrapper.  The A/B switches that exist so that a measured claim of DESIGN.md can be
+// repeated -- one of them (MCA_HIP_BFW_ABL) returns deliberately wrong audio -- are compiled in only with -DMCA_MEASURE
+// (make MEASURE=1, tools/*.py say when they need it); in the default build they are the constants below.
+struct Knobs {
+    // product
+    bool fb_enabled = true;            // MCA_HIP_ADAPT_FALLBACK=0 / cfg.adaptive_fallback = OFF
+    long long adapt_min_rows = 4096;   // MCA_HIP_ADAPT_MIN_ROWS / cfg.adaptive_min_rows
+    int adapt_max_sources = 1;         // MCA_HIP_ADAPT_MAX_SOURCES / cfg.adaptive_max_sources
+    double tau_scale = 1.0;            // MCA_HIP_ADAPT_TAU_SCALE (tools/adaptive_check.py: 1e9 turns the repair off to measure the coarse error)
+    long long ws_max_bytes = 4LL << 30;   // MCA_HIP_WS_MAX_MB: A-operand workspace budget per slice of frames (tests force the sliced path)
+    bool force_generic = false;        // MCA_HIP_FORCE_GENERIC: the any-length kernels at N = 1024 too (parity test of both)
+    bool scan_carry = false;           // MCA_HIP_SCAN_CARRY / cfg.scan_carry
+    // measurement only (-DMCA_MEASURE)
+    bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
+         v1_nosplit = false, no_n512 = false, no_sub2 = false;
+    int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
+};
 
 // Per-call workspace (everything a stream call allocates besides the per-array state, which lives in the context).  A call
 // can be worked off in pieces over a sub-range of its arrays -- the chunks of the host-pointer path -- with the per-array
@@ -62,7 +84,7 @@ struct mca_hip_ctx {
     mca_hip_config cfg{};
     std::vector<double> xyz;
     int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, H = 0, logH = 0, Kp = 0, S = 1, prec = 0;
-    bool ula = false, stream_ok = false, generic = false, force_v1 = false;
+    bool ula = false, stream_ok = false, generic = false;
     bool n512 = false;             // 512-sample frames with <= 8 microphones: k_stft_phat_512 / k_beamform_512 instead of the any-length kernels
     std::string stream_why;       // why the stream API is unavailable for this configuration
     int v2_min_rows = 16384;       // one operand plane; twice that with two (plan_gemm)
@@ -116,14 +138,13 @@ struct mca_hip_ctx {
     // only, silence: every pick is a near tie and coarse + repair of everything costs twice the direct exact pass.  The last
     // kernel of an adaptive call leaves its running totals in page-locked memory; the next calls read them when they have arrived
     // (no synchronisation) and suspend the mode for fb_backoff eligible calls, then probe again with one adaptive call.
-    bool fb_enabled = true, adapt_suspended = false, capturing = false;
+    Knobs kn;
+    bool adapt_suspended = false, capturing = false;
     int fb_left = 0, fb_backoff = 8, fb_state = 0;      // (adapt_policy_begin)
     unsigned long long fb_probe_seq = 0;
     unsigned long long *h_probe = nullptr;              // [3] flagged frames, listed repair units, sequence number of the call
     unsigned long long fb_calls = 0, fb_seq_seen = 0, fb_groups_prev = 0, fb_frames_prev = 0;
     unsigned long long fb_frames_ring[64] = {};         // adapt_frames_total after adaptive call number i + 1
-    int adapt_max_sources = 1;
-    long long adapt_min_rows = 4096;        // (round 2: 8192; with the merged index the coarse contraction of 4096 rows takes 26 us against 81 + 12 us of the three-product one: the literal BASELINE configs[2] call -- 1 array x 4096 frames -- runs 0.194 instead of 0.199 ms)
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
     double *d_fr = nullptr; size_t fr_elems = 0;
@@ -195,6 +216,42 @@ void free_ctx(mca_hip_ctx *c)
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// (the environment is read through knobs.h, by mca_hip_create only)
+Knobs read_knobs(const mca_hip_config &cfg)
+{
+    Knobs k;
+    auto geti = [](const char *v, long long dflt) { return v ? std::atoll(v) : dflt; };
+    k.fb_enabled = cfg.adaptive_fallback != MCA_HIP_ADAPT_FALLBACK_OFF;
+    if (const char *v = env_str("MCA_HIP_ADAPT_FALLBACK")) k.fb_enabled = std::atoi(v) != 0;
+    // (4096 rows -- round 2: 8192; with the merged index the coarse contraction of 4096 rows takes 26 us against 81 + 12 us of the
+    // three-product one: the literal BASELINE configs[2] call, 1 array x 4096 frames, is inside)
+    k.adapt_min_rows = geti(env_str("MCA_HIP_ADAPT_MIN_ROWS"), cfg.adaptive_min_rows > 0 ? cfg.adaptive_min_rows : 4096);
+    k.adapt_max_sources = (int)geti(env_str("MCA_HIP_ADAPT_MAX_SOURCES"), cfg.adaptive_max_sources > 0 ? cfg.adaptive_max_sources : 1);
+    if (const char *v = env_str("MCA_HIP_ADAPT_TAU_SCALE")) k.tau_scale = std::atof(v);
+    if (const char *v = env_str("MCA_HIP_WS_MAX_MB")) k.ws_max_bytes = (long long)std::atoll(v) << 20;
+    k.force_generic = env_str("MCA_HIP_FORCE_GENERIC") != nullptr;
+    k.scan_carry = cfg.scan_carry != 0 || env_str("MCA_HIP_SCAN_CARRY") != nullptr;
+    // measurement only: constants unless the library was built with -DMCA_MEASURE
+    k.no_merge = measure_env("MCA_HIP_NO_MERGE") != nullptr;
+    k.stft_wg = measure_env("MCA_HIP_STFT_WG") != nullptr;
+    k.bf_ola = measure_env("MCA_HIP_BF_OLA") != nullptr;
+    k.bf_occ2 = measure_env("MCA_HIP_BF_OCC2") != nullptr;
+    k.no_fused_partial = measure_env("MCA_HIP_NO_FUSED_PARTIAL") != nullptr;
+    k.gemm_v1 = measure_env("MCA_HIP_GEMM_V1") != nullptr;
+    k.gemm_v2 = measure_env("MCA_HIP_GEMM_V2") != nullptr;
+    k.v1_nosplit = measure_env("MCA_HIP_V1_NOSPLIT") != nullptr;
+    k.no_n512 = measure_env("MCA_HIP_NO_N512") != nullptr;
+    k.no_sub2 = measure_env("MCA_HIP_NO_SUB2") != nullptr;
+    k.spw_fpw = (int)geti(measure_env("MCA_HIP_SPW_FPW"), 0);
+    k.bfw_ft = (int)geti(measure_env("MCA_HIP_BFW_FT"), 0);
+    k.bfw_abl = (int)geti(measure_env("MCA_HIP_BFW_ABL"), 0);
+    k.bfw_var = (int)geti(measure_env("MCA_HIP_BFW_VAR"), 15);
+    k.repair_ksplit = (int)geti(measure_env("MCA_HIP_REPAIR_KSPLIT"), 0);
+    k.v2_min_rows = (int)geti(measure_env("MCA_HIP_V2_MIN_ROWS"), 0);
+    k.repick_grid = (int)geti(measure_env("MCA_HIP_REPICK_GRID"), 256);
+    return k;
+}
 
 // _currentDOA = 0, _prob = -1 (BeamformingSeparationAndLocalisation.cpp:51-52); no frame has fired yet -> bin -1
 int init_last_state(mca_hip_ctx *c, hipStream_t st)
@@ -274,7 +331,7 @@ int cur_kp(const mca_hip_ctx *c) { return (c->merged && c->a_planes == 1) ? c->K
 int build_merged_tables(mca_hip_ctx *c)
 {
     c->merged = false;
-    if (!c->ula || c->generic || c->n512 || (c->M != 4 && c->M != 8) || c->Dp % 64 != 0 || std::getenv("MCA_HIP_NO_MERGE") || std::getenv("MCA_HIP_STFT_WG")) return MCA_HIP_OK;
+    if (!c->ula || c->generic || c->n512 || (c->M != 4 && c->M != 8) || c->Dp % 64 != 0 || c->kn.no_merge || c->kn.stft_wg) return MCA_HIP_OK;
     if (c->prec != MCA_HIP_SRP_ADAPTIVE && c->prec != MCA_HIP_SRP_FP16) return MCA_HIP_OK;
     const int K = c->K, D = c->D, Dp = c->Dp, G = c->G;
     const double N = 2.0 * (K - 1);
@@ -353,7 +410,7 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
     if (c->plan_rows > 0) rows = c->plan_rows;
     // 256 x 384 tiles from 16 384 rows with one operand plane (128 workgroups of k_srp_gemm_f16_v3 beat the 128 x 192 kernel
     // there: 134 vs 156 us, and leave the scan's chunk results), from 32 768 rows with the hi + lo planes (343 vs 299 us at 16 384)
-    g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= (long long)c->v2_min_rows * (c->a_planes == 2 ? 2 : 1) && !c->force_v1;
+    g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= (long long)c->v2_min_rows * (c->a_planes == 2 ? 2 : 1) && !c->kn.gemm_v1;
     if (g.v2) {
         g.ksplit = rows >= 65536 ? 1 : 2;   // 256 x 384 tiles need >= ~256 workgroups to fill the chip
     } else {
@@ -366,8 +423,7 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
         if (ks > nk / 8) ks = nk / 8;
         if (ks > 16) ks = 16;
         if (ks < 1) ks = 1;
-        static const bool nosplit = std::getenv("MCA_HIP_V1_NOSPLIT") != nullptr;    // A/B switch for measurements
-        g.ksplit = nosplit ? 1 : (int)ks;
+        g.ksplit = c->kn.v1_nosplit ? 1 : (int)ks;
     }
     return g;
 }
@@ -435,17 +491,13 @@ int ensure_scan_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chun
     return MCA_HIP_OK;
 }
 
-long long ws_max_bytes()
-{
-    // A-operand workspace budget per chunk of frames; MCA_HIP_WS_MAX_MB lets the tests force the chunked path
-    static const long long v = std::getenv("MCA_HIP_WS_MAX_MB") ? (long long)std::atoll(std::getenv("MCA_HIP_WS_MAX_MB")) << 20 : 4LL << 30;
-    return v;
-}
+// A-operand workspace budget per slice of frames (MCA_HIP_WS_MAX_MB lets the tests force the sliced path)
+long long ws_max_bytes(const mca_hip_ctx *c) { return c->kn.ws_max_bytes; }
 
 long long chunk_frames_for(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     long long row_bytes = (long long)c->a_row_elems * c->a_elem;
-    long long rows_cap = ws_max_bytes() / row_bytes;
+    long long rows_cap = ws_max_bytes(c) / row_bytes;
     long long fc = rows_cap / n_arrays;
     if (fc >= n_frames) return n_frames;
     fc = fc / 8 * 8;
@@ -466,8 +518,8 @@ bool adaptive_shape(const mca_hip_ctx *c, int n_arrays, int n_frames)
     // (more than one source: the S-th pick is a weak peak more often than not -- a second source, or noise when fewer than S
     // are active -- and a third to all of the frames are flagged: 8 x 4096 frames with S = 2 / 3 / 4 real sources spend 0.89 / 1.60 /
     // 1.76 ms in the repair pass, more than the 0.3 ms the coarse contraction saves; MCA_HIP_ADAPT_MAX_SOURCES lifts the limit)
-    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 && c->S <= c->adapt_max_sources &&
-           rows >= c->adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
+    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 && c->S <= c->kn.adapt_max_sources &&
+           rows >= c->kn.adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
 }
 bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames) { return adaptive_shape(c, n_arrays, n_frames) && !c->adapt_suspended; }
 
@@ -482,7 +534,7 @@ bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames) { return
 // path's bins (MCA_HIP_ADAPT_FALLBACK=0 pins the mode).
 void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
-    if (!c->fb_enabled || c->capturing || !c->h_probe || !adaptive_shape(c, n_arrays, n_frames)) return;
+    if (!c->kn.fb_enabled || c->capturing || !c->h_probe || !adaptive_shape(c, n_arrays, n_frames)) return;
     bool fresh = false, heavy = false;
     const unsigned long long seq = __atomic_load_n(&c->h_probe[2], __ATOMIC_ACQUIRE);
     if (seq > c->fb_seq_seen && seq <= c->fb_calls && c->fb_calls - seq < 64) {
@@ -519,8 +571,7 @@ void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
 // 128 arrays leave thousands, where 32 partial maps per row cost more (k_repair_patch reads them all) than they buy.
 int repair_ksplit_for(const mca_hip_ctx *c, int n_arrays)
 {
-    static const int env = std::getenv("MCA_HIP_REPAIR_KSPLIT") ? std::atoi(std::getenv("MCA_HIP_REPAIR_KSPLIT")) : 0;
-    if (env > 0) return std::min(env, REPAIR_KSPLIT_MAX);
+    if (c->kn.repair_ksplit > 0) return std::min(c->kn.repair_ksplit, REPAIR_KSPLIT_MAX);
     const long long arrays = c->plan_arrays > 0 ? c->plan_arrays : n_arrays;
     const long long tail_rows = arrays * (REPAIR_WARM + 1 + REPAIR_GROUP);
     return tail_rows <= 1024 ? 32 : (tail_rows <= 2560 ? 16 : 8);
@@ -531,7 +582,7 @@ long long repair_pass_rows(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     const long long gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
     const long long all = (long long)n_arrays * gpa * REPAIR_GROUP;
-    long long cap = ws_max_bytes() / ((long long)2 * c->Kp * 2) / 128 * 128;
+    long long cap = ws_max_bytes(c) / ((long long)2 * c->Kp * 2) / 128 * 128;
     // (the repair contraction always leaves REPAIR_KSPLIT partial maps: Cx is sized for the worst case, all rows listed --
     // 1.6 GB next to the 1.9 GB of two-plane A rows on the bench shape; one pass in the common case, so no empty launches)
     if (cap < 128) cap = 128;
@@ -614,12 +665,12 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
 {
     const int M = c->M; const bool ula = c->ula;
     // 4 or 8 microphones: one wave per run of frames on the 1024-point transform of channel pairs (k_stft_phat_wave)
-    if ((M == 8 || M == 4) && (a.no_phat || std::getenv("MCA_HIP_STFT_WG") == nullptr)) {
+    if ((M == 8 || M == 4) && (a.no_phat || !c->kn.stft_wg)) {
         StftPhatArgs w = a;
         dim3 gw;
         if (a.list) { w.fpb = 1; gw = dim3(grid.x, 1); }      // a listed group of REPAIR_GROUP = 4 frames per workgroup, a frame per wave
         else {
-            const int env = std::getenv("MCA_HIP_SPW_FPW") ? std::atoi(std::getenv("MCA_HIP_SPW_FPW")) : 0;
+            const int env = c->kn.spw_fpw;
             w.fpb = env > 0 ? env : 16;       // frames per wave: two waves per SIMD want 2048 runs
             while (!env && w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
             gw = dim3(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
@@ -718,11 +769,14 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
 {
     if (!cfg || !out) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "cfg/out is NULL");
     *out = nullptr;
-    // (a caller built against the header before gcc_weighting was appended passes the shorter size: PHAT)
-    if (cfg->struct_size != (int)sizeof(mca_hip_config) && cfg->struct_size != (int)offsetof(mca_hip_config, gcc_weighting))
+    // Callers built against an earlier header pass its size: round 2 ended before gcc_weighting (PHAT), round 3 behind it -- that
+    // struct was 60 bytes of fields padded to 64, and the padding is not read -- and the fields appended since default to zero.
+    constexpr int size_r2 = (int)offsetof(mca_hip_config, gcc_weighting), size_r3 = (size_r2 + 4 + 7) / 8 * 8;
+    static_assert(size_r3 <= (int)offsetof(mca_hip_config, adaptive_min_rows), "round-3 struct size");
+    if (cfg->struct_size != (int)sizeof(mca_hip_config) && cfg->struct_size != size_r2 && cfg->struct_size != size_r3)
         return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "struct_size mismatch");
     mca_hip_config cfg_full{};
-    std::memcpy(&cfg_full, cfg, (size_t)cfg->struct_size);
+    std::memcpy(&cfg_full, cfg, cfg->struct_size == size_r3 ? (size_t)offsetof(mca_hip_config, adaptive_fallback) : (size_t)cfg->struct_size);
     cfg_full.struct_size = (int)sizeof(mca_hip_config);
     cfg = &cfg_full;
     if (cfg->gcc_weighting != MCA_HIP_GCC_PHAT && cfg->gcc_weighting != MCA_HIP_GCC_NONE)
@@ -737,6 +791,9 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     if (!(cfg->doa_step_deg > 0) || cfg->doa_step_deg > 45) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_step_deg must be in (0,45]");
     if (cfg->srp_precision < 0 || cfg->srp_precision > 3) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "bad srp_precision");
     if (cfg->max_arrays < 1) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "max_arrays < 1");
+    if (cfg->adaptive_fallback != MCA_HIP_ADAPT_FALLBACK_AUTO && cfg->adaptive_fallback != MCA_HIP_ADAPT_FALLBACK_OFF)
+        return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "adaptive_fallback must be MCA_HIP_ADAPT_FALLBACK_AUTO or _OFF");
+    if (cfg->adaptive_min_rows < 0 || cfg->adaptive_max_sources < 0) return fail(nullptr, MCA_HIP_ERR_INVALID_ARGUMENT, "adaptive_min_rows / adaptive_max_sources < 0");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -750,6 +807,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
 
     mca_hip_ctx *c = new mca_hip_ctx();
     c->cfg = *cfg;
+    c->kn = read_knobs(*cfg);
     c->M = cfg->n_mics; c->S = cfg->n_sources; c->N = cfg->fft_size; c->K = c->N / 2 + 1; c->prec = cfg->srp_precision;
     c->xyz.assign(cfg->mic_xyz, cfg->mic_xyz + 3 * c->M);
     c->cfg.mic_xyz = nullptr;
@@ -763,7 +821,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     c->H = c->N / 2;
     // stream API: the tuned 1024-sample kernels, or the any-power-of-two kernels (kernels_generic.hip)
     // whose channel spectra of one frame must fit the 160 KiB LDS of a CU
-    c->generic = c->N != FFT_N || std::getenv("MCA_HIP_FORCE_GENERIC") != nullptr;
+    c->generic = c->N != FFT_N || c->kn.force_generic;
     c->stream_ok = true;
     if (c->generic) {
         while ((1 << c->logH) < c->H) ++c->logH;
@@ -776,9 +834,8 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         c->stream_ok = false;
         c->stream_why = "gcc_weighting NONE: the stream API serves it at fft_size 1024 with 4 or 8 microphones (the frame API takes any shape)";
     }
-    c->n512 = c->N == 512 && c->M <= 8 && c->stream_ok && std::getenv("MCA_HIP_NO_N512") == nullptr;
-    c->force_v1 = std::getenv("MCA_HIP_GEMM_V1") != nullptr;   // A/B switches for measurements
-    if (std::getenv("MCA_HIP_V2_MIN_ROWS")) c->v2_min_rows = std::atoi(std::getenv("MCA_HIP_V2_MIN_ROWS"));
+    c->n512 = c->N == 512 && c->M <= 8 && c->stream_ok && !c->kn.no_n512;
+    if (c->kn.v2_min_rows > 0) c->v2_min_rows = c->kn.v2_min_rows;
 
     // generateLookupTable (SteeringBeamforming.cpp:58-94): pairs i<j lexicographic, float delays
     c->delays.resize((size_t)c->P * c->D);
@@ -824,11 +881,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         if (c->ula) for (int g = 0; g < c->G; ++g) sum_n2 += (double)(c->M - 1 - g) * (c->M - 1 - g);
         else sum_n2 = c->P;
         const double sigma_c = 5.0e-4 * std::sqrt(0.5 * c->K * sum_n2);
-        const double scale = std::getenv("MCA_HIP_ADAPT_TAU_SCALE") ? std::atof(std::getenv("MCA_HIP_ADAPT_TAU_SCALE")) : 1.0;
-        c->tau_en = (float)(scale * 8.0 * std::sqrt(2.0) * sigma_c / (30.0 * c->P));
-        if (std::getenv("MCA_HIP_ADAPT_MIN_ROWS")) c->adapt_min_rows = std::atoll(std::getenv("MCA_HIP_ADAPT_MIN_ROWS"));
-        if (std::getenv("MCA_HIP_ADAPT_FALLBACK")) c->fb_enabled = std::atoi(std::getenv("MCA_HIP_ADAPT_FALLBACK")) != 0;
-        if (std::getenv("MCA_HIP_ADAPT_MAX_SOURCES")) c->adapt_max_sources = std::atoi(std::getenv("MCA_HIP_ADAPT_MAX_SOURCES"));
+        c->tau_en = (float)(c->kn.tau_scale * 8.0 * std::sqrt(2.0) * sigma_c / (30.0 * c->P));
     }
 
     int rc = MCA_HIP_OK;
@@ -864,7 +917,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
     }
-    if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->fb_enabled) {
+    if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->kn.fb_enabled) {
         if (hipHostMalloc((void **)&c->h_probe, 32, hipHostMallocDefault) == hipSuccess) std::memset(c->h_probe, 0, 32);
         else { c->h_probe = nullptr; (void)hipGetLastError(); }                    // (no page-locked memory: the mode never backs off)
     }
@@ -1016,18 +1069,24 @@ static int reserve_lane(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     const int n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
     int rc;
-    if (c->prec == MCA_HIP_SRP_ADAPTIVE) {
-        const bool adaptive = adaptive_applies(c, n_arrays, n_frames);
-        set_call_planes(c, adaptive ? 1 : 2);
-        if (adaptive && (rc = ensure_adapt_workspace(c, n_arrays, n_frames, n_chunks))) return rc;
+    if (c->prec == MCA_HIP_SRP_ADAPTIVE && adaptive_shape(c, n_arrays, n_frames)) {
+        // by the SHAPE of the call, whatever the back-off is doing at the moment: a graph recording always runs coarse + repair
+        // (graph_record clears adapt_suspended), and reserving for plain FP16X3 only would make it allocate inside the capture
+        // (ADVICE r3).  While the mode is suspended the eager calls run as FP16X3: their two-plane rows are reserved as well.
+        set_call_planes(c, 1);
+        if ((rc = ensure_adapt_workspace(c, n_arrays, n_frames, n_chunks))) return rc;
+        const long long fc1 = chunk_frames_for(c, n_arrays, n_frames);
+        if ((rc = ensure_workspace(c, (long long)n_arrays * fc1, (long long)n_arrays * n_frames))) return rc;
+        if (!c->adapt_suspended) return ensure_scan_workspace(c, n_arrays, n_frames, n_chunks);
     }
+    if (c->prec == MCA_HIP_SRP_ADAPTIVE) set_call_planes(c, 2);
     long long fc = chunk_frames_for(c, n_arrays, n_frames);
     rc = ensure_workspace(c, (long long)n_arrays * fc, (long long)n_arrays * n_frames);
     if (rc) return rc;
     return ensure_scan_workspace(c, n_arrays, n_frames, n_chunks);
 }
 
-static int reserve_impl(mca_hip_ctx *c, int n_arrays, int n_frames, bool)
+static int reserve_impl(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     c->cur_lane = 0;
@@ -1037,7 +1096,7 @@ static int reserve_impl(mca_hip_ctx *c, int n_arrays, int n_frames, bool)
 int mca_hip_reserve(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     if (!c || n_arrays < 1 || n_frames < 1) return MCA_HIP_ERR_INVALID_ARGUMENT;
-    return reserve_impl(c, n_arrays, n_frames, false);
+    return reserve_impl(c, n_arrays, n_frames);
 }
 
 // STFT + PHAT + steering contraction for every frame: fills c->ws().d_C [arrays][n_frames][Dp]
@@ -1051,7 +1110,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
     // The 256 x 384 contraction leaves the chunk-local results of the scan over frames (k_scan_partial's job) when every
     // 32-row block of every launch is one scan chunk of one map: no gate, one map, whole chunks, that kernel for every slice.
     bool fused_partial = SCAN_CHUNK == 32 && c->a_planes == 1 && !c->cfg.use_power_floor && n_frames % SCAN_CHUNK == 0 && fc % SCAN_CHUNK == 0 &&
-                         plan_gemm(c, (long long)n_arrays * fc).ksplit <= 2 && std::getenv("MCA_HIP_NO_FUSED_PARTIAL") == nullptr;
+                         plan_gemm(c, (long long)n_arrays * fc).ksplit <= 2 && !c->kn.no_fused_partial;
     for (int f0 = 0; fused_partial && f0 < n_frames; f0 += (int)fc)
         fused_partial = plan_gemm(c, (long long)n_arrays * std::min<long long>(fc, n_frames - f0)).v2;
     c->ws().partial_done = fused_partial;
@@ -1093,7 +1152,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
 #undef L512T
 #undef L512
             rc = MCA_HIP_OK;
-        } else if ((c->N == 4096 || c->N == 2048) && c->M == 2 && c->stream_ok && std::getenv("MCA_HIP_NO_SUB2") == nullptr) {
+        } else if ((c->N == 4096 || c->N == 2048) && c->M == 2 && c->stream_ok && !c->kn.no_sub2) {
             // two microphones at 2048- / 4096-sample frames (FreqGCC at 32 / 44.1 / 48 kHz): 512-sample sub-sequences per channel
             sa.fpb = 8;
             while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
@@ -1155,7 +1214,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
                 hipLaunchKernelGGL(K, gv, dim3(512), smem, st, ga);                                                       \
             } while (0)
-            static const bool use_v3 = std::getenv("MCA_HIP_GEMM_V2") == nullptr;       // A/B switch: the 32x32x16 one-plane kernel
+            const bool use_v3 = !c->kn.gemm_v2;       // (A/B switch: the 32x32x16 one-plane kernel)
             if (c->a_planes == 2) V2_LAUNCH((k_srp_gemm_f16_v2<true>));
             else if (use_v3) V2_LAUNCH(k_srp_gemm_f16_v3);
             else V2_LAUNCH((k_srp_gemm_f16_v2<false>));
@@ -1230,8 +1289,11 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (!c->ws().partial_done) hipLaunchKernelGGL(k_scan_partial, g3, dim3(round_up(c->Dp / 4, 64)), 0, st, pa);   // a thread per four delays
     // ungated calls: k_scan_pick composes its chunk's start value itself (the chunks further back than four have decayed below the
     // last bit); with the gate a chunk may hold no advancing frame at all and the composition runs over all of them, in order
-    const bool no_lookback = std::getenv("MCA_HIP_SCAN_CARRY") != nullptr;           // A/B switch for measurements and tests (read per call)
-    pa.lookback = (!gate && !no_lookback) ? 4 : 0;
+    // The look-back drops g^4 E_{c-4} (g = 0.8^32: 3.9e-13 of E), which is below the last bit only while the map is bounded: under PHAT
+    // |C| <= P whatever the level.  With gcc_weighting NONE the map scales with the amplitude squared, and after a loud passage that
+    // falls to digital silence the exact recursion still carries the old peak for ~180 frames when the look-back has zeroed it
+    // (ADVICE r3): NONE always runs the serial carry pass.
+    pa.lookback = (!gate && !c->kn.scan_carry && c->cfg.gcc_weighting == MCA_HIP_GCC_PHAT) ? 4 : 0;
     if (!pa.lookback) hipLaunchKernelGGL(k_scan_carry, dim3(n_arrays, nthr / 64), dim3(64), 0, st, pa);   // one wave per 64 delays
     const size_t smem3 = (size_t)SCAN_SUB * (c->Dp + 8) * sizeof(float);
     const int ppl = c->D - 2 <= 128 ? 2 : c->D - 2 <= 384 ? 6 : 8;            // positions per lane of the peak pick
@@ -1289,7 +1351,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         }
         set_call_planes(c, 1);
         const size_t smem4 = (size_t)32 * (c->Dp + 8) * sizeof(float);
-        static const int repick_grid = std::getenv("MCA_HIP_REPICK_GRID") ? std::max(1, std::atoi(std::getenv("MCA_HIP_REPICK_GRID"))) : 256;   // A/B switch
+        const int repick_grid = std::max(1, c->kn.repick_grid);
 #define LAUNCH_REPICK(PL)                                                                                                           \
         do {                                                                                                                        \
             if (smem4 > 64 * 1024)      /* grids finer than 0.45 degrees: Dp >= 512 */                                              \
@@ -1325,8 +1387,7 @@ int mca_hip_get_repair_stats(mca_hip_ctx *c, unsigned long long *frames, unsigne
 // bins (the localiser's own picks); everything else stays on k_beamform_ola / _512 / _gen
 static bool wave_beamformer_applies(const mca_hip_ctx *c)
 {
-    const bool off = std::getenv("MCA_HIP_BF_OLA") != nullptr;      // A/B switch for measurements
-    return !off && !c->generic && !c->n512 && c->S <= 2 && c->M >= 2 && c->M <= MCA_MAX_MICS;   // (S = 3, 4: k_beamform_ola shares the forward transforms: 0.54 / 0.64 vs 0.54 / 0.69 ms)
+    return !c->kn.bf_ola && !c->generic && !c->n512 && c->S <= 2 && c->M >= 2 && c->M <= MCA_MAX_MICS;   // (S = 3, 4: k_beamform_ola shares the forward transforms: 0.54 / 0.64 vs 0.54 / 0.69 ms)
 }
 
 // steering rows of every grid angle (+ the initial DOA): allocated and built once, outside any capture
@@ -1353,13 +1414,13 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         wa.M = c->M; wa.n_pairs = c->bf_pairs; wa.n_frames = n_frames; wa.S = c->S;
         // frames per run (one wave each; every run re-analyses one extra frame for its overlap-add carry): long runs are
         // cheaper per frame, short ones fill the chip -- two waves per SIMD want 2048 runs
-        const int ft_env = std::getenv("MCA_HIP_BFW_FT") ? std::atoi(std::getenv("MCA_HIP_BFW_FT")) : 0;
+        const int ft_env = c->kn.bfw_ft;
         wa.ft = ft_env > 0 ? ft_env : 16;
         while (!ft_env && wa.ft > 2 && (long long)n_arrays * c->S * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
         wa.window = c->d_window; wa.doa_bin = doa_bin; wa.table = c->d_bftab; wa.out = out_pcm;
         wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->S * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->S * c->H;
-        const int abl = std::getenv("MCA_HIP_BFW_ABL") ? std::atoi(std::getenv("MCA_HIP_BFW_ABL")) & 3 : 0;     // measurement only: wrong results
-        const int var = abl ? 14 : (std::getenv("MCA_HIP_BFW_VAR") ? std::atoi(std::getenv("MCA_HIP_BFW_VAR")) & 15 : 15);
+        const int abl = c->kn.bfw_abl & 3;     // (-DMCA_MEASURE only: ablations with wrong results)
+        const int var = abl ? 14 : (c->kn.bfw_var & 15);
         // workgroups per array: 4 runs of ft frames each, or (hand-off of the overlap-add carries inside the workgroup, VAR bit 1)
         // 4 ft - 1 frames.  With the hand-off ft is the smallest run length whose workgroups are all resident at once (two per
         // CU: 512) -- one workgroup more than that costs a whole extra round.
@@ -1433,7 +1494,7 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (smem > 160 * 1024) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "n_mics/n_sources combination exceeds the 160 KiB LDS of a CU");
     dim3 g((n_frames + ba.ft - 1) / ba.ft, n_arrays);
     time_begin(c, MCA_HIP_K_BEAMFORM, st);
-    static const bool occ4 = std::getenv("MCA_HIP_BF_OCC2") == nullptr;     // A/B switch for measurements
+    const bool occ4 = !c->kn.bf_occ2;
 #define BF_LAUNCH(K)                                                                                                     \
     do {                                                                                                                 \
         if (smem > 64 * 1024)                                                                                            \
@@ -1549,10 +1610,12 @@ int mca_hip_graph_create(mca_hip_ctx *c, const float *pcm, long long array_strid
     *out = nullptr;
     int rc = check_stream_args(c, pcm, array_stride, mic_stride, n_arrays, n_frames);
     if (rc) return rc;
-    if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
+    // doa_bin_dev NULL: the separation stage alone, steered by the caller's angles in doa_rad_dev (mca_hip_separate_frames_dev: the
+    // delay-and-sum stream of mcabeamf.cpp:77-122, BASELINE configs[1])
+    if (!doa_bin && !out_pcm) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev and out_pcm_dev are both NULL: nothing to record");
     if (out_pcm && !doa_rad) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_rad_dev is NULL (the separation stage steers with it)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    if ((rc = reserve_impl(c, n_arrays, n_frames, true))) return rc;   // recording must not allocate (a recording runs as one lane)
+    if (doa_bin && (rc = reserve_impl(c, n_arrays, n_frames))) return rc;   // recording must not allocate (a recording runs as one lane)
     if (out_pcm && (rc = ensure_bf_table(c))) return rc;
     mca_hip_graph *g = new mca_hip_graph();
     g->c = c; g->pcm = pcm; g->array_stride = array_stride; g->mic_stride = mic_stride; g->n_arrays = n_arrays; g->n_frames = n_frames;
@@ -1575,7 +1638,9 @@ static int graph_record(mca_hip_graph *g, int idx)
     c->adapt_suspended = false; c->capturing = true;   // a recording is the mode's own kernels, whatever the eager calls do at the moment
     struct Restore { mca_hip_ctx *c; bool s; ~Restore() { c->adapt_suspended = s; c->capturing = false; } } restore{c, suspended};
     HIP_TRY(c, hipStreamBeginCapture(g->cap, hipStreamCaptureModeRelaxed));
-    int rc = mca_hip_localise_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_bin, g->doa_rad,
+    int rc = MCA_HIP_OK;
+    if (g->doa_bin)
+        rc = mca_hip_localise_frames_dev(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_bin, g->doa_rad,
                                          g->prob, g->energy, g->cap);
     if (!rc && g->out_pcm)
         rc = separate_frames_dev_bins(c, g->pcm, g->array_stride, g->mic_stride, g->n_arrays, g->n_frames, g->doa_rad, g->out_pcm, g->cap, g->doa_bin);
@@ -1602,7 +1667,7 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
         // would run on freed memory.  Make sure the workspace (still) fits this graph's shape, then record afresh.
         HIP_TRY(c, hipDeviceSynchronize());      // launches of the old recordings may still be in flight
         graph_drop_recordings(g);
-        const int rc = reserve_impl(c, g->n_arrays, g->n_frames, true);
+        const int rc = g->doa_bin ? reserve_impl(c, g->n_arrays, g->n_frames) : MCA_HIP_OK;
         if (rc) return rc;
         g->ws_gen = c->ws_gen;
     }
@@ -1612,11 +1677,13 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
         if (rc) return rc;
     }
     HIP_TRY(c, hipGraphLaunch(g->exec[idx], (hipStream_t)stream));
-    if (adaptive_shape(c, g->n_arrays, g->n_frames)) c->adapt_frames_total += (unsigned long long)g->n_arrays * g->n_frames;   // (a recording counts nothing)
-    c->e_cur ^= 1;                              // as the eager calls do
+    if (g->doa_bin && adaptive_shape(c, g->n_arrays, g->n_frames)) c->adapt_frames_total += (unsigned long long)g->n_arrays * g->n_frames;   // (a recording counts nothing)
+    if (g->doa_bin) c->e_cur ^= 1;              // as the eager calls do
     if (g->out_pcm) c->tail_cur ^= 1;
-    c->last_arrays = g->n_arrays; c->last_frames = g->n_frames;
-    c->n_lanes_last = 1; c->lanes[0].last_a0 = 0; c->lanes[0].last_arrays = g->n_arrays;
+    if (g->doa_bin) {
+        c->last_arrays = g->n_arrays; c->last_frames = g->n_frames;
+        c->n_lanes_last = 1; c->lanes[0].last_a0 = 0; c->lanes[0].last_arrays = g->n_arrays;
+    }
     return MCA_HIP_OK;
 }
 
@@ -2064,6 +2131,9 @@ int mca_hip_reset_timing(mca_hip_ctx *c)
     if (c->d_rstats) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipMemset(c->d_rstats, 0, 16)); }
     c->adapt_frames_total = 0;
     c->fb_groups_prev = 0; c->fb_frames_prev = 0; c->fb_seq_seen = c->fb_calls;   // (the reports in flight belong to the old totals)
+    // ... including a probe's, if the back-off is waiting for one: that report will never count as fresh, so the wait ends here
+    // and the mode resumes (the context stayed on FP16X3 until mca_hip_reset)
+    if (c->fb_state == 2) { c->fb_state = 0; c->adapt_suspended = false; }
     return rc;
 }
 

@@ -4,6 +4,7 @@
 #include "../../include/mcarray_hip.h"
 #include "fft512.h"
 #include "kernels.h"
+#include "knobs.h"
 #include "stage.h"
 #include "state_blob.h"
 
@@ -234,7 +235,7 @@ int mca_hip_mask_frames_dev(mca_hip_mask_ctx *c, const float *pcm, long long str
     a.Q_in = c->d_Q[c->q_cur]; a.Q_out = c->d_Q[c->q_cur ^ 1]; a.noise = c->d_noise;
     a.tail_in = c->d_tail[c->tail_cur]; a.tail_out = c->d_tail[c->tail_cur ^ 1];
     a.out = out_pcm; a.decisions = decisions;
-    static const bool no_tuned = std::getenv("MCA_HIP_MASK_GENERIC") != nullptr;      // A/B switch for measurements
+    static const bool no_tuned = mca::measure_env("MCA_HIP_MASK_GENERIC") != nullptr;      // A/B switch for measurements
     if (c->N == FFT_N && !no_tuned) {
         // 79 KiB: two workgroups per CU
         const size_t smem = (size_t)MK_NB * 2 * FFT_SCRATCH * sizeof(float2) + (size_t)MK_NB * 3 * 520 * sizeof(float) +

@@ -4,6 +4,7 @@
 #include "../../include/mcarray_hip.h"
 #include "fft512.h"
 #include "kernels.h"
+#include "knobs.h"
 #include "stage.h"
 #include "state_blob.h"
 
@@ -230,7 +231,7 @@ int mca_hip_mb_frames_dev(mca_hip_mb_ctx *c, const float *pcm, long long array_s
     aa.N = c->N; aa.logH = c->logH; aa.nbins = c->nb; aa.D = c->D;
     aa.window = c->d_window; aa.tw = c->d_tw; aa.coef = c->d_coef; aa.lo = c->d_lo; aa.hi = c->d_hi; aa.T = c->d_T;
     aa.raw = c->d_raw; aa.band_energy = c->d_be; aa.p_full = c->d_pf; aa.p_half = c->d_ph;
-    static const bool no_tuned = std::getenv("MCA_HIP_MB_GENERIC") != nullptr;     // A/B switch for measurements
+    static const bool no_tuned = mca::measure_env("MCA_HIP_MB_GENERIC") != nullptr;     // A/B switch for measurements
     if (c->N == FFT_N && !no_tuned) {
         // 1024-sample frames: wave-level FFT, 4 frames x 2 channels per pass
         int fpb = 16;

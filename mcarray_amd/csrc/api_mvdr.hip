@@ -5,6 +5,7 @@
 #include "../../include/mcarray_hip.h"
 #include "fft512.h"
 #include "kernels.h"
+#include "knobs.h"
 #include "stage.h"
 #include "state_blob.h"
 
@@ -24,6 +25,7 @@ struct mca_hip_mvdr_ctx {
     double *d_micx = nullptr;
     float2 *d_phi = nullptr;      // [max_streams][K][tri]
     float *d_trace = nullptr;     // [max_streams][K]
+    float2 *d_phi_tail = nullptr; float *d_trace_tail = nullptr;   // exit state of the pieced tail launch (<= 128 workgroups x 64 problems), copied back behind it
     float *d_tail[2] = {nullptr, nullptr}; int tail_cur = 0;   // [max_streams][H]
     // workspace
     float2 *d_X = nullptr; size_t x_rows = 0;      // [rows][K][M]
@@ -59,7 +61,7 @@ void free_mvdr(mca_hip_mvdr_ctx *c)
 {
     if (!c) return;
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->d_window); F(c->d_tw); F(c->d_micx); F(c->d_phi); F(c->d_trace); F(c->d_tail[0]); F(c->d_tail[1]);
+    F(c->d_window); F(c->d_tw); F(c->d_micx); F(c->d_phi); F(c->d_trace); F(c->d_phi_tail); F(c->d_trace_tail); F(c->d_tail[0]); F(c->d_tail[1]);
     F(c->d_X); F(c->d_Y); F(c->d_T);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     c->stage.release();
@@ -164,6 +166,7 @@ int mca_hip_mvdr_create(const mca_hip_mvdr_config *cfg, mca_hip_mvdr_ctx **out)
     if ((rc = up((void **)&c->d_window, win.data(), win.size() * 4)) || (rc = up((void **)&c->d_tw, tw.data(), tw.size() * 8)) ||
         (rc = up((void **)&c->d_micx, mx.data(), mx.size() * 8)) ||
         (rc = alloc((void **)&c->d_phi, ns * c->K * c->tri * sizeof(float2))) || (rc = alloc((void **)&c->d_trace, ns * c->K * 4)) ||
+        (rc = alloc((void **)&c->d_phi_tail, (size_t)128 * 64 * c->tri * sizeof(float2))) || (rc = alloc((void **)&c->d_trace_tail, (size_t)128 * 64 * 4)) ||
         (rc = alloc((void **)&c->d_tail[0], ns * c->H * 4)) || (rc = alloc((void **)&c->d_tail[1], ns * c->H * 4)) ||
         (rc = init_state(c, nullptr))) {
         g_mvdr_create_error = c->err; free_mvdr(c); return rc;
@@ -215,7 +218,7 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     aa.N = c->N; aa.logH = c->logH; aa.M = c->M; aa.window = c->d_window; aa.tw = c->d_tw; aa.doa_rad = doa_rad;
     aa.X = c->d_X; aa.T = c->d_T; aa.mic_x = c->d_micx;
     aa.unit = (double)c->cfg.sample_rate / (double)c->N / 346.1;                      // Beamformer.cpp:59 without 2 pi
-    static const bool no_tuned = std::getenv("MCA_HIP_MVDR_GENERIC") != nullptr;     // A/B switch for measurements
+    static const bool no_tuned = mca::measure_env("MCA_HIP_MVDR_GENERIC") != nullptr;     // A/B switch for measurements
     t_begin(c, 0, st);
     if (c->N == FFT_N && !no_tuned) {
         // 1024-sample frames: wave-level FFT, one wave per channel, eight channels per pass
@@ -249,6 +252,10 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     const int Q = (c->M + 3) / 4;                                                     // row slots per lane
     auto launch_solve = [&](long long pid0, long long n_prob, int pieces) {
         sa.pid0 = pid0; sa.n_prob = n_prob; sa.pieces = pieces;
+        // an unsplit launch updates the state in place; the pieces of a split one all read the entry state, so the last piece
+        // writes the exit state to a scratch copy that is moved over behind the launch
+        if (pieces > 1) { sa.phi_out = c->d_phi_tail; sa.trace_out = c->d_trace_tail; sa.out_base = pid0; }
+        else { sa.phi_out = c->d_phi; sa.trace_out = c->d_trace; sa.out_base = 0; }
         const dim3 sgrid((unsigned)((n_prob + 63) / 64 * pieces));
 #define SOLVE(QQ)                                                                                          \
     do {                                                                                                   \
@@ -264,19 +271,21 @@ int mca_hip_mvdr_frames_dev(mca_hip_mvdr_ctx *c, const float *pcm, long long str
     // 512 workgroups are resident (two per CU at 253 VGPRs) and all take the same time: the workgroups behind the last whole
     // round (256 streams x 513 bins: 4 of 2052) would hold the GPU for a round of their own.  They go in a second launch,
     // cut along the FRAMES into pieces that each repeat the (cheap) covariance recursion of the frames before their own.
-    static const int env_pieces = std::getenv("MCA_HIP_MVDR_PIECES") ? std::atoi(std::getenv("MCA_HIP_MVDR_PIECES")) : -1;   // A/B switch
+    static const int env_pieces = mca::measure_env("MCA_HIP_MVDR_PIECES") ? std::atoi(mca::measure_env("MCA_HIP_MVDR_PIECES")) : -1;   // A/B switch
     const long long n_prob = (long long)n_streams * c->K, n_wg = (n_prob + 63) / 64;
     const long long rem_wg = n_wg % 512;
     int pieces = 1;
     if (n_wg > 512 && rem_wg > 0 && rem_wg <= 128) {
         while (pieces < 8 && rem_wg * pieces * 2 <= 512 && n_frames / (pieces * 2) >= 4) pieces *= 2;
     }
-    if (env_pieces >= 0) pieces = env_pieces == 0 ? 1 : std::min(std::max(env_pieces, 1), n_frames);
+    if (env_pieces >= 0 && (env_pieces <= 1 || (n_wg > 512 && rem_wg > 0 && rem_wg <= 128))) pieces = env_pieces == 0 ? 1 : std::min(std::max(env_pieces, 1), n_frames);
     t_begin(c, 1, st);
     if (pieces > 1 && n_wg > 512) {
-        const long long main_prob = (n_wg - rem_wg) * 64;
+        const long long main_prob = (n_wg - rem_wg) * 64, tail_prob = n_prob - main_prob;       // tail_prob <= 128 x 64: the scratch copy's size
         launch_solve(0, main_prob, 1);
-        launch_solve(main_prob, n_prob - main_prob, pieces);
+        launch_solve(main_prob, tail_prob, pieces);
+        VHIP_TRY(c, hipMemcpyAsync(c->d_phi + main_prob * c->tri, c->d_phi_tail, (size_t)tail_prob * c->tri * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        VHIP_TRY(c, hipMemcpyAsync(c->d_trace + main_prob, c->d_trace_tail, (size_t)tail_prob * 4, hipMemcpyDeviceToDevice, st));
     } else {
         launch_solve(0, n_prob, 1);
     }

@@ -262,14 +262,15 @@ __global__ __launch_bounds__(256, 2) void k_mvdr_solve(MvdrSolveArgs p)
         if (l == 0 && pv) yo[(long long)t * K] = y;
     }
     if (pv && t_last == F) {
+        float2 *so = p.phi_out + (pc - p.out_base) * tri;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int i = 4 * q + l;
 #pragma unroll
             for (int m = 0; m < 4 * (q + 1); ++m)
-                if (i < M && m <= i) st[i * (i + 1) / 2 + m] = P[2 * q * (q + 1) + m];
+                if (i < M && m <= i) so[i * (i + 1) / 2 + m] = P[2 * q * (q + 1) + m];
         }
-        if (l == 0) p.trace[pc] = tr;
+        if (l == 0) p.trace_out[pc - p.out_base] = tr;
     }
 }
 

@@ -329,8 +329,12 @@ struct MvdrSolveArgs {
     const float2 *T;          // [streams][n_frames][M][nhi + 32] factored steering phasors (MvdrAnalyseArgs)
     int n_streams, n_frames, K, M;
     float alpha, one_minus_alpha, loading_over_m;
-    float2 *phi;              // [streams][K][M(M+1)/2] lower triangle of the covariance, row-major
+    float2 *phi;              // [streams][K][M(M+1)/2] lower triangle of the covariance, row-major (state at entry)
     float *trace;             // [streams][K] tr(Phi), carried as its own recursion
+    // state at exit: problem pid goes to phi_out[(pid - out_base) tri], trace_out[pid - out_base].  The same buffers for an unsplit
+    // launch (every problem is read and written by one workgroup); a launch cut into pieces writes to a scratch copy, because
+    // every piece reads the entry state when it starts and nothing orders that before the last piece's stores
+    float2 *phi_out; float *trace_out; long long out_base;
     float2 *Y;                // [streams][n_frames][K] beamformed spectrum
 };
 

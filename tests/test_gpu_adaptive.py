@@ -231,3 +231,56 @@ def test_adaptive_fine_grid_dp512(force_small):
     o = po.ssl_stream(fs, N, synth.ULA8, pcm.astype(np.float64), 1, 0.4, want_map=True, want_audio=False)
     _assert_bins(r["bin"][0], o["bin"], o["energy"], ctx.P, max_ties=2)
     ctx.close()
+
+
+def test_adaptive_fallback_off_is_an_api_field_and_runs_are_bit_reproducible(monkeypatch):
+    """mca_hip_config.adaptive_fallback = OFF (round 4; before: the environment only): every eligible call runs coarse + repair
+    whatever the content, and two identical runs return the same bits in EVERY output -- on noise-only input too, where AUTO
+    would back off at a call that depends on when the GPU's report reaches the host."""
+    monkeypatch.delenv("MCA_HIP_ADAPT_FALLBACK", raising=False)       # the field decides, not the environment
+    monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "256")
+    fs, N, F, A, n_calls = 48000, 1024, 256, 2, 6
+    xs = synth.ULA8
+    rng = np.random.default_rng(11)
+    pcm = (0.1 * rng.standard_normal((A, len(xs), (n_calls * F + 1) * 512))).astype(np.float32)
+    pcm[1] = synth.noise_source_stream(xs, np.deg2rad(31.0), fs, (n_calls * F + 1) * 512, 77, snr_db=10.0)
+    runs = []
+    for _ in range(2):
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A, adaptive_fallback=False)
+        ctx.reset_timing()
+        outs = [ctx.process_frames_host(pcm[:, :, i * F * 512:((i + 1) * F + 1) * 512], want_energy=True) for i in range(n_calls)]
+        assert ctx.repair_stats()["frames"] == n_calls * A * F           # no call backed off
+        runs.append(outs)
+        ctx.close()
+    for a, b in zip(*runs):
+        for k in ("bin", "doa", "prob", "energy", "out"):
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_graph_of_a_new_shape_while_the_mode_is_suspended(monkeypatch):
+    """mca_hip_graph_create while the back-off has suspended the adaptive mode reserved the FP16X3 workspace only; the
+    recording -- always coarse + repair -- then allocated inside the capture and failed.  Reserve is by the shape of the call."""
+    monkeypatch.setenv("MCA_HIP_ADAPT_FALLBACK", "1")
+    monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "256")
+    fs, N, F, A = 48000, 1024, 256, 1
+    xs = synth.ULA8
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=2)
+    ctx.reset_timing()
+    noise = (0.1 * rng.standard_normal((A, len(xs), (F + 1) * 512))).astype(np.float32)
+    ctx.process_frames_host(noise)                     # adaptive: everything flagged, the report says so
+    ctx.process_frames_host(noise)                     # reads the report: suspended from here on
+    assert ctx.repair_stats()["frames"] == A * F
+    F2, A2 = 320, 2                                    # a shape this context has not run in adaptive mode
+    pcm = torch.from_numpy(np.stack([synth.noise_source_stream(xs, np.deg2rad(20.0 + 30 * a), fs, (F2 + 1) * 512, 5 + a) for a in range(A2)])).to(dev)
+    b = torch.empty(A2, F2, 1, dtype=torch.int32, device=dev); r = torch.empty(A2, F2, 1, dtype=torch.float32, device=dev)
+    q = torch.empty(A2, F2, 1, dtype=torch.float32, device=dev); o = torch.empty(A2, 1, F2 * 512, dtype=torch.float32, device=dev)
+    ctx.reset()
+    g = ctx.graph_create(pcm, F2, b, r, q, None, o)
+    g.launch()
+    torch.cuda.synchronize()
+    ref = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16X3, max_arrays=2).process_frames_host(pcm.cpu().numpy())
+    assert np.mean(b.cpu().numpy() != ref["bin"]) < 0.01
+    assert np.abs(o.cpu().numpy() - ref["out"]).max() <= 1e-3 * np.abs(ref["out"]).max()     # (a flipped tie moves the steering by one bin)
+    g.close(); ctx.close()

@@ -97,3 +97,46 @@ def test_graph_survives_workspace_growth_and_context_destruction():
         g.launch(st)
     g.close()
     eager.close()
+
+
+def test_separation_only_graph_equals_the_eager_delay_and_sum_call():
+    """doa_bin NULL (round 4): the graph records mca_hip_separate_frames_dev alone -- the delay-and-sum stream of the reference's
+    mcabeamf (src/programs/mcabeamf.cpp:77-122, Beamformer.cpp:51-71) chunk by chunk at a caller-given angle; bit-identical to the
+    eager calls, overlap-add carried from chunk to chunk."""
+    import torch
+    from mcarray_amd import api, synth
+    fs, N, Fc, n_chunks = 48000, 1024, 8, 5
+    xs = synth.ULA8
+    dev = torch.device("cuda:0")
+    pcm = torch.from_numpy(synth.noise_source_stream(xs, np.deg2rad(-37.0), fs, (Fc * n_chunks + 1) * 512, 21)[None]).to(dev)
+    ang = float(np.deg2rad(-36.3))                      # not a grid angle
+    outs = {}
+    for mode in ("eager", "graph"):
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
+        buf = torch.zeros(1, len(xs), (Fc + 1) * 512, dtype=torch.float32, device=dev)
+        rad = torch.full((1, Fc, 1), ang, dtype=torch.float32, device=dev)
+        o = torch.empty(1, 1, Fc * 512, dtype=torch.float32, device=dev)
+        g = ctx.graph_create(buf, Fc, None, rad, None, None, o) if mode == "graph" else None
+        got = []
+        for i in range(n_chunks):
+            buf.copy_(pcm[:, :, i * Fc * 512:((i + 1) * Fc + 1) * 512])
+            if g:
+                g.launch()
+            else:
+                ctx.process_frames_dev(buf, Fc, None, rad, None, None, o, localise=False, separate=True)
+            torch.cuda.synchronize()
+            got.append(o.cpu().numpy().copy())
+        outs[mode] = np.concatenate(got, axis=2)
+        if g:
+            g.close()
+        ctx.close()
+    assert np.array_equal(outs["eager"], outs["graph"])
+    from oracle import pyoracle as po
+    # the oracle's Beamformer stream at the same angle
+    ref = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
+    whole = torch.empty(1, 1, Fc * n_chunks * 512, dtype=torch.float32, device=dev)
+    ref.process_frames_dev(pcm.contiguous(), Fc * n_chunks, None, torch.full((1, Fc * n_chunks, 1), ang, dtype=torch.float32, device=dev), None, None, whole,
+                           localise=False, separate=True)
+    torch.cuda.synchronize()
+    assert np.abs(whole.cpu().numpy() - outs["graph"]).max() <= 2e-6 * np.abs(outs["graph"]).max() + 1e-9   # run boundaries differ: fp32 rounding only
+    ref.close()

@@ -924,3 +924,29 @@ def test_gcc_weighting_none_localises_the_references_literal_sines():
     # fp16 operands cannot carry un-normalised spectra: refused, not silently whitened
     with pytest.raises(api.MCArrayHipError):
         api.Context(fs, synth.ULA8, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, gcc_weighting=api.GCC_NONE)
+
+
+def test_gcc_weighting_none_long_stream_loud_then_digital_silence():
+    """under gcc_weighting NONE the map scales with the amplitude squared and has no bound, so the four-chunk look-back of
+    the ungated scan (which drops 0.8^128 of an earlier energy: below the last bit only of a BOUNDED map) is not taken: after a loud
+    passage at the reference's own 16-bit scale (test_mcarray.cpp:397: amplitude 5000) that falls to exact zeros, the recursion
+    E = 0.8f E + ... must keep carrying the old peak, frame by frame, like the reference's (SteeringBeamforming.cpp:132-144).  Checked
+    against the oracle with a PER-FRAME scale (the global one is blind to a decayed tail), over two calls."""
+    fs, N, F, loud = 48000, 1024, 420, 90
+    xs = synth.ULA8
+    pcm = (5000.0 * synth.noise_source_stream(xs, np.deg2rad(-24.0), fs, (F + 1) * N // 2, 12, snr_db=25.0)).astype(np.float32)
+    pcm[:, (loud + 1) * 512:] = 0.0
+    ctx = api.Context(fs, xs, N, 5.0, 1, srp_precision=api.SRP_FP32, gcc_weighting=api.GCC_NONE)
+    cut = 200
+    ra = ctx.process_frames_host(pcm[None, :, :(cut + 1) * 512], want_energy=True)
+    rb = ctx.process_frames_host(pcm[None, :, cut * 512:], want_energy=True)
+    en = np.concatenate([ra["energy"], rb["energy"]], axis=1)[0]
+    o = po.ssl_stream(fs, N, xs, pcm.astype(np.float64), 1, 5.0, want_map=True, weighting="none")
+    peak = np.abs(o["energy"]).max(axis=1)
+    assert peak[loud - 1] > 1e12                              # 16-bit scale: nothing like PHAT's |C| <= P
+    live = peak > 1e-20                                       # (above fp32's denormals: ~330 silent frames)
+    assert live.sum() > loud + 250
+    rel = np.abs(en - o["energy"]).max(axis=1)[live] / peak[live]
+    assert rel.max() <= 5e-5, (int(np.argmax(rel)), float(rel.max()))
+    _assert_bins(np.concatenate([ra["bin"], rb["bin"]], axis=1)[0][:loud], o["bin"][:loud], o["energy"][:loud], ctx.P, max_ties=1)
+    ctx.close()

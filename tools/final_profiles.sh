@@ -3,12 +3,12 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 for p in adaptive fp16x3; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_$p -- python3 bench.py --steps 100 --warmup 20 --cpu-frames 0 --single-stream 0 --precision $p > gpurun_out/final/rocprof_$p.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_$p -- python3 bench.py --steps 100 --warmup 20 --cpu-frames 0 --single-stream 0 --extras 0 --precision $p > gpurun_out/final/rocprof_$p.log 2>&1
   python3 tools/summarize_rocprof.py gpurun_out/final/rocprof_$p gpurun_out/final/kernel_stats_$p.csv > /dev/null
 done
 timeout 900 python bench.py > gpurun_out/final/bench_adaptive.log 2>&1
 # BASELINE configs[4]'s per-GPU shape (128 arrays x 256 frames) in the shipped default
-timeout 300 python bench.py --arrays 128 --frames 256 --cpu-frames 0 --single-stream 0 > gpurun_out/final/bench_128x256.log 2>&1
+timeout 300 python bench.py --arrays 128 --frames 256 --cpu-frames 0 --single-stream 0 --extras 0 > gpurun_out/final/bench_128x256.log 2>&1
 grep "^{" gpurun_out/final/bench_128x256.log | tail -1 > gpurun_out/final/bench_128x256.json
 timeout 900 python bench.py --precision fp16x3 --cpu-frames 0 > gpurun_out/final/bench_fp16x3.log 2>&1
 timeout 900 python bench.py --precision fp16 --cpu-frames 0 > gpurun_out/final/bench_fp16.log 2>&1

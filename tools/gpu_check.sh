@@ -6,7 +6,7 @@ mkdir -p gpurun_out/$tag
 timeout 1200 python -m pytest tests -m gpu -q --timeout 900 "$@" 2>&1 | tail -40 > gpurun_out/$tag/tests.log
 cat gpurun_out/$tag/tests.log
 for p in fp32 fp16x3 fp16; do
-  timeout 300 python bench.py --steps 10 --warmup 2 --precision $p --cpu-frames 0 > gpurun_out/$tag/bench_$p.log 2>&1
+  timeout 300 python bench.py --steps 10 --warmup 2 --precision $p --cpu-frames 0 --extras 0 > gpurun_out/$tag/bench_$p.log 2>&1
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/$tag/bench_$p.log") if x.startswith("{")]

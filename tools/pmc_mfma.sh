@@ -5,7 +5,7 @@
 prec=${1:-fp16x3}; out=${2:-gpurun_out/pmc_mfma}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F16 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/p1 -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --precision $prec > $out/p1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F16 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/p1 -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --single-stream 0 --extras 0 --precision $prec > $out/p1.log 2>&1
 python3 - <<PY
 import csv,glob,collections,json
 res=collections.defaultdict(dict)

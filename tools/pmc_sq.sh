@@ -9,7 +9,7 @@ P2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WA
 i=0
 for set in "$P1" "$P2"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --single-stream 0 --precision $prec > $out/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --single-stream 0 --extras 0 --precision $prec > $out/p$i.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json

@@ -5,7 +5,7 @@ prec=${1:-fp16x3}; out=${2:-gpurun_out/pmc_traffic}; extra=${3:-}       # extra:
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --single-stream 0 --precision $prec $extra > $out/$ctr.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --single-stream 0 --extras 0 --precision $prec $extra > $out/$ctr.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json
