@@ -664,6 +664,26 @@ template <typename OutT>
 int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, hipStream_t st)
 {
     const int M = c->M; const bool ula = c->ula;
+    // a 16-microphone uniform linear array, one fp16 operand plane (the ADAPTIVE coarse pass, plain FP16): the wave-per-run kernel
+    // with its whitened spectra packed to fp16 (k_stft_phat_wave16); the exact rows of such an array stay on k_stft_phat<16>
+    if constexpr (sizeof(OutT) == 2) {
+        if (M == 16 && ula && a.a_planes == 1 && !a.list && !a.no_phat && !c->kn.stft_wg) {
+            StftPhatArgs w = a;
+            w.fpb = 16;
+            while (w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
+            const dim3 gw(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
+            const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 4 * w.fpb * 8) * sizeof(float2) + 1024 * sizeof(float);
+            if (a.power) {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_wave16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw));
+                hipLaunchKernelGGL(k_stft_phat_wave16<true>, gw, dim3(256), smw, st, w);
+            } else {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_wave16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw));
+                hipLaunchKernelGGL(k_stft_phat_wave16<false>, gw, dim3(256), smw, st, w);
+            }
+            HIP_TRY(c, hipGetLastError());
+            return MCA_HIP_OK;
+        }
+    }
     // 4 or 8 microphones: one wave per run of frames on the 1024-point transform of channel pairs (k_stft_phat_wave)
     if ((M == 8 || M == 4) && (a.no_phat || !c->kn.stft_wg)) {
         StftPhatArgs w = a;
@@ -1387,7 +1407,9 @@ int mca_hip_get_repair_stats(mca_hip_ctx *c, unsigned long long *frames, unsigne
 // bins (the localiser's own picks); everything else stays on k_beamform_ola / _512 / _gen
 static bool wave_beamformer_applies(const mca_hip_ctx *c)
 {
-    return !c->kn.bf_ola && !c->generic && !c->n512 && c->S <= 2 && c->M >= 2 && c->M <= MCA_MAX_MICS;   // (S = 3, 4: k_beamform_ola shares the forward transforms: 0.54 / 0.64 vs 0.54 / 0.69 ms)
+    // several sources: up to 8 microphones k_beamform_wave_ms (forward transforms shared, the pair spectra in registers); more
+    // microphones with two sources a grid row of k_beamform_wave per source, with three or four k_beamform_ola
+    return !c->kn.bf_ola && !c->generic && !c->n512 && (c->S <= 2 || c->M <= 8) && c->M >= 2 && c->M <= MCA_MAX_MICS;
 }
 
 // steering rows of every grid angle (+ the initial DOA): allocated and built once, outside any capture
@@ -1419,6 +1441,32 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         while (!ft_env && wa.ft > 2 && (long long)n_arrays * c->S * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
         wa.window = c->d_window; wa.doa_bin = doa_bin; wa.table = c->d_bftab; wa.out = out_pcm;
         wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->S * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->S * c->H;
+        if (c->S >= 2 && c->M <= 8) {
+            // the forward transforms of a frame shared by its sources
+            wa.ft = 16;
+            while (wa.ft > 2 && (long long)n_arrays * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
+            const int runs = (n_frames + wa.ft - 1) / wa.ft;
+            const size_t smem_ms = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2) + (size_t)4 * c->S * FFT_H * sizeof(float);
+            const dim3 gms((runs + 3) / 4, n_arrays);
+            time_begin(c, MCA_HIP_K_BEAMFORM, st);
+#define BFMS(NPT)                                                                                                                   \
+            do {                                                                                                                    \
+                if (smem_ms > 64 * 1024) {                                                                                          \
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_wave_ms<NPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ms)); \
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_wave_ms<NPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ms));  \
+                }                                                                                                                   \
+                if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave_ms<NPT, true>), gms, dim3(256), smem_ms, st, wa);                 \
+                else hipLaunchKernelGGL((k_beamform_wave_ms<NPT, false>), gms, dim3(256), smem_ms, st, wa);                         \
+            } while (0)
+            if (c->bf_pairs == 1) { time_end(c, st); return fail(c, MCA_HIP_ERR_UNSUPPORTED, "several sources need more than two microphones on the wave beamformer"); }
+            else if (c->bf_pairs == 2) BFMS(2);
+            else if (c->bf_pairs == 3) BFMS(3);
+            else BFMS(4);
+#undef BFMS
+            time_end(c, st);
+            HIP_TRY(c, hipGetLastError());
+            return MCA_HIP_OK;
+        }
         const int abl = c->kn.bfw_abl & 3;     // (-DMCA_MEASURE only: ablations with wrong results)
         const int var = abl ? 14 : (c->kn.bfw_var & 15);
         // workgroups per array: 4 runs of ft frames each, or (hand-off of the overlap-add carries inside the workgroup, VAR bit 1)
@@ -1433,6 +1481,7 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         time_begin(c, MCA_HIP_K_BEAMFORM, st);
 #define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa); \
                             else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa); break;
+#ifdef MCA_MEASURE
         if (abl == 1) hipLaunchKernelGGL((k_beamform_wave<false, 14, 1>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);
         else if (abl == 2) hipLaunchKernelGGL((k_beamform_wave<false, 14, 2>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);
         else if (abl == 3) hipLaunchKernelGGL((k_beamform_wave<false, 14, 3>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);
@@ -1441,6 +1490,9 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             BFW_CASE(0) BFW_CASE(1) BFW_CASE(2) BFW_CASE(3) BFW_CASE(4) BFW_CASE(5) BFW_CASE(6) BFW_CASE(7)
             BFW_CASE(8) BFW_CASE(9) BFW_CASE(10) BFW_CASE(11) BFW_CASE(12) BFW_CASE(13) BFW_CASE(14) BFW_CASE(15)
         }
+#else
+        switch (var) { BFW_CASE(15) }
+#endif
 #undef BFW_CASE
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());

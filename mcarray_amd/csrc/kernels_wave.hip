@@ -11,6 +11,8 @@
 //     y = Re IDFT(W),   W[k] = sum_p Z_p[k] T_p[k],   T_p[k] = (P_a[k] - j P_b[k]) / (M N),   k = 0..1023
 // because Y = W' + conj-mirror(W') for W' = W N / 2.  T depends on the steering angle only: one 8 KB row per (angle, pair),
 // built once per context (k_bf_table) and read through L2 -- the kernel computes no sincos and keeps no phasor state.
+#include <type_traits>
+
 #include "fft1024c.h"
 #include "mca_internal.h"
 #include "phat_pairs.h"
@@ -207,10 +209,129 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
 }
 
 #define INST_BFW(V) template __global__ void k_beamform_wave<false, V, 0>(BeamformWaveArgs); template __global__ void k_beamform_wave<true, V, 0>(BeamformWaveArgs);
+INST_BFW(15)              // the shipped variant
+#ifdef MCA_MEASURE        // the A/B variants and the ablations (wrong results) of DESIGN.md's measurements: make MEASURE=1 only
 template __global__ void k_beamform_wave<false, 14, 1>(BeamformWaveArgs); template __global__ void k_beamform_wave<false, 14, 2>(BeamformWaveArgs);
 template __global__ void k_beamform_wave<false, 14, 3>(BeamformWaveArgs);
 INST_BFW(0) INST_BFW(1) INST_BFW(2) INST_BFW(3) INST_BFW(4) INST_BFW(5) INST_BFW(6) INST_BFW(7)
-INST_BFW(8) INST_BFW(9) INST_BFW(10) INST_BFW(11) INST_BFW(12) INST_BFW(13) INST_BFW(14) INST_BFW(15)
+INST_BFW(8) INST_BFW(9) INST_BFW(10) INST_BFW(11) INST_BFW(12) INST_BFW(13) INST_BFW(14)
+#endif
+
+// --------------------------------------------------------------------------------------
+// k_beamform_wave_ms: several sources per array, the forward transforms SHARED (round 4; up to 8 microphones)
+// --------------------------------------------------------------------------------------
+// processFrameSeparation beamforms min(M, S) outputs from the SAME analysis frames (BeamformingSeparationAndLocalisation.cpp:113-114,
+// Beamformer.cpp:51-71): per frame the NPT pair spectra Z_p stay in registers (NPT <= 4: 128 of them) and every source s takes
+// W_s = sum_p Z_p T_p[bin_s], one inverse transform and its own overlap-add carry (LDS).  Per frame 4 forward + S inverse transforms
+// instead of S x (4 + 1): 2 975 instead of 5 286 vector instructions for three sources.  The steering rows of (source, pair + 1) are
+// requested element by element behind the multiply-accumulates of (source, pair) -- one buffer of 16 registers, refilled as it is
+// consumed --, those of the next source's first pair and the next frame's first samples in the middle of an inverse transform, where
+// the pair spectra (the last source) or the steering rows are dead.  One wave per run of ft frames; a run re-analyses the frame
+// before it for its overlap-add carry (its output is dropped).
+template <int NPT, bool ODD>
+__global__ __launch_bounds__(256, 2) void k_beamform_wave_ms(BeamformWaveArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *tab = reinterpret_cast<float2 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
+    const int S = p.S;
+    float *carry = reinterpret_cast<float *>(tab + F1K_TWORDS + 4 * F1K_SCRATCH) + wave * (S * FFT_H) + lane;   // [S][512] of this wave
+    f1k_table_init(tab, tid, 256);
+    F1kLane lc;
+    lc.init(lane);
+    __syncthreads();
+
+    const int a = blockIdx.y;
+    const int t0 = ((int)blockIdx.x * 4 + wave) * p.ft, t1 = min(t0 + p.ft, p.n_frames);
+    if (t0 >= t1) return;                                                 // (no barrier below)
+    const int tfirst = t0 > 0 ? t0 - 1 : 0;
+    v2f win[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { win[i].x = p.window[lane + 128 * i]; win[i].y = p.window[lane + 128 * i + 64]; }
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) carry[s * FFT_H + 64 * i] = t0 == 0 ? p.tail_in[((long long)a * S + s) * FFT_H + lane + 64 * i] : 0.f;
+    }
+    const float *base = p.pcm + (long long)a * p.array_stride + lane;
+    const int *bins = p.doa_bin + (long long)a * p.n_frames * S;            // [frame][source]
+    float xa[16], xb[16];
+    auto load_pair = [&](int t, int pr) {
+        const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)t * FFT_H;
+        const float *pb = (ODD && pr == NPT - 1) ? pa : pa + p.mic_stride;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
+    };
+    auto row_of = [&](int t, int s) { return p.table + ((long long)(bins[(long long)t * S + s] + 1) * NPT) * 1024 + lane; };
+    load_pair(tfirst, 0);
+    for (int t = tfirst; t < t1; ++t) {
+        float2 Z[NPT][16];
+#pragma unroll
+        for (int pr = 0; pr < NPT; ++pr) {
+            float2 z[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
+            if (ODD && pr == NPT - 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i].y = 0.f;
+            }
+            fft1024c<false, 3>(z, buf, lane, tab, lc, [&]() { if (pr + 1 < NPT) load_pair(t, pr + 1); });
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Z[pr][i] = z[i];
+        }
+        float2 T[16];
+        const float2 *trow = row_of(t, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = trow[64 * dr16(i)];
+        // one source: W = sum_p Z_p T_p, inverse transform, overlap-add.  LAST (peeled below: the pair spectra are dead behind its
+        // products, which the compiler must be able to see): the next frame's first samples are requested in the middle of its inverse
+        // transform; the other sources request the next source's first row right behind theirs.
+        auto source = [&](int s, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            float2 W[16];
+#pragma unroll
+            for (int pr = 0; pr < NPT; ++pr) {
+                __builtin_amdgcn_sched_barrier(0);      // (the refills stay behind this pair's products: hoisted, every pair's row would be live at once)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    W[i] = pr == 0 ? cmul(Z[0][i], T[i]) : cmac(W[i], Z[pr][i], T[i]);
+                    if (pr + 1 < NPT) T[i] = trow[(pr + 1) * 1024 + 64 * dr16(i)];   // the next pair's row, element by element behind its use
+                }
+            }
+            // W[q] holds bin lane + 64 dr16(q); the inverse takes register i = bin lane + 64 i and returns sample lane + 64 dr16(q)
+            float2 y[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] = W[dr16(i)];
+            if (LAST) {
+                fft1024c<true, 3>(y, buf, lane, tab, lc, [&]() { load_pair(min(t + 1, t1 - 1), 0); });   // (the run's last frame reloads its own)
+            } else {
+                fft1024c<true, 3>(y, buf, lane, tab, lc);
+                trow = row_of(t, s + 1);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) T[i] = trow[64 * dr16(i)];
+            }
+            float *cs = carry + s * FFT_H;
+            if (t >= t0) {
+                float *o = p.out + ((long long)a * S + s) * p.n_frames * FFT_H + (long long)t * FFT_H + lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[64 * i] = cs[64 * i] + y[dr16(i)].x;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cs[64 * i] = y[dr16(i + 8)].x;
+        };
+        for (int s = 0; s + 1 < S; ++s) source(s, std::false_type());
+        source(S - 1, std::true_type());
+    }
+    if (t1 == p.n_frames) {
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p.tail_out[((long long)a * S + s) * FFT_H + lane + 64 * i] = carry[s * FFT_H + 64 * i];
+        }
+    }
+}
+template __global__ void k_beamform_wave_ms<2, false>(BeamformWaveArgs); template __global__ void k_beamform_wave_ms<2, true>(BeamformWaveArgs);
+template __global__ void k_beamform_wave_ms<3, false>(BeamformWaveArgs); template __global__ void k_beamform_wave_ms<3, true>(BeamformWaveArgs);
+template __global__ void k_beamform_wave_ms<4, false>(BeamformWaveArgs); template __global__ void k_beamform_wave_ms<4, true>(BeamformWaveArgs);
 
 // --------------------------------------------------------------------------------------
 // k_stft_phat_wave: STFT analysis + GCC-PHAT pair products (SteeringBeamforming.cpp:104-130 up to the steering sum), one
@@ -533,6 +654,165 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         wave_lds_fence();
     }
 }
+
+// --------------------------------------------------------------------------------------
+// k_stft_phat_wave16: the wave-per-run analysis for a 16-microphone uniform linear array, ONE fp16 operand plane (round 4)
+// --------------------------------------------------------------------------------------
+// Eight pair transforms per frame; 16 channels x 8 bins of whitened spectra per lane would be 256 registers in fp32, so they are
+// kept as packed fp16 pairs (128 registers) -- this kernel only serves the rows that are rounded to fp16 anyway (the ADAPTIVE
+// coarse pass, plain FP16: every operand of the contraction carries that rounding, api.hip's error model) -- and the 120 pair
+// products of a bin are formed on v_dot2_f32_f16 with fp32 sums: Re a conj b = dot2(a, b), Im a conj b = dot2(a, (-b.y, b.x)), the
+// rotated copy one v_pk_mul_f16 per channel and bin.  The sums of the 15 spacings of a bin are converted and stored before the
+// next bin's are formed (30 accumulators).  The exact rows of such an array (FP16X3, the repair pass) stay on k_stft_phat<16>.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 rot_j_conj(h2 b)                            // (-b.y, b.x)
+{
+    h2 r;
+    const unsigned c = 0x3C00BC00u;                                        // (lo, hi) = (-1, +1)
+    asm("v_pk_mul_f16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(b), "v"(c));
+    return r;
+}
+
+template <bool POWER>
+__global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
+{
+    constexpr int MT = 16, NP = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *tab = reinterpret_cast<float2 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
+    float *wtab = reinterpret_cast<float *>(tab + F1K_TWORDS + 4 * F1K_SCRATCH);   // [64 lanes][16]: the lane's window samples w[lane + 64 i]
+    float2 *nyq = reinterpret_cast<float2 *>(wtab + 1024) + wave * (p.fpb * NP);  // [fpb][NP] Z_p[512] of the run's frames
+    for (int e = tid; e < 1024; e += 256) wtab[(e & 63) * 16 + (e >> 6)] = p.window[e];
+    f1k_table_init(tab, tid, 256);
+    F1kLane lc;
+    lc.init(lane);
+    __syncthreads();
+    const int lam = lane <= 32 ? lane : 96 - lane;
+    const unsigned voff = (unsigned)lam * 4u;
+    const bool self = (lane & 31) == 0;
+    // (the window is read from LDS per pair: 16 registers that the 128 of packed spectra do not leave room for)
+    const float4 *wq = reinterpret_cast<const float4 *>(wtab + lane * 16);
+
+    const int a = blockIdx.y;
+    const int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+    if (f_begin >= f_end) return;                                                 // (no barrier below)
+    const long long row_base = (long long)a * p.n_frames;
+    const float *base = p.pcm + (long long)a * p.array_stride + lane;
+    float xa[16], xb[16];
+    auto load_pair = [&](int f, int pr) {
+        const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)(p.frame0 + f) * FFT_H;
+        const float *pb = pa + p.mic_stride;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
+    };
+    const int nfr = f_end - f_begin;
+    const int rot = (int)((unsigned)(5 * a + 3 * ((int)blockIdx.x * 4 + wave)) % (unsigned)nfr);      // (row pitch: see k_stft_phat_wave)
+    auto frame_of = [&](int i) { const int j = i + rot; return f_begin + (j >= nfr ? j - nfr : j); };
+    load_pair(frame_of(0), 0);
+    for (int fi = 0; fi < nfr; ++fi) {
+        const int f = frame_of(fi);
+        h2 Xh[MT][8];
+        v2f ptime = {0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            float2 z[16];
+            unsigned oa = __float_as_uint(xa[0]), ob = __float_as_uint(xb[0]);
+#pragma unroll
+            for (int i = 1; i < 15; i += 2) { oa = or3(oa, __float_as_uint(xa[i]), __float_as_uint(xa[i + 1])); ob = or3(ob, __float_as_uint(xb[i]), __float_as_uint(xb[i + 1])); }
+            oa |= __float_as_uint(xa[15]); ob |= __float_as_uint(xb[15]);
+            const bool alive_a = __any((oa << 1) != 0), alive_b = __any((ob << 1) != 0);
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const float4 w4 = wq[i4];
+                const v2f w01 = {w4.x, w4.y}, w23 = {w4.z, w4.w};
+                z[4 * i4] = win_lo(xa[4 * i4], xb[4 * i4], w01); z[4 * i4 + 1] = win_hi(xa[4 * i4 + 1], xb[4 * i4 + 1], w01);
+                z[4 * i4 + 2] = win_lo(xa[4 * i4 + 2], xb[4 * i4 + 2], w23); z[4 * i4 + 3] = win_hi(xa[4 * i4 + 3], xb[4 * i4 + 3], w23);
+            }
+            if (POWER) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const v2f zv = to_v2f(z[i]); asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(ptime) : "v"(zv)); }
+            }
+            fft1024c<false, 3>(z, buf, lane, tab, lc, [&]() {
+                const bool lastp = pr == NP - 1, last = lastp && fi + 1 >= nfr;
+                load_pair(last ? f : (lastp ? frame_of(fi + 1) : f), last ? pr : (lastp ? 0 : pr + 1));
+            }, lam);
+            // the mirror exchange and the separation of the two channels: as k_stft_phat_wave
+            if (lane == 0) {
+                const float2 n = z[dr16(8)];
+                nyq[(f - f_begin) * NP + pr] = make_float2(alive_a ? n.x : 0.f, alive_b ? n.y : 0.f);
+                float2 t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t[j] = z[dr16(j)];
+#pragma unroll
+                for (int j = 8; j < 16; ++j) z[dr16(j < 12 ? j + 4 : j - 4)] = t[(j + 1) & 15];
+            } else if (self) {
+#pragma unroll
+                for (int j = 8; j < 12; ++j) { const float2 t = z[dr16(j)]; z[dr16(j)] = z[dr16(j + 4)]; z[dr16(j + 4)] = t; }
+            } else {
+#pragma unroll
+                for (int j = 8; j < 12; ++j) {
+                    float2 &u = z[dr16(j)], &w = z[dr16(j + 4)];
+                    swap_rows32(u.x, w.x); swap_rows32(w.x, u.x);
+                    swap_rows32(u.y, w.y); swap_rows32(w.y, u.y);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float2 zk = z[dr16(s)], zm = z[dr16(15 - s < 12 ? 15 - s + 4 : 15 - s - 4)];
+                const float2 a2 = make_float2(zk.x + zm.x, zk.y - zm.y);                               // 2 X_a
+                const float2 b2 = make_float2(zk.y + zm.y, zm.x - zk.x);                               // 2 X_b
+                float pwa, pwb;
+                const float2 wa = whiten4<false>(a2, pwa, alive_a), wb = whiten4<false>(b2, pwb, alive_b);
+                const float2_t va = {wa.x, wa.y}, vb = {wb.x, wb.y};
+                Xh[2 * pr][s] = __builtin_convertvector(va, h2);
+                Xh[2 * pr + 1][s] = __builtin_convertvector(vb, h2);
+            }
+        }
+        _Float16 *arow = reinterpret_cast<_Float16 *>(p.A) + (row_base + f) * (long long)p.a_row_elems;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            __builtin_amdgcn_sched_barrier(0);           // (one bin's 30 sums at a time: interleaved, the bins' accumulators spill)
+            h2 rj[MT];
+#pragma unroll
+            for (int j = 1; j < MT; ++j) rj[j] = rot_j_conj(Xh[j][s]);
+            float re[MT - 1], im[MT - 1];
+#pragma unroll
+            for (int g = 0; g < MT - 1; ++g) { re[g] = 0.f; im[g] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = i + 1; j < MT; ++j) {
+                    re[j - i - 1] = __builtin_amdgcn_fdot2(Xh[i][s], Xh[j][s], re[j - i - 1], false);
+                    im[j - i - 1] = __builtin_amdgcn_fdot2(Xh[i][s], rj[j], im[j - i - 1], false);
+                }
+#pragma unroll
+            for (int g = 0; g < MT - 1; ++g) store_a_wave<false>(arow, voff, g * KG + 64 * s, make_float2(re[g], im[g]), p.Kp);
+        }
+        if (POWER) {
+            const float pacc = wave_sum64(ptime.x + ptime.y);
+            if (lane == 0) p.power[(long long)a * p.total_frames + p.frame0 + f] = pacc / (float)FFT_N / (float)MT;
+        }
+    }
+    // Nyquist bins of the run: lane = frame (fp32: 120 products once per run)
+    wave_lds_fence();
+    if (lane < f_end - f_begin) {
+        float2 xn[MT], out[MT - 1];
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            const float2 n = nyq[lane * NP + pr];
+            float pw;
+            xn[2 * pr] = whiten4<false>(make_float2(2.f * n.x, 0.f), pw);
+            xn[2 * pr + 1] = whiten4<false>(make_float2(2.f * n.y, 0.f), pw);
+        }
+        _Float16 *arow = reinterpret_cast<_Float16 *>(p.A) + (row_base + f_begin + lane) * (long long)p.a_row_elems;
+        pair_products<MT, true>(xn, out);
+#pragma unroll
+        for (int g = 0; g < MT - 1; ++g) store_a_wave<false>(arow, 0u, g * KG + FFT_H, out[g], p.Kp);
+    }
+}
+template __global__ void k_stft_phat_wave16<false>(StftPhatArgs);
+template __global__ void k_stft_phat_wave16<true>(StftPhatArgs);
 
 #define INST_SPW1(MT, ULA, T, PL2, NP) template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, false, NP, false>(StftPhatArgs); \
                                        template __global__ void k_stft_phat_wave<MT, ULA, T, PL2, true, NP, false>(StftPhatArgs);

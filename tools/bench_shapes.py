@@ -74,6 +74,12 @@ if __name__ == "__main__":
             run(8, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, gate=gate, steps=30)
             run(4, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, gate=gate, steps=30)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "m16":         # 16 microphones, one far-field source per array: the exact split and the shipped default
+        run(16, 48000, 1024, 0.5, 8, 2048, prec=api.SRP_FP16X3, sources=True, steps=30)
+        run(16, 48000, 1024, 0.5, 8, 2048, prec=api.SRP_FP16, sources=True, steps=30)
+        run(16, 48000, 1024, 0.5, 8, 2048, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
+        run(16, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sources":
         for S in (1, 2, 3, 4):
             run(8, 48000, 1024, 0.5, 8, 4096, S=S, sources=True, prec=api.SRP_ADAPTIVE, steps=30)

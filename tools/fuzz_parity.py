@@ -16,10 +16,43 @@ os.environ.setdefault("MCA_HIP_ADAPT_FALLBACK", "0")     # the sweep is about co
 os.environ.setdefault("MCA_HIP_ADAPT_MAX_SOURCES", "4")   # ... with any number of sources
 os.environ.setdefault("MCA_HIP_ADAPT_MIN_ROWS", "128")      # let the adaptive mode run on the small batches the oracle can follow
 TOL_E = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: 2e-4}
-# a DOA-bin difference is CLASSIFIED if the oracle's own pick on that frame is fragile under perturbations of this size of the
-# normalised energies (mca_or_select_doa_fragile: peak ties, sign-chain ties, zero picks; tests/parity_helpers.py) -- the bar of
+# a DOA-bin difference is CLASSIFIED if the oracle's own pick on that frame is fragile under perturbations of this size -- relative to
+# the row's largest normalised energy, parity_helpers.row_eps -- of the normalised energies (mca_or_select_doa_fragile: peak ties, sign-chain ties, zero picks; tests/parity_helpers.py) -- the bar of
 # the GPU tests for the exact modes (ADAPTIVE is held to it: its bins are those of FP16X3), the mode's own error for plain fp16
 TIE = {api.SRP_FP32: parity_helpers.EPS_TIE, api.SRP_FP16X3: parity_helpers.EPS_TIE, api.SRP_FP16: 2e-4, api.SRP_ADAPTIVE: parity_helpers.EPS_TIE}
+
+
+def dump_case(fs, N, xs, step, S, gate, pcm, a, t, cut, r, o, P):
+    """MCA_FUZZ_DUMP=1: the numbers behind an unclassified difference -- normalised energies around the differing bins in the
+    oracle (fp64), in this run and in the two exact GPU modes on the same input, and the smallest perturbation at which the
+    oracle's own pick stops being pinned."""
+    hop = N // 2
+    En = lambda E: (np.asarray(E, dtype=np.float64) + 15.0 * P) / (30.0 * P)
+    rows = {"oracle": En(o["energy"][t]), "this run": En(r["energy"][a, t])}
+    for name, prec in (("fp32", api.SRP_FP32), ("fp16x3", api.SRP_FP16X3)):
+        c2 = api.Context(fs, xs, N, step, S, use_power_floor=gate, srp_precision=prec, max_arrays=pcm.shape[0])
+        if cut:
+            c2.process_frames_host(pcm[:, :, :(cut + 1) * hop], want_energy=True)
+            r2 = c2.process_frames_host(pcm[:, :, cut * hop:], want_energy=True)
+            tt = t - cut
+            if tt < 0:
+                c2.close()
+                continue
+        else:
+            r2, tt = c2.process_frames_host(pcm, want_energy=True), t
+        rows[name] = En(r2["energy"][a, tt])
+        print("   DUMP %-8s bins %s" % (name, r2["bin"][a, tt].tolist()))
+        c2.close()
+    gb, ob = r["bin"][a, t].tolist(), o["bin"][t].tolist()
+    for b in sorted(set(gb) | set(ob)):
+        lo, hi = max(b - 3, 0), min(b + 3, len(rows["oracle"]) - 1)
+        for name, e in rows.items():
+            print("   DUMP %-8s En[%d..%d] - En[%d] = %s" % (name, lo, hi, b, " ".join("%+.3e" % (e[i] - e[b]) for i in range(lo, hi + 1))))
+    for eps in (1e-6, 2e-6, 5e-6, 1e-5, 1e-4):
+        if po.select_doa_fragile(o["energy"][t], P, S, eps):
+            print("   DUMP the oracle's pick is fragile from eps = %.0e on; largest |En difference| to the oracle: %s" %
+                  (eps, {k: "%.2e" % np.abs(v - rows["oracle"]).max() for k, v in rows.items() if k != "oracle"}))
+            break
 
 
 def main(cases, seed, only_prec=None, adaptive_shapes=False):
@@ -66,11 +99,21 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False):
                 o = po.ssl_stream_gated(fs, N, xs, pcm[a].astype(np.float64), S, step, gate)
                 scale = np.abs(o["energy"]).max() + 1e-300
                 err = np.abs(r["energy"][a] - o["energy"]).max() / scale
-                assert err <= TOL_E[prec], "energy error %.2e" % err
+                # fp16-level maps (plain FP16, the unrepaired frames of ADAPTIVE): the rounding of the operands is an ABSOLUTE error of the
+                # map, sigma_C = 5e-4 sqrt(K/2 sum_g n_g^2) (api.hip's error model) -- few microphones and a weak peak make it a larger
+                # share of max|E| (round 4, seed 4003 case 352: 3 microphones, 6.4e-4 of a small peak)
+                tol = TOL_E[prec]
+                if prec in (api.SRP_FP16, api.SRP_ADAPTIVE):
+                    n_g2 = sum((M - 1 - g) ** 2 for g in range(M - 1)) if ctx.G == M - 1 and M > 2 else ctx.P
+                    tol = max(tol, 6.0 * 5e-4 * np.sqrt(0.5 * (N // 2 + 1) * n_g2) / scale)
+                assert err <= tol, "energy error %.2e (allowed %.2e)" % (err, tol)
                 mism = np.unique(np.argwhere(r["bin"][a] != o["bin"])[:, 0])
                 for t in mism:
-                    assert po.select_doa_fragile(o["energy"][t], ctx.P, S, TIE[prec]), \
-                        "UNCLASSIFIED bin difference at frame %d: gpu %s oracle %s (the oracle's pick is pinned at %.0e)" % (t, r["bin"][a, t].tolist(), o["bin"][t].tolist(), TIE[prec])
+                    if os.environ.get("MCA_FUZZ_DUMP") and not parity_helpers.fragile(o["energy"][t], ctx.P, S, TIE[prec]):
+                        dump_case(fs, N, xs, step, S, gate, pcm, a, t, cut, r, o, ctx.P)
+                    assert parity_helpers.fragile(o["energy"][t], ctx.P, S, TIE[prec]), \
+                        "UNCLASSIFIED bin difference at frame %d: gpu %s oracle %s (the oracle's pick is pinned at %.1e = %.0e of the row's peak)" % (
+                            t, r["bin"][a, t].tolist(), o["bin"][t].tolist(), parity_helpers.row_eps(o["energy"][t], ctx.P, TIE[prec]), TIE[prec])
                     ties += 1
                 if len(mism):
                     continue            # a flipped near-tie steers the beamformer elsewhere: the audio is not comparable
