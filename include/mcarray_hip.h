@@ -55,7 +55,15 @@ typedef enum {
                                 gate; every other call of such a context runs as FP16X3 -- as do its calls while most rows
                                 need the repair (noise only, silence: the context backs off by itself and probes again
                                 later; mca_hip_config.adaptive_fallback = OFF pins the mode).  The optional energy map
-                                keeps fp16 accuracy on unrepaired frames. */
+                                keeps fp16 accuracy on unrepaired frames.
+                                GUARANTEE: an unflagged frame carries the picks of the exact (FP16X3) map under the error model of
+                                the sensitivity test; a flagged frame is picked on energies recomputed exactly for its own row and
+                                the 16 rows before it (0.8^17 of the coarse error remains: within ~4e-7 of the map's peak of
+                                FP16X3's energies).  Picks that are TIES at that level -- two candidates, or a first difference
+                                against zero, closer than 1e-6 of the row's largest normalised energy: the bar of the parity tests
+                                -- may resolve differently from FP16X3 and between calls of different shapes.  Measured over 40
+                                random configurations / 696 320 frames: 61 picks on 43 frames differ from FP16X3, all 43 such ties
+                                (the same 61 / 43 with 24 rows instead of 16: profiles/r04_adaptive_check*.json). */
 } mca_hip_srp_precision;
 
 /* Weighting of the generalised cross-correlation inside dsp::GeneralisedCrossCorrelation::calculateCorrelationsForPrecomputedTauMatrix

@@ -32,7 +32,10 @@ constexpr int REPAIR_WARM = MCA_REPAIR_WARM;   // exact rows recomputed BEFORE a
                                   // error (~1.6e-5 of the map's peak) remains, i.e. ~3.6e-7 of the peak -- five times below the error of the
                                   // three-product split itself and below the 1e-6 tie bar of the parity tests.  (Round 2 used 24 rows,
                                   // 0.8^25: the always-recomputed tail of every array and call is what the repair pass mostly works on
-                                  // when a call has many arrays and few frames -- 128 x 256: 13.9 % of the rows with 24, 10.7 % with 16.)
+                                  // when a call has many arrays and few frames -- 128 x 256: 13.9 % of the rows with 24, 10.7 % with 16.
+                                  // Round 4, ADVICE r3: the flips against FP16X3 over 40 configurations / 696 320 frames are the SAME with
+                                  // 16 and with 24 rows -- 61 picks on 43 frames, all 43 ties at the parity bar's level -- profiles/
+                                  // r04_adaptive_check.json / _warm24.json; 24 rows cost +12 % / +30 % repair time at 8 x 4096 / 128 x 256.)
 constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mode pass of a k_stft_phat workgroup
 
 struct StftPhatArgs {

@@ -3,7 +3,11 @@ products with fp32 accumulation, fp16 intermediate) do to the COARSE SRP map of 
 coarse pass does (fp32 transform, one fp16 rounding of the merged PHAT sums and of the steering table)?  Bench geometry (8-mic
 ULA 0.04 m, 48 kHz, N = 1024, 361 angles), one far-field white source + sensor noise.  Prints the error of the map in units of
 the shipped coarse error and of the decision margin tau (api.hip), and the tail of the per-bin error of the whitened spectra.
-usage: python tools/probes/mfma_dft_error_sim.py [frames] [snr_db]"""
+Round 4: a COLOURED source (colour = "speech": flat to 300 Hz, then -12 dB per octave: 76 dB down at 24 kHz -- the long-term slope of
+speech and most real signals) next to the white one of the bench.  PHAT gives every bin the same weight whatever its level, and a
+transform whose error is relative to the frame's RMS (fp16 operands) leaves the bins that lie 50 dB below it without a usable
+phase; the share of bins that would need the exact fix-up (modulus below 30 x the transform's error) is printed.
+usage: python tools/probes/mfma_dft_error_sim.py [frames] [snr_db] [white|speech]"""
 import sys
 
 import numpy as np
@@ -16,12 +20,15 @@ def cf16(z):
     return f16(z.real) + 1j * f16(z.imag)
 
 
-def main(frames=48, snr_db=20.0, theta_deg=23.0, seed=3):
+def main(frames=48, snr_db=20.0, theta_deg=23.0, seed=3, colour="white"):
     rng = np.random.default_rng(seed)
     L = (frames + 1) * (N // 2)
     s = rng.standard_normal(L + 64) * 0.1
     S = np.fft.rfft(s)
     f = np.fft.rfftfreq(L + 64, 1.0 / FS)
+    if colour == "speech":
+        S = S * np.minimum(1.0, (300.0 / np.maximum(f, 1.0)) ** 2)                                  # -12 dB per octave above 300 Hz
+        S *= np.sqrt((s ** 2).sum() / max((np.fft.irfft(S, n=L + 64) ** 2).sum(), 1e-300))         # same total power as the white source
     xs = DX * np.arange(M)
     adv = xs * np.sin(np.deg2rad(theta_deg)) / C_SOUND
     x = np.fft.irfft(S[None, :] * np.exp(2j * np.pi * f[None, :] * adv[:, None]), n=L + 64, axis=1)[:, :L]
@@ -58,6 +65,11 @@ def main(frames=48, snr_db=20.0, theta_deg=23.0, seed=3):
     print("whitened spectra, |error| of the MFMA-style transform: rms %.2e  99%% %.2e  99.9%% %.2e  max %.2e   (fp16 rounding of a unit value: 2.4e-4 rms)"
           % (np.sqrt((err_bin ** 2).mean()), np.quantile(err_bin, 0.99), np.quantile(err_bin, 0.999), err_bin.max()))
 
+    # bins that an exact fix-up would have to recompute: modulus below 30 x the transform's error (3e-4 of the frame's RMS spectrum)
+    rms_spec = np.sqrt((np.abs(X) ** 2).mean(axis=2, keepdims=True))
+    need = np.abs(X) < 30 * 3.0e-4 * rms_spec
+    print("bins below 30 x the transform's error (exact fix-up needed): %.2f %% of all (channel, frame, bin) = %.1f per frame of %d microphones; "
+          "bins whose whitened error exceeds 0.1 (phase off by > 6 degrees): %.2f %%" % (100 * need.mean(), need.mean() * M * (N // 2 + 1), M, 100 * (err_bin > 0.1).mean()))
     # merged PHAT sums (ULA: index m = k g) and the steering contraction
     tau1 = (DX * np.sin(np.deg2rad(np.arange(D) * 0.5 - 90.0)) / C_SOUND * FS)                      # delay of spacing 1, samples
     def srp(W, round_sums):
@@ -88,4 +100,4 @@ def main(frames=48, snr_db=20.0, theta_deg=23.0, seed=3):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 48, float(sys.argv[2]) if len(sys.argv) > 2 else 20.0)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 48, float(sys.argv[2]) if len(sys.argv) > 2 else 20.0, colour=sys.argv[3] if len(sys.argv) > 3 else "white")
