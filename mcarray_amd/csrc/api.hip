@@ -1458,7 +1458,10 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
                 if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave_ms<NPT, true>), gms, dim3(256), smem_ms, st, wa);                 \
                 else hipLaunchKernelGGL((k_beamform_wave_ms<NPT, false>), gms, dim3(256), smem_ms, st, wa);                         \
             } while (0)
-            if (c->bf_pairs == 1) { time_end(c, st); return fail(c, MCA_HIP_ERR_UNSUPPORTED, "several sources need more than two microphones on the wave beamformer"); }
+            if (c->bf_pairs == 1) {          // two microphones: one pair (never odd)
+                if (smem_ms > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_wave_ms<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ms));
+                hipLaunchKernelGGL((k_beamform_wave_ms<1, false>), gms, dim3(256), smem_ms, st, wa);
+            }
             else if (c->bf_pairs == 2) BFMS(2);
             else if (c->bf_pairs == 3) BFMS(3);
             else BFMS(4);

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_beamform_wave_ms(BeamformWaveArgs p)
         }
     }
 }
+template __global__ void k_beamform_wave_ms<1, false>(BeamformWaveArgs);      // (two microphones: one pair)
 template __global__ void k_beamform_wave_ms<2, false>(BeamformWaveArgs); template __global__ void k_beamform_wave_ms<2, true>(BeamformWaveArgs);
 template __global__ void k_beamform_wave_ms<3, false>(BeamformWaveArgs); template __global__ void k_beamform_wave_ms<3, true>(BeamformWaveArgs);
 template __global__ void k_beamform_wave_ms<4, false>(BeamformWaveArgs); template __global__ void k_beamform_wave_ms<4, true>(BeamformWaveArgs);

@@ -965,7 +965,7 @@ def test_gcc_weighting_none_long_stream_loud_then_digital_silence():
     ctx.close()
 
 
-@pytest.mark.parametrize("M,S,step", [(8, 3, 1.0), (5, 4, 3.0), (7, 2, 0.5), (3, 2, 5.0)])
+@pytest.mark.parametrize("M,S,step", [(8, 3, 1.0), (5, 4, 3.0), (7, 2, 0.5), (3, 2, 5.0), (2, 3, 3.0)])
 def test_several_sources_share_the_forward_transforms(M, S, step):
     """k_beamform_wave_ms (round 4): the S beamformed outputs of a frame (processFrameSeparation,
     BeamformingSeparationAndLocalisation.cpp:113-118; Beamformer.cpp:51-71) come from ONE set of forward transforms of the channel pairs,
