@@ -987,3 +987,33 @@ def test_several_sources_share_the_forward_transforms(M, S, step):
         assert nout == min(M, S)
         assert np.abs(r["out"][0][:nout] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
     ctx.close()
+
+
+@pytest.mark.parametrize("gate", [False, True])
+def test_sixteen_microphone_wave_analysis_matches_oracle(gate):
+    """k_stft_phat_wave16 (round 4): a 16-microphone uniform linear array with ONE fp16 operand plane (MCA_HIP_SRP_FP16 here; the
+    ADAPTIVE coarse pass is test_adaptive_matches_oracle[ULA16]) -- whitened spectra packed to fp16, 120 pair products per bin on
+    v_dot2_f32_f16 (SteeringBeamforming.cpp:104-130 up to the steering sum).  Against the oracle at the plain-fp16 bars (energy map
+    2e-4 of the peak, bins at the mode's own tie level), with the power gate (the frame power comes from the same kernel), a dead
+    channel (exact zeros: X = 0 as in the reference's own transform, not its partner's rounding noise whitened to unit modulus)
+    and runs of frames that do not fill a wave's share."""
+    fs, N, F = 48000, 1024, 173 if gate else 77
+    xs = synth.ULA16
+    pcm = synth.noise_source_stream(xs, np.deg2rad(-33.0), fs, (F + 1) * N // 2, 61, snr_db=25.0).astype(np.float32)
+    if gate:
+        pcm[:, :150 * 512] *= 1e-3                                     # quiet lead-in: 3 s of floor estimation, then the source
+    pcm[11] = 0.0                                                       # a dead microphone
+    ctx = api.Context(fs, xs, N, 1.0, 1, use_power_floor=gate, srp_precision=api.SRP_FP16)
+    ra = ctx.process_frames_host(pcm[None, :, :(40 + 1) * 512], want_energy=True)
+    rb = ctx.process_frames_host(pcm[None, :, 40 * 512:], want_energy=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out") + (("voiced",) if gate else ())}
+    o = po.ssl_stream_gated(fs, N, xs, pcm.astype(np.float64), 1, 1.0, gate)
+    if gate:
+        assert np.array_equal(r["voiced"][0], o["fired"]) and 0 < o["fired"].sum() < F
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-4 * np.abs(o["energy"]).max()
+    from parity_helpers import fragile
+    for t in np.nonzero(r["bin"][0][:, 0] != o["bin"][:, 0])[0]:
+        assert fragile(o["energy"][t], ctx.P, 1, 2e-4), "frame %d: gpu %d oracle %d" % (t, r["bin"][0][t, 0], o["bin"][t, 0])
+    if np.array_equal(r["bin"][0], o["bin"]):
+        assert np.abs(r["out"][0] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
