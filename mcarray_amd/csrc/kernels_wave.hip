@@ -55,7 +55,7 @@ __device__ __forceinline__ float2 win_lo(float a, float b, v2f w)
 __device__ __forceinline__ float2 win_hi(float a, float b, v2f w)
 {
     v2f x = {a, b}, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(w));
+    asm("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(w));   // w in src0: its high half may feed the low result there (fft512.h, RULE)
     return from_v2f(r);
 }
 
@@ -272,8 +272,12 @@ __global__ __launch_bounds__(256, 2) void k_beamform_wave_ms(BeamformWaveArgs p)
 #pragma unroll
             for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
             if (ODD && pr == NPT - 1) {
+                // a zero the compiler cannot see through: folding it into the first butterflies makes the vectoriser pack adds with the
+                // operand selects fft512.h's RULE forbids (tools/check_isa.py fails the build on those)
+                float zero;
+                asm("v_mov_b32 %0, 0" : "=v"(zero));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) z[i].y = 0.f;
+                for (int i = 0; i < 16; ++i) z[i].y = zero;
             }
             fft1024c<false, 3>(z, buf, lane, tab, lc, [&]() { if (pr + 1 < NPT) load_pair(t, pr + 1); });
 #pragma unroll

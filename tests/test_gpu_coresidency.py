@@ -1,0 +1,102 @@
+"""The library beside other GPU work.  A host application may run its own kernels on other streams while this library serves its
+stream; both then share compute units.  On the MI355X boxes of this pool a neighbour that mixes MFMA with LDS reads makes one
+packed-fp32 operand path of a co-resident wave unreliable (the low result taking the high half of src1 -- DESIGN.md section 7;
+tools/probes/coresidency_standalone.hip reproduces it with no library code, and rocFFT returns wrong transforms under the same
+neighbour).  The library's kernels hold no such instruction (tools/check_isa.py, tests/test_cabi_loads.py), so its results must not
+move by one bit whatever runs beside it: that is what is tested here, with tests/cxx/neighbour.hip as the neighbour, next to a
+canary that tells whether this machine shows the effect at all."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mcarray_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _neighbour():
+    path = os.path.join(ROOT, "tests", "cxx", "libneighbour.so")
+    assert os.path.exists(path), "tests/cxx/libneighbour.so is missing: run __graft_entry__.build() (make -C tests/cxx)"
+    nb = C.CDLL(path)
+    nb.neighbour_launch.argtypes = [C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+    nb.canary_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return nb
+
+
+def _cus(dev):
+    return torch.cuda.get_device_properties(dev).multi_processor_count
+
+
+def test_the_neighbour_disturbs_the_forbidden_operand_select_on_this_machine():
+    nb = _neighbour()
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(device=dev)
+    sink = torch.zeros(1024 * 256, dtype=torch.float32, device=dev)
+    out = torch.zeros(2048 * 256, dtype=torch.int32, device=dev)
+    main = torch.cuda.current_stream().cuda_stream
+    assert nb.canary_launch(2048, 2000, C.c_void_p(out.data_ptr()), C.c_void_p(main)) == 0
+    torch.cuda.synchronize()
+    assert int(out.sum()) == 0, "the canary is wrong with nothing beside it"
+    assert nb.neighbour_launch(_cus(dev), 20000, C.c_void_p(sink.data_ptr()), C.c_void_p(side.cuda_stream)) == 0
+    assert nb.canary_launch(2048, 2000, C.c_void_p(out.data_ptr()), C.c_void_p(main)) == 0
+    torch.cuda.synchronize()
+    wrong = int(out.sum())
+    if wrong == 0:
+        pytest.skip("this machine does not show the operand-select effect: the immunity tests below have nothing to resist here")
+    print("canary: %d wrong results of %d beside the neighbour" % (wrong, 2048 * 256 * 2000))
+
+
+CASES = [  # (name, microphones, sources, precision, off-grid angles for the separation-only pass)
+    ("bench shape, ADAPTIVE", "ULA8", 1, "ADAPTIVE", False),
+    ("bench shape, exact split", "ULA8", 1, "FP16X3", True),
+    ("two sources", "ULA8", 2, "FP16X3", False),
+    ("sixteen microphones", "ULA16", 1, "ADAPTIVE", False),
+    ("four microphones (generic analysis)", "REEM_C", 1, "FP32", True),
+]
+
+
+@pytest.mark.parametrize("name,array,S,precision,offgrid", CASES, ids=[c[0] for c in CASES])
+def test_results_do_not_move_beside_a_matrix_core_neighbour(name, array, S, precision, offgrid):
+    nb = _neighbour()
+    dev = torch.device("cuda:0")
+    fs, N, F, A = 48000, 1024, 512, 8
+    xs = getattr(synth, array)
+    M = len(xs)
+    pcm = np.stack([sum(synth.noise_source_stream(xs, np.deg2rad(-60.0 + 17 * a + 40 * s), fs, (F + 1) * 512, 11 + a + 100 * s) for s in range(S)) for a in range(A)])
+    pcm = torch.from_numpy(pcm.astype(np.float32)).to(dev)
+    assert pcm.shape[1] == M
+    side = torch.cuda.Stream(device=dev)
+    sink = torch.zeros(1024 * 256, dtype=torch.float32, device=dev)
+    main = torch.cuda.current_stream().cuda_stream
+
+    def run(with_neighbour):
+        ctx = api.Context(fs, xs, N, 0.5, S, srp_precision=getattr(api, "SRP_" + precision), max_arrays=A)
+        b = torch.empty(A, F, S, dtype=torch.int32, device=dev); r = torch.empty(A, F, S, dtype=torch.float32, device=dev)
+        q = torch.empty(A, F, S, dtype=torch.float32, device=dev); o = torch.zeros(A, S, F * 512, dtype=torch.float32, device=dev)
+        en = torch.zeros(A, F, ctx.D, dtype=torch.float32, device=dev); o2 = torch.zeros(A, S, F * 512, dtype=torch.float32, device=dev)
+        off = torch.full((A, F, S), 0.1234, dtype=torch.float32, device=dev)
+        ctx.process_frames_dev(pcm, F, b, r, q, None, o, stream=main)       # tables, warm-up
+        torch.cuda.synchronize(); ctx.reset(); torch.cuda.synchronize()
+        if with_neighbour:
+            assert nb.neighbour_launch(_cus(dev), 20000, C.c_void_p(sink.data_ptr()), C.c_void_p(side.cuda_stream)) == 0
+        ctx.process_frames_dev(pcm, F, b, r, q, en, o, stream=main)
+        if offgrid:
+            ctx.process_frames_dev(pcm, F, None, off, None, None, o2, stream=main, localise=False, separate=True)
+        still_running = with_neighbour and not side.query()
+        torch.cuda.synchronize()
+        res = tuple(t.cpu().numpy().copy() for t in (b, q, en, o, o2))
+        ctx.close()
+        return res, still_running
+
+    ref, _ = run(False)
+    for rep in range(2):
+        got, overlapped = run(True)
+        assert overlapped, "the neighbour ended before the library's calls did: nothing ran side by side"
+        for what, x, y in zip(("DOA bins", "probabilities", "energy map", "beamformed audio", "off-grid audio"), ref, got):
+            assert np.array_equal(x, y), "%s: %s moved beside the neighbour (%d values, max |d| %.3e)" % (
+                name, what, int((x != y).sum()), float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))

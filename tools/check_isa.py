@@ -1,0 +1,50 @@
+"""ISA lint of the built library: no packed-fp32 instruction may let the LOW result take the HIGH half of src1 (op_sel bit 1).
+
+On the MI355X boxes of this pool that operand path returns a wrong value now and then while a wave of another kernel on the same SIMD
+mixes MFMA with LDS reads (tools/probes/coresidency_standalone.hip reproduces it without this library, rocFFT
+shows it too).  The hand-written helpers keep to the rule (fft512.h, RULE); this script catches what the compiler's vectoriser
+invents.  It disassembles every gfx950 code object inside mcarray_amd/libmcarray_hip.so and lists the offending instructions per
+kernel.  usage: python tools/check_isa.py [path/to/lib.so]     (exit code 1 when anything is found; tests/test_cabi_loads.py runs it)"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+RISKY = re.compile(r"\bv_pk_(?:add|mul|fma)_f32\b.*\bop_sel:\[[01],1")
+
+
+def offenders(lib):
+    """{kernel symbol: [instruction text, ...]} over all device code objects of lib."""
+    found = {}
+    tmp = tempfile.mkdtemp(prefix="mca_isa_")
+    try:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
+        if not objs:
+            raise RuntimeError("no device code objects found in %s" % lib)
+        for f in objs:
+            text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", f], cwd=tmp, check=True, capture_output=True, text=True).stdout
+            kernel = "?"
+            for line in text.splitlines():
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+                if m:
+                    kernel = m.group(1)
+                elif RISKY.search(line):
+                    found.setdefault(kernel, []).append(line.split("//")[0].strip())
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return found
+
+
+if __name__ == "__main__":
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mcarray_amd", "libmcarray_hip.so")
+    bad = offenders(lib)
+    for k in sorted(bad, key=lambda k: -len(bad[k])):
+        print("%5d  %s   e.g. %s" % (len(bad[k]), k, bad[k][0]))
+    print("%s: %d kernels hold %d packed-fp32 instructions with the high half of src1 in the low result" % (lib, len(bad), sum(len(v) for v in bad.values())))
+    sys.exit(1 if bad else 0)
