@@ -100,3 +100,100 @@ def test_results_do_not_move_beside_a_matrix_core_neighbour(name, array, S, prec
         for what, x, y in zip(("DOA bins", "probabilities", "energy map", "beamformed audio", "off-grid audio"), ref, got):
             assert np.array_equal(x, y), "%s: %s moved beside the neighbour (%d values, max |d| %.3e)" % (
                 name, what, int((x != y).sum()), float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
+
+
+def _noise2(fs, N, F, seed):
+    rng = np.random.default_rng(seed)
+    n = (F + 1) * (N // 2)
+    src = rng.standard_normal(n) * 0.1
+    return np.stack([src + rng.standard_normal(n) * 0.003, np.roll(src, 1) * 0.9 + rng.standard_normal(n) * 0.003]).astype(np.float32)
+
+
+def _module_cases():
+    """(name, callable returning a dict / tuple of numpy outputs): the other modules and frame lengths through their host-pointer entry points"""
+    def masking():
+        m = api.FastBinauralMasking(48000, 0.086, 300.0, 5000.0, fft_size=2048)
+        out, dec = m.process(_noise2(48000, 2048, 300, 3))
+        m.close()
+        return out, dec
+
+    def masking_1024():
+        m = api.FastBinauralMasking(16000, 0.086, 300.0, 5000.0, fft_size=1024)
+        out, dec = m.process(_noise2(16000, 1024, 600, 4))
+        m.close()
+        return out, dec
+
+    def multiband():
+        F, A = 400, 8
+        pcm = np.stack([synth.noise_source_stream(synth.BINAURAL, np.deg2rad(-55.0 + 15.0 * a), 48000, (F + 1) * 512, 40 + a) for a in range(A)])
+        loc = api.MultibandBinarualLocalisation(48000, synth.BINAURAL, 15, False, max_arrays=A)
+        r = loc.process(pcm, want_bands=True)
+        return tuple(r[k] for k in sorted(r))
+
+    def gcc2():
+        F, A = 600, 8
+        N = 1 << api.calculate_order_from_sample_rate(16000, api.FreqGCCBinauralLocalisation.FRAME_SECONDS)
+        pcm = np.stack([synth.noise_source_stream(synth.BINAURAL, np.deg2rad(-55.0 + 15.0 * a), 16000, (F + 1) * N // 2, 60 + a) for a in range(A)])
+        loc = api.FreqGCCBinauralLocalisation(16000, synth.BINAURAL, False, max_arrays=A)
+        r = loc.process(pcm, want_corr=True)
+        return tuple(r[k] for k in sorted(r))
+
+    def mvdr():
+        F, A, N = 60, 16, 1024
+        xs = synth.ULA16
+        pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(20.0 - 7 * a), 48000, (F + 1) * N // 2, 80 + a) for a in range(A)]).astype(np.float32)
+        doa = (np.deg2rad(20.0 - 7 * np.arange(A))[:, None] + 0.01 * np.arange(F)[None, :]).astype(np.float32)
+        bf = api.MvdrBeamformer(48000, xs, N, max_streams=A)
+        r = bf.process(pcm, doa, want_spec=True)
+        return r["out"], r["spec"]
+
+    def frames_512():
+        F, A = 1024, 8
+        pcm = np.stack([synth.noise_source_stream(synth.ULA8, np.deg2rad(-60.0 + 17 * a), 16000, (F + 1) * 256, 90 + a) for a in range(A)])
+        ctx = api.Context(16000, synth.ULA8, 512, 1.0, 1, srp_precision=api.SRP_FP16X3, max_arrays=A)
+        r = ctx.process_frames_host(pcm, want_energy=True)
+        ctx.close()
+        return tuple(r[k] for k in sorted(r))
+
+    def frames_2048():
+        F, A = 256, 8
+        pcm = np.stack([synth.noise_source_stream(synth.ULA8, np.deg2rad(-60.0 + 17 * a), 96000, (F + 1) * 1024, 95 + a) for a in range(A)])
+        ctx = api.Context(96000, synth.ULA8, 2048, 1.0, 1, srp_precision=api.SRP_FP32, max_arrays=A)
+        r = ctx.process_frames_host(pcm, want_energy=True)
+        ctx.close()
+        return tuple(r[k] for k in sorted(r))
+
+    return [("masking, 2048-sample frames", masking), ("masking, 1024-sample frames", masking_1024), ("multiband localiser", multiband), ("2-microphone GCC localiser", gcc2),
+            ("MVDR, 16 microphones", mvdr), ("512-sample frames", frames_512), ("2048-sample frames", frames_2048)]
+
+
+@pytest.mark.parametrize("which", range(7), ids=[c[0] for c in _module_cases()])
+def test_module_results_do_not_move_beside_a_matrix_core_neighbour(which):
+    name, fn = _module_cases()[which]
+    nb = _neighbour()
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(device=dev)
+    sink = torch.zeros(1024 * 256, dtype=torch.float32, device=dev)
+    import time
+    fn()                                                                      # (builds tables, loads code objects)
+    t0 = time.perf_counter()
+    ref = fn()
+    call_s = time.perf_counter() - t0
+    # a neighbour that outlasts the whole host-pointer call (copies in, kernels, copies out), sized from its measured rate
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        e0.record()
+        assert nb.neighbour_launch(_cus(dev), 20000, C.c_void_p(sink.data_ptr()), C.c_void_p(side.cuda_stream)) == 0
+        e1.record()
+    torch.cuda.synchronize()
+    per_iter_s = e0.elapsed_time(e1) * 1e-3 / 20000
+    iters = int(min(max(2.0 * call_s, 0.02), 3.0) / per_iter_s)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        assert nb.neighbour_launch(_cus(dev), iters, C.c_void_p(sink.data_ptr()), C.c_void_p(side.cuda_stream)) == 0
+        got = fn()              # (some host-pointer paths end in a device-wide synchronise, so "is the neighbour still running" cannot be
+        torch.cuda.synchronize()  # asked here: it is started first and lasts twice the whole call, copies included)
+        for i, (x, y) in enumerate(zip(ref, got)):
+            x, y = np.asarray(x), np.asarray(y)
+            assert np.array_equal(x, y), "%s: output %d moved beside the neighbour (%d values, max |d| %.3e)" % (
+                name, i, int((x != y).sum()), float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
