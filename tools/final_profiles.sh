@@ -1,7 +1,9 @@
 # Round profiles: the driver's bench command, bench lines per precision, rocprofv3 kernel stats, PMC traffic / SQ counters, shapes.
-# usage (GPU box, from the repo root): bash tools/final_profiles.sh ; then python tools/collect_profiles.py r04 here
+# usage (GPU box, from the repo root): bash tools/final_profiles.sh [a|b] (two halves that each fit one 20-minute gpurun call; default both) ; then python tools/collect_profiles.py r04 here
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
+PART=${1:-ab}
+if [[ $PART == *a* ]]; then
 # the driver's exact command, and the two short warm-ups VERDICT r3 asked about
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/final/bench_driver_cmd.log 2>&1
 grep "^{" gpurun_out/final/bench_driver_cmd.log | tail -1 > gpurun_out/final/bench_driver_cmd.json
@@ -24,6 +26,8 @@ timeout 900 python bench.py --precision fp32 --cpu-frames 0 --extras 0 --steps 3
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_mvdr -- python3 bench.py --config mvdr --steps 20 --warmup 5 --cpu-frames 0 > gpurun_out/final/rocprof_mvdr.log 2>&1
 python3 tools/summarize_rocprof.py gpurun_out/final/rocprof_mvdr gpurun_out/final/kernel_stats_mvdr.csv > /dev/null
 timeout 300 python bench.py --config mvdr > gpurun_out/final/bench_mvdr.log 2>&1
+fi
+if [[ $PART == *b* ]]; then
 bash tools/pmc_traffic.sh adaptive gpurun_out/pmc_traffic_adaptive > gpurun_out/final/pmc_traffic.log 2>&1
 bash tools/pmc_sq.sh adaptive gpurun_out/pmc_sq > gpurun_out/final/pmc_sq.log 2>&1
 timeout 600 python tools/precision_report.py > gpurun_out/final/precision_report.json 2> gpurun_out/final/precision_report.log
@@ -31,5 +35,6 @@ timeout 300 python tools/host_path_rate.py > gpurun_out/final/host_path.log 2>&1
 python tools/bench_fallback.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/fallback.log
 (python tools/bench_shapes.py; python tools/bench_shapes.py m16; python tools/bench_shapes.py sources; python tools/bench_shapes.py gate) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/shapes.log
 timeout 300 python tools/stream_latency.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/stream_latency.log
+fi
 tail -c 300 gpurun_out/final/bench_driver_cmd.json
 cat gpurun_out/final/kernel_stats_driver_cmd.csv
