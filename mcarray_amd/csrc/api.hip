@@ -40,6 +40,7 @@ struct Knobs {
     // product
     bool fb_enabled = true;            // MCA_HIP_ADAPT_FALLBACK=0 / cfg.adaptive_fallback = OFF
     long long adapt_min_rows = 4096;   // MCA_HIP_ADAPT_MIN_ROWS / cfg.adaptive_min_rows
+    int repair_items = 768;            // (measurement) MCA_HIP_REPAIR_ITEMS: work items above which the repair contraction halves its K split (0: never)
     int adapt_max_sources = 1;         // MCA_HIP_ADAPT_MAX_SOURCES / cfg.adaptive_max_sources
     double tau_scale = 1.0;            // MCA_HIP_ADAPT_TAU_SCALE (tools/adaptive_check.py: 1e9 turns the repair off to measure the coarse error)
     long long ws_max_bytes = 4LL << 30;   // MCA_HIP_WS_MAX_MB: A-operand workspace budget per slice of frames (tests force the sliced path)
@@ -234,6 +235,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.scan_carry = cfg.scan_carry != 0 || env_str("MCA_HIP_SCAN_CARRY") != nullptr;
     // measurement only: constants unless the library was built with -DMCA_MEASURE
     k.no_merge = measure_env("MCA_HIP_NO_MERGE") != nullptr;
+    k.repair_items = (int)geti(measure_env("MCA_HIP_REPAIR_ITEMS"), 768);
     k.stft_wg = measure_env("MCA_HIP_STFT_WG") != nullptr;
     k.bf_ola = measure_env("MCA_HIP_BF_OLA") != nullptr;
     k.bf_occ2 = measure_env("MCA_HIP_BF_OCC2") != nullptr;
@@ -566,7 +568,8 @@ void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
     }
 }
 
-// K segments of the repair contraction: by the shape of the (whole) call only.  The tails of every array -- REPAIR_WARM + 1 rows
+// K segments of the repair contraction AT MOST: by the shape of the (whole) call (a long list lowers the number on the device,
+// repair_ksplit_eff).  The tails of every array -- REPAIR_WARM + 1 rows
 // rounded up to repair units -- are always recomputed: a few arrays leave a few hundred rows, where 32 segments fill the chip;
 // 128 arrays leave thousands, where 32 partial maps per row cost more (k_repair_patch reads them all) than they buy.
 int repair_ksplit_for(const mca_hip_ctx *c, int n_arrays)
@@ -1357,14 +1360,14 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
             ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
             ga.n_list = c->ws().d_nlist; ga.list0 = (int)g0;
-            ga.repair_ksplit = repair_ksplit_for(c, n_arrays);
+            ga.repair_ksplit = repair_ksplit_for(c, n_arrays); ga.repair_items = c->kn.repair_items;
             const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
             const long long max_work = (pass_rows + 127) / 128 * col_tiles * ga.repair_ksplit;
             dim3 gg((unsigned)std::min<long long>(max_work, 768));
             if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
             else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
             RepairPatchArgs pp{};
-            pp.Cx = c->ws().d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit;
+            pp.Cx = c->ws().d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit; pp.items = ga.repair_items;
             pp.list = c->ws().d_list; pp.n_list = c->ws().d_nlist; pp.list0 = (int)g0; pp.groups_per_array = gpa; pp.need = c->ws().d_need;
             pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames; pp.Dp = c->Dp;
             hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);

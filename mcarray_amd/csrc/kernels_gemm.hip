@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_srp_gemm_repair(GemmArgs p)
     const int n_rows = min(p.rows, (*p.n_list - p.list0) * REPAIR_GROUP);
     if (n_rows <= 0) return;
     const int col_tiles = p.Dp / BN, row_tiles = (n_rows + G16_BM - 1) / G16_BM;
-    const int ksplit = p.repair_ksplit;
+    const int ksplit = repair_ksplit_eff(p.repair_ksplit, n_rows, p.Dp, p.repair_items);
     const long long plane_elems = repair_plane_stride(n_rows, p.Dp);
     const int n_work = row_tiles * col_tiles * ksplit;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(128) void k_repair_patch(RepairPatchArgs p)
 {
     const int n_here = min(*p.n_list - p.list0, p.pass_rows / REPAIR_GROUP);
     const int n_rows = n_here * REPAIR_GROUP;
-    const int planes_x = p.ksplit;
+    const int planes_x = repair_ksplit_eff(p.ksplit, n_rows, p.Dp, p.items);
     const long long plane_x_stride = repair_plane_stride(n_rows, p.Dp);
     const int n4 = p.Dp >> 2;                                            // Dp is a multiple of 64
     for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {

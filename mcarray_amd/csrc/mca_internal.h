@@ -94,7 +94,8 @@ struct GemmArgs {
     const void *Bt;          // fp16 steering table tiled for the 256 x 384 kernel: [plane][Kp/32][Dp][32] (a K stage of all columns is contiguous)
     // device-side row count (repair pass): rows = min(rows, (*n_list - list0) * REPAIR_GROUP); workgroups beyond it exit
     const int *n_list; int list0;
-    int repair_ksplit;       // K segments of k_srp_gemm_repair (shape-dependent, see REPAIR_KSPLIT_MAX)
+    int repair_ksplit;       // K segments of k_srp_gemm_repair at most (shape-dependent, see REPAIR_KSPLIT_MAX)
+    int repair_items;        // ... halved while the list gives more work items than this (repair_ksplit_eff; 0: never)
     // chunk-local scan result from the contraction's epilogue (256 x 384 kernel, one map, no gate, 32-row blocks = scan chunks):
     // part[arr][chunk][d] = sum_t scan_w[t] C[t][d] = the recursion E = 0.8f E + 0.2f C run from zero over the chunk's frames
     float *part; int *nvoiced; int D, n_chunks;
@@ -143,10 +144,23 @@ struct ScanPickArgs {
 constexpr int REPAIR_KSPLIT_MAX = 32;
 __host__ __device__ inline long long repair_plane_stride(int n_rows, int Dp) { return (long long)((n_rows + 127) / 128 * 128) * Dp; }
 __host__ __device__ inline long long repair_cx_rows(long long pass_rows, int ksplit) { return ((pass_rows + 127) / 128 * 128) * ksplit; }
+// K segments the repair contraction really uses for n_rows listed rows: the call's shape gives the most (repair_ksplit_for: enough to
+// fill the chip when only the tails are listed); a long list has the work items without cutting K that fine, and every halving
+// halves the partial maps that are written and read back -- halved until at most items_max items (row tile, column tile, segment)
+// are left.  The row count is the device's, so k_srp_gemm_repair and k_repair_patch both work it out from it.  (The exact rows' last
+// bits then depend on how many rows a call lists -- as they already do on the call's shape; tie-level)
+__host__ __device__ inline int repair_ksplit_eff(int ksplit, int n_rows, int Dp, int items_max)
+{
+    if (items_max <= 0) return ksplit;
+    const int tiles = ((n_rows + 127) / 128) * (Dp == 64 ? 1 : Dp / 192);
+    int k = ksplit;
+    while (k > 4 && tiles * k > items_max) k >>= 1;
+    return k;
+}
 
 struct RepairPatchArgs {
     const float *Cx;         // [repair_ksplit][repair_plane_stride] exact rows, split-K partial maps
-    int pass_rows, col_tiles, ksplit;
+    int pass_rows, col_tiles, ksplit, items;     // (ksplit, items: as GemmArgs::repair_ksplit, repair_items)
     const int *list; const int *n_list; int list0, groups_per_array;
     int *need;               // the groups' test-and-set words, released here
     float *C;                // [c_planes][arrays][n_frames][Dp]: plane 0 takes the exact row, the others zeros
