@@ -62,8 +62,16 @@ typedef enum {
                                 FP16X3's energies).  Picks that are TIES at that level -- two candidates, or a first difference
                                 against zero, closer than 1e-6 of the row's largest normalised energy: the bar of the parity tests
                                 -- may resolve differently from FP16X3 and between calls of different shapes.  Measured over 40
-                                random configurations / 696 320 frames: 61 picks on 43 frames differ from FP16X3, all 43 such ties
-                                (the same 61 / 43 with 24 rows instead of 16: profiles/r04_adaptive_check*.json). */
+                                random configurations / 696 320 frames: 41 picks on 29 frames differ from FP16X3, all 29 such ties
+                                (profiles/r04_adaptive_check.json; the warm-row count of 16 against 24: _warm24.json).
+                                OUTSIDE THE MODEL, in any precision: a frame in which a channel's DC or Nyquist bin -- the two real
+                                bins -- is at the rounding level of an fp32 transform (about one frame in 10^5 per 8 channels).
+                                PHAT keeps only the SIGN of such a bin, and no two implementations, the reference's double-precision
+                                one included, need agree on it; the frame's normalised energies then differ by up to
+                                2 (M - 1) / (30 P) x 0.2 between them, decaying 0.8 per frame.  With 16 microphones the coarse and
+                                the exact rows of this mode come from two kernels, so there such a frame is up to 1.9 tau off
+                                without being flagged (profiles/r04_case23_real_bin_at_rounding_level.log; with 4 and 8
+                                microphones both passes run the same transform and agree). */
 } mca_hip_srp_precision;
 
 /* Weighting of the generalised cross-correlation inside dsp::GeneralisedCrossCorrelation::calculateCorrelationsForPrecomputedTauMatrix
