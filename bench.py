@@ -49,7 +49,7 @@ def synth_batch(xs, seeds, n_frames, device, noise=0.01):
     theta = torch.empty(n_arrays, device=device, dtype=torch.float64)
     # channel rows are ROW_PAD floats longer than their (F + 1) * hop samples (the C ABI takes the strides): a row pitch of a power
     # of two plus a little -- 257 half frames = 2^19 + 2^11 bytes at 128 arrays x 256 frames -- lines the loads of all resident
-    # waves up on the same few HBM channels (k_beamform_wave 0.33 instead of 0.295 ms)
+    # waves up on the same few HBM channels (k_beamform_wave 0.33 instead of 0.295 ms; HISTORY.md)
     out = torch.zeros(n_arrays, n_mics, L + ROW_PAD, device=device, dtype=torch.float32)
     f = torch.fft.rfftfreq(L, d=1.0 / FS).to(device=device, dtype=torch.float64)
     for a in range(n_arrays):   # one array at a time keeps the fp64 temporaries small

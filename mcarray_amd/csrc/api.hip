@@ -55,7 +55,7 @@ struct Knobs {
 // Per-call workspace (everything a stream call allocates besides the per-array state, which lives in the context).  A call
 // can be worked off in pieces over a sub-range of its arrays -- the chunks of the host-pointer path -- with the per-array
 // state addressed at c->a0.  (Round 2 also split large device-pointer calls over 2-4 internal streams, "lanes"; measured 7 %
-// slower with two and 57 % slower with three on the bench shape, DESIGN.md section 5, so that code is gone.)
+// slower with two and 57 % slower with three on the bench shape, HISTORY.md, so that code is gone.)
 struct Workspace {
     void *d_A = nullptr; size_t a_bytes = 0;          // A operand: [rows][a_row_elems]
     void *d_Ax = nullptr; size_t ax_bytes = 0;        // ADAPTIVE: the two-plane A rows (repair pass, FP16X3 calls)

@@ -248,7 +248,7 @@ template __global__ void k_srp_gemm_f16<true, 64>(GemmArgs);
 // ---------------------------------------------------------------------------------------
 // The 256 x 384 contraction kernel for Dp == 384 (the 361-angle grid).  Measured on MI355X this contraction is
 // bound by operand delivery into LDS, not by the MFMA pipe (ablation of its 16-deep predecessor, ms per launch
-// of the bench shape: full 0.60, no MFMAs 0.43, no DMA 0.37).  The design goal is therefore
+// of the bench shape: full 0.60, no MFMAs 0.43, no DMA 0.37; HISTORY.md).  The design goal is therefore
 // the fewest operand bytes per CU, i.e. the largest output tile the register file can hold, and request shapes
 // the memory system likes:
 //   * a 256 x 384 output tile per workgroup (8 waves as 4 x 2, wave tile 64 x 192 = 2 x 6 MFMA tiles, 192
