@@ -849,7 +849,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     if (c->generic) {
         while ((1 << c->logH) < c->H) ++c->logH;
         if ((1 << c->logH) != c->H || c->N < 64) { c->stream_ok = false; c->stream_why = "the stream API needs a power-of-two fft_size >= 64 (the frame API takes any even size)"; }
-        else if ((size_t)(c->M + c->S) * (c->H + 1) * 8 + (size_t)c->S * c->H * 4 + 17 * c->S * 8 + 16 > 160 * 1024) {
+        else if ((size_t)(c->M + 1) * (c->H + 1) * 8 + (size_t)c->H * 4 + 17 * 8 + 16 > 160 * 1024) {      // (the beamformer takes the sources in passes if need be)
             c->stream_ok = false; c->stream_why = "fft_size x n_mics exceeds the 160 KiB LDS of a CU in the stream API (use the frame API)";
         }
     }
@@ -1536,11 +1536,23 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         return MCA_HIP_OK;
     }
     if (c->generic) {
-        const size_t smem = (size_t)(c->M + c->S) * (c->H + 1) * sizeof(float2) + (size_t)c->S * c->H * sizeof(float) + (size_t)(ba.ft + 1) * c->S * sizeof(double);
+        // all sources in one launch while M + S spectra (and the S carries) fit the 160 KiB of a CU; else as many per launch as do --
+        // 16 microphones at 2048-sample frames hold two -- each pass transforming the channels again
+        auto smem_for = [&](int s_pass) {
+            return (size_t)(c->M + s_pass) * (c->H + 1) * sizeof(float2) + (size_t)s_pass * c->H * sizeof(float) + (size_t)(ba.ft + 1) * s_pass * sizeof(double) + 8;
+        };
+        int s_pass = c->S;
+        while (s_pass > 1 && smem_for(s_pass) > 160 * 1024) --s_pass;
+        const size_t smem = smem_for(s_pass);
+        if (smem > 160 * 1024) return fail(c, MCA_HIP_ERR_UNSUPPORTED, "fft_size x n_mics exceeds the 160 KiB LDS of a CU");
         if (smem > 64 * 1024)
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_beamform_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         time_begin(c, MCA_HIP_K_BEAMFORM, st);
-        hipLaunchKernelGGL(k_beamform_gen, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(gen_threads(c, true)), smem, st, ba);
+        ba.S_all = c->S;
+        for (int s0 = 0; s0 < c->S; s0 += s_pass) {
+            ba.s0 = s0; ba.S = std::min(s_pass, c->S - s0);
+            hipLaunchKernelGGL(k_beamform_gen, dim3((n_frames + ba.ft - 1) / ba.ft, n_arrays), dim3(gen_threads(c, true)), smem, st, ba);
+        }
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
         return MCA_HIP_OK;

@@ -93,11 +93,14 @@ __global__ __launch_bounds__(1024) void k_beamform_gen(BeamformArgs p)
     const int t1 = min(t0 + p.ft, p.n_frames);
     const int tfirst = t0 > 0 ? t0 - 1 : 0;
 
+    // (S sources of this launch: numbers s0 ... s0 + S - 1 of the context's S_all -- one launch while M + S_all spectra fit the LDS)
+    const int SA = p.S_all, s0 = p.s0;
     for (int e = tid; e < (t1 - tfirst) * S; e += NT) {
-        const double doa = (double)p.doa_rad[((long long)a * p.n_frames + tfirst) * S + e];
+        const int r = e / S, s = e - r * S;
+        const double doa = (double)p.doa_rad[((long long)a * p.n_frames + tfirst + r) * SA + s0 + s];
         cdoa[e] = cos(doa + 1.57079632679489661923);                    // cos(DOA + M_PI/2), Beamformer.cpp:59
     }
-    for (int e = tid; e < S * H; e += NT) carry[e] = t0 == 0 ? p.tail_in[(long long)a * S * H + e] : 0.f;
+    for (int e = tid; e < S * H; e += NT) carry[e] = t0 == 0 ? p.tail_in[((long long)a * SA + s0) * H + e] : 0.f;
     __syncthreads();
 
     const float *base = p.pcm + (long long)a * p.array_stride;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(1024) void k_beamform_gen(BeamformArgs p)
             const float2 hi = ys[s * zs + (int)(__brev((unsigned)(n + H / 2)) >> (32 - logH))];
             float *cr = carry + s * H + 2 * n;
             if (t >= t0) {
-                float *o = p.out + ((long long)a * S + s) * (long long)p.n_frames * H + (long long)t * H + 2 * n;
+                float *o = p.out + ((long long)a * SA + s0 + s) * (long long)p.n_frames * H + (long long)t * H + 2 * n;
                 o[0] = cr[0] + lo.x * sc; o[1] = cr[1] + lo.y * sc;
             }
             cr[0] = hi.x * sc; cr[1] = hi.y * sc;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_beamform_gen(BeamformArgs p)
         __syncthreads();
     }
     if (t1 == p.n_frames)
-        for (int e = tid; e < S * H; e += NT) p.tail_out[(long long)a * S * H + e] = carry[e];
+        for (int e = tid; e < S * H; e += NT) p.tail_out[((long long)a * SA + s0) * H + e] = carry[e];
 }
 
 }  // namespace mca

@@ -202,6 +202,7 @@ struct BeamformArgs {
     // any-N kernel only (kernels_generic.hip)
     int N, logH;
     const float2 *tw;        // [N/2] exp(-j 2 pi i / N)
+    int S_all, s0;           // ... which takes the sources s0 ... s0 + S - 1 of S_all per launch (all at once while M + S spectra fit the LDS)
 };
 
 // wave-per-run delay-and-sum on the 1024-point complex transform (kernels_wave.hip): one source, any M <= 16

@@ -197,6 +197,29 @@ def test_masking_stream_other_frame_lengths(fs, N, method, alg):
     m.close()
 
 
+def test_sixteen_microphones_2048_sample_frames_several_sources_in_passes():
+    """M + S spectra of 1 025 bins do not fit the 160 KiB of a CU for S >= 3: the any-length beamformer then takes the sources
+    two at a time (the shapes the round-4 fuzz runs listed as refused).  Bins, energies and every source's audio against the
+    oracle; then the same stream in two calls (the per-source overlap-add carries go through the passes too)."""
+    fs, N, F, S = 96000, 2048, 14, 3
+    xs = synth.ULA16
+    pcm = sum(synth.noise_source_stream(xs, np.deg2rad(th), fs, (F + 1) * N // 2, 50 + i) for i, th in enumerate((-48.0, 7.0, 52.0)))
+    ctx = api.Context(fs, xs, N, 5.0, S)
+    r = ctx.process_frames_host(pcm[None], want_energy=True)
+    o = po.ssl_stream(fs, N, xs, pcm.astype(np.float64), S, 5.0, want_map=True)
+    _assert_bins(r["bin"][0], o["bin"], o["energy"], ctx.P, max_ties=2)
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+    if np.array_equal(r["bin"][0], o["bin"]):
+        assert np.abs(r["out"][0] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+    ctx = api.Context(fs, xs, N, 5.0, S)
+    h, hop = 6, N // 2
+    ra = ctx.process_frames_host(pcm[None, :, :(h + 1) * hop]); rb = ctx.process_frames_host(pcm[None, :, h * hop:])
+    assert np.array_equal(np.concatenate([ra["bin"], rb["bin"]], axis=1), r["bin"])
+    np.testing.assert_allclose(np.concatenate([ra["out"], rb["out"]], axis=2), r["out"], rtol=0, atol=1e-6 * np.abs(r["out"]).max())
+    ctx.close()
+
+
 def test_unsupported_stream_sizes_say_why():
     ctx = api.Context(48000, synth.ULA8, 1000, 5.0, 1)             # even but not a power of two: frame API only
     with pytest.raises(api.MCArrayHipError, match="power-of-two"):
