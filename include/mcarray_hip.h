@@ -68,10 +68,10 @@ typedef enum {
                                 bins -- is at the rounding level of an fp32 transform (about one frame in 10^5 per 8 channels).
                                 PHAT keeps only the SIGN of such a bin, and no two implementations, the reference's double-precision
                                 one included, need agree on it; the frame's normalised energies then differ by up to
-                                2 (M - 1) / (30 P) x 0.2 between them, decaying 0.8 per frame.  With 16 microphones the coarse and
-                                the exact rows of this mode come from two kernels, so there such a frame is up to 1.9 tau off
-                                without being flagged (profiles/r04_case23_real_bin_at_rounding_level.log; with 4 and 8
-                                microphones both passes run the same transform and agree). */
+                                2 (M - 1) / (30 P) x 0.2 between them, decaying 0.8 per frame.  Inside this mode the coarse and the
+                                exact pass agree on such a bin: with 4 and 8 microphones both run the same transform; with 16 they
+                                are two kernels, so the coarse one marks the frame and it is repaired with its six successors
+                                whatever the map says (profiles/r04_case23_real_bin_at_rounding_level.log). */
 } mca_hip_srp_precision;
 
 /* Weighting of the generalised cross-correlation inside dsp::GeneralisedCrossCorrelation::calculateCorrelationsForPrecomputedTauMatrix

@@ -70,13 +70,14 @@ struct Workspace {
     float *d_power = nullptr; unsigned char *d_voiced = nullptr; float *d_power_out = nullptr; size_t gate_frames = 0;
     // ADAPTIVE: flags, repair list
     unsigned char *d_flags = nullptr; int *d_chunk_from = nullptr, *d_list = nullptr, *d_need = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
+    unsigned char *d_unsure = nullptr;                // 16 microphones: frames whose DC / Nyquist bin the coarse analysis could not vouch for (StftPhatArgs::unsure)
     int *d_nlist = nullptr, *d_last_vchunk = nullptr; size_t lastv_arrays = 0;
     int last_a0 = 0, last_arrays = 0;                 // the arrays this lane ran in the last call (mca_hip_copy_gate)
     void release()
     {
         auto F = [](void *q) { if (q) (void)hipFree(q); };
         F(d_A); F(d_Ax); F(d_C); F(d_Cx); F(d_part); F(d_estart); F(d_nv); F(d_power); F(d_voiced); F(d_power_out);
-        F(d_flags); F(d_chunk_from); F(d_list); F(d_need); F(d_nlist); F(d_last_vchunk);
+        F(d_flags); F(d_chunk_from); F(d_list); F(d_need); F(d_nlist); F(d_last_vchunk); F(d_unsure);
         *this = Workspace();
     }
 };
@@ -600,6 +601,9 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
         if (c->ws().d_flags) (void)hipFree(c->ws().d_flags);
         c->ws().d_flags = nullptr; c->ws().adapt_frames = 0;
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_flags, nf));
+        if (c->ws().d_unsure) (void)hipFree(c->ws().d_unsure);
+        c->ws().d_unsure = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_unsure, nf));
         c->ws().adapt_frames = nf; ++c->ws_gen;
     }
     if (nc > c->ws().adapt_chunks) {
@@ -663,6 +667,12 @@ static float exact_reciprocal(float d)
     return best;
 }
 
+// the coarse (one fp16 plane) analysis of a 16-microphone uniform linear array runs on k_stft_phat_wave16
+static bool wave16_applies(const mca_hip_ctx *c)
+{
+    return c->M == 16 && c->ula && !c->generic && c->cfg.gcc_weighting != MCA_HIP_GCC_NONE && !c->kn.stft_wg;
+}
+
 template <typename OutT>
 int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, hipStream_t st)
 {
@@ -670,12 +680,12 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
     // a 16-microphone uniform linear array, one fp16 operand plane (the ADAPTIVE coarse pass, plain FP16): the wave-per-run kernel
     // with its whitened spectra packed to fp16 (k_stft_phat_wave16); the exact rows of such an array stay on k_stft_phat<16>
     if constexpr (sizeof(OutT) == 2) {
-        if (M == 16 && ula && a.a_planes == 1 && !a.list && !a.no_phat && !c->kn.stft_wg) {
+        if (wave16_applies(c) && a.a_planes == 1 && !a.list) {
             StftPhatArgs w = a;
             w.fpb = 16;
             while (w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
             const dim3 gw(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
-            const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 4 * w.fpb * 8) * sizeof(float2) + 1024 * sizeof(float);
+            const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 2 * 4 * w.fpb * 8) * sizeof(float2) + (1024 + 4 * w.fpb) * sizeof(float);   // (+ the scales and DC marks of unsure frames)
             if (a.power) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_wave16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw));
                 hipLaunchKernelGGL(k_stft_phat_wave16<true>, gw, dim3(256), smw, st, w);
@@ -1153,6 +1163,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         if (c->merged && c->a_planes == 1) { sa.mrank = c->d_mrank; sa.n_merged = c->n_merged; }
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         sa.no_phat = c->cfg.gcc_weighting == MCA_HIP_GCC_NONE ? 1 : 0;
+        if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 1 && wave16_applies(c)) sa.unsure = c->ws().d_unsure;   // (adaptive coarse pass)
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         if (c->n512) {
             // 512-sample frames: two frames of up to 8 channels per pass on the wave-level transform
@@ -1301,6 +1312,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     if (adaptive) {
         pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
         pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_from = c->ws().d_chunk_from; pa.last_vchunk = c->ws().d_last_vchunk; pa.stats = c->d_rstats;
+        pa.unsure = wave16_applies(c) ? c->ws().d_unsure : nullptr;
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
             c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;

@@ -621,6 +621,13 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
         // the batch's frames that passed the power gate (all without it), one bit each: every wave works the mask out for itself
         // from one byte per lane (a load of vc[t] inside the recursion made every step of it a round trip to memory)
         const unsigned vmask = (unsigned)__ballot(lane < 32 && ts + (lane & 31) < te && (!vc || vc[ts + (lane & 31)] != 0));
+        // MODE 1: frames the coarse analysis marked unsure (StftPhatArgs::unsure) are repaired with their six successors (0.8^7 of their
+        // error is left after those): bit i of um = frame ts - 6 + i
+        unsigned long long um = 0;
+        if (MODE == 1 && p.unsure) {
+            const int u = ts - 6 + lane;
+            um = __ballot(lane < SCAN_SUB + 6 && u >= 0 && u < te && p.unsure[(long long)a * p.n_frames + u] != 0);
+        }
         if (act) {
             auto load_rows = [&](float (&c8)[SCAN_LD], int t0) {
                 if (p.c_planes == 1) {
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
 #else
             const bool sens = wave_pick_pl<MODE == 1, PL>(sEn + tl * Dl, D, S, p.tau, s_bin + tl * MCA_MAX_SOURCES, s_val + tl * MCA_MAX_SOURCES, lane);
 #endif
-            if (MODE == 1 && lane == 0 && (sens || t == t_force)) atomicOr(&s_flagmask, 1u << tl);
+            if (MODE == 1 && lane == 0 && (sens || t == t_force || ((um >> tl) & 0x7full) != 0)) atomicOr(&s_flagmask, 1u << tl);
         }
         __syncthreads();
         // the batch's outputs, one thread per (frame, source)

@@ -688,6 +688,10 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
     float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
     float *wtab = reinterpret_cast<float *>(tab + F1K_TWORDS + 4 * F1K_SCRATCH);   // [64 lanes][16]: the lane's window samples w[lane + 64 i]
     float2 *nyq = reinterpret_cast<float2 *>(wtab + 1024) + wave * (p.fpb * NP);  // [fpb][NP] Z_p[512] of the run's frames
+    // (unsure frames, see StftPhatArgs: per frame and pair the power of bin 64 as the scale, per frame whether a DC bin fell below it)
+    float2 *nref = reinterpret_cast<float2 *>(wtab + 1024) + 4 * (p.fpb * NP) + wave * (p.fpb * NP);
+    float *dcbad = reinterpret_cast<float *>(reinterpret_cast<float2 *>(wtab + 1024) + 8 * (p.fpb * NP)) + wave * p.fpb;
+    constexpr float UNSURE = 1e-10f;                                               // power ratio: 1e-5 of the amplitude of bin 64
     for (int e = tid; e < 1024; e += 256) wtab[(e & 63) * 16 + (e >> 6)] = p.window[e];
     f1k_table_init(tab, tid, 256);
     F1kLane lc;
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
         const int f = frame_of(fi);
         h2 Xh[MT][8];
         v2f ptime = {0.f, 0.f};
+        bool dc_unsure = false;                                                    // (lane 0's: it holds bin 0)
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             float2 z[16];
@@ -762,6 +767,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
                     swap_rows32(u.y, w.y); swap_rows32(w.y, u.y);
                 }
             }
+            float pw0a = 0.f, pw0b = 0.f;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const float2 zk = z[dr16(s)], zm = z[dr16(15 - s < 12 ? 15 - s + 4 : 15 - s - 4)];
@@ -772,8 +778,14 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
                 const float2_t va = {wa.x, wa.y}, vb = {wb.x, wb.y};
                 Xh[2 * pr][s] = __builtin_convertvector(va, h2);
                 Xh[2 * pr + 1][s] = __builtin_convertvector(vb, h2);
+                if (s == 0) { pw0a = pwa; pw0b = pwb; }
+                if (s == 1 && p.unsure && lane == 0) {                             // lane 0: bin 0 (s = 0) against bin 64 (s = 1)
+                    nref[(f - f_begin) * NP + pr] = make_float2(pwa, pwb);
+                    dc_unsure = dc_unsure || (pw0a < UNSURE * pwa) || (pw0b < UNSURE * pwb);
+                }
             }
         }
+        if (p.unsure && lane == 0) dcbad[f - f_begin] = dc_unsure ? 1.f : 0.f;
         _Float16 *arow = reinterpret_cast<_Float16 *>(p.A) + (row_base + f) * (long long)p.a_row_elems;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -809,6 +821,15 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
             float pw;
             xn[2 * pr] = whiten4<false>(make_float2(2.f * n.x, 0.f), pw);
             xn[2 * pr + 1] = whiten4<false>(make_float2(2.f * n.y, 0.f), pw);
+        }
+        if (p.unsure) {
+            bool u = dcbad[lane] != 0.f;
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const float2 n = nyq[lane * NP + pr], r = nref[lane * NP + pr];       // (n is X, the scale |2 X|^2)
+                u = u || (4.f * n.x * n.x < UNSURE * r.x) || (4.f * n.y * n.y < UNSURE * r.y);
+            }
+            p.unsure[(long long)a * p.total_frames + p.frame0 + f_begin + lane] = u ? 1 : 0;
         }
         _Float16 *arow = reinterpret_cast<_Float16 *>(p.A) + (row_base + f_begin + lane) * (long long)p.a_row_elems;
         pair_products<MT, true>(xn, out);

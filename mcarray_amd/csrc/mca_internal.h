@@ -58,6 +58,10 @@ struct StftPhatArgs {
     const unsigned short *mrank; int n_merged;   // k_stft_phat_wave, merged index (ULA, one fp16 plane): rank of the product m = k (j - i)
                              // among the n_merged distinct ones, [(M - 1) * 512 + 1]; NULL: per-group index g * 513 + k
     int no_phat;             // 1: gcc_weighting NONE -- the pair products of the spectra themselves (k_stft_phat_wave, fp32 rows only)
+    unsigned char *unsure;   // k_stft_phat_wave16 in the adaptive coarse pass, else NULL: [arrays][total_frames] 1 = a channel's DC or Nyquist bin of this
+                             // frame is at the rounding level of the transform.  PHAT keeps only the SIGN of such a bin, and the exact rows of 16
+                             // microphones come from another kernel (k_stft_phat<16>) that need not round it the same way: k_scan_pick repairs the
+                             // frame and the six after it whatever the map says ("A limit of PHAT itself")
 };
 
 __device__ __forceinline__ void store_a(float *row, const StftPhatArgs &, int cidx, float2 v)
@@ -134,6 +138,7 @@ struct ScanPickArgs {
     unsigned long long probe_seq;
     int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
     unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
+    const unsigned char *unsure;  // [arrays][n_frames] or NULL: frames the coarse analysis could not vouch for (StftPhatArgs::unsure): flagged with their six successors
 };
 
 // The repair contraction runs on however many rows the coarse pass listed (a device-side count): the K range is what

@@ -284,3 +284,36 @@ def test_graph_of_a_new_shape_while_the_mode_is_suspended(monkeypatch):
     assert np.mean(b.cpu().numpy() != ref["bin"]) < 0.01
     assert np.abs(o.cpu().numpy() - ref["out"]).max() <= 1e-3 * np.abs(ref["out"]).max()     # (a flipped tie moves the steering by one bin)
     g.close(); ctx.close()
+
+
+def test_sixteen_microphones_repair_the_frames_whose_real_bins_are_at_rounding_level(force_small):
+    """PHAT keeps only the SIGN of a bin, and the DC and Nyquist bins are real: when one of them sits at the rounding level of the
+    transform, two implementations need not agree on it (seed 1 / case 23 of tools/adaptive_check.py).  With 16
+    microphones the coarse rows (k_stft_phat_wave16) and the exact rows (k_stft_phat<16>) come from two kernels, so the coarse
+    analysis marks such frames and k_scan_pick repairs them with their six successors whatever the map says.  Here the Nyquist bin of
+    one channel is cancelled in one frame; the frames around it must turn up in the repair statistics, and the bins stay FP16X3's."""
+    fs, N, F, hop = 48000, 1024, 512, 512
+    xs = synth.ULA16
+    pcm = synth.noise_source_stream(xs, np.deg2rad(31.0), fs, (F + 1) * hop, 77).astype(np.float64)
+    t0, ch = 300, 9
+    w = np.hanning(N + 1)[:N]                                             # (periodic Hann, as the library's window)
+    alt = (-1.0) ** np.arange(N)
+    seg = pcm[ch, t0 * hop:t0 * hop + N]
+    seg -= (alt * w * seg).sum() * alt * w / (w * w).sum()                # sum (-1)^n w[n] x[n] = 0: the frame's Nyquist bin
+    pcm32 = pcm.astype(np.float32)
+    X = np.fft.rfft(pcm32[ch, t0 * hop:t0 * hop + N].astype(np.float64) * w)
+    assert abs(X[N // 2]) < 1e-6 * np.abs(X).max()                        # (what float32 samples leave of it)
+    orig = synth.noise_source_stream(xs, np.deg2rad(31.0), fs, (F + 1) * hop, 77).astype(np.float32)
+
+    def run(x, prec):
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=prec)
+        ctx.reset_timing()
+        r = ctx.process_frames_host(x[None])
+        st = ctx.repair_stats() if prec == api.SRP_ADAPTIVE else None
+        ctx.close()
+        return r["bin"][0], st
+    b_plain, st_plain = run(orig, api.SRP_ADAPTIVE)
+    b_mod, st_mod = run(pcm32, api.SRP_ADAPTIVE)
+    b_x3, _ = run(pcm32, api.SRP_FP16X3)
+    assert st_mod["flagged"] >= st_plain["flagged"] + 5, (st_plain, st_mod)     # frames t0 ... t0 + 6, unless some were flagged anyway
+    assert np.array_equal(b_mod, b_x3)

@@ -75,3 +75,17 @@ print("channels 14 and 15 exchanged: error of the first frame %.3f tau" % float(
 x = base[0, 15, :1024].double().cpu().numpy(); w = np.hanning(1025)[:1024]
 X = np.fft.rfft(x * w)
 print("channel 15, frame 812: |X| min %.3e at bin %d, max %.3e; bins below 1e-4 of the max: %d" % (np.abs(X).min(), int(np.abs(X).argmin()), np.abs(X).max(), int((np.abs(X) < 1e-4 * np.abs(X).max()).sum())))
+
+# the adaptive mode on the same case: the coarse analysis marks the frame, k_scan_pick repairs it and its six successors
+os.environ["MCA_HIP_ADAPT_FALLBACK"] = "0"
+res = {}
+for name, prec in (("x3", api.SRP_FP16X3), ("adaptive", api.SRP_ADAPTIVE)):
+    ctx = api.Context(ac.FS, xs, ac.N, step, S, srp_precision=prec, max_arrays=A)
+    ctx.reset_timing()
+    res[name] = ac.run(ctx, pcm, F, S, 0)
+    if name == "adaptive":
+        print("adaptive repair statistics:", ctx.repair_stats())
+    ctx.close()
+err = (res["adaptive"][2] - res["x3"][2]).abs().amax(dim=2) / (30.0 * P) / tau
+print("adaptive vs x3 around array 1 frame 812 (max over directions, in tau):", [round(float(err[1, t]), 3) for t in range(808, 824)])
+print("bins equal:", bool((res["adaptive"][0] == res["x3"][0]).all()))
