@@ -167,7 +167,13 @@ def das_single_stream(pcm, theta, dev, stream, local_rank, calls):
     n1 = max(10, min(calls, 100))
     res = {"workload": "BASELINE configs[1]: 1 array (8-mic ULA), delay-and-sum only (localise = False), caller-given DOA %.2f deg, 48 kHz, N=1024" % np.degrees(ang),
            "algorithmic_bytes_per_frame": das_bytes}
+    check = {"pcm": p1[0, :, :(F1 + 1) * HOP].cpu().numpy(), "runs": {}}
     for key, kw, r_ in (("offline_any_angle", dict(bins_are_grid=False), rad), ("offline_grid_angle", dict(bins_are_grid=True), grad)):
+        # one call from a fresh state, kept for the oracle comparison that follows the timed region (das_oracle_check)
+        c1.reset(stream)
+        c1.process_frames_dev(p1, F1, gbin, r_, None, None, out, stream=stream, localise=False, separate=True, **kw)
+        torch.cuda.synchronize()
+        check["runs"][key] = (out[0, 0].cpu().numpy().copy(), r_[0, :, 0].cpu().numpy().astype(np.float64))
         e = timed_loop(lambda: c1.process_frames_dev(p1, F1, gbin, r_, None, None, out, stream=stream, localise=False, separate=True, **kw),
                        lambda: None, n1, 5, False, None, dev)
         fps = F1 * n1 / e
@@ -200,10 +206,30 @@ def das_single_stream(pcm, theta, dev, stream, local_rank, calls):
                              "chunk_audio_ms": fch * HOP / FS * 1e3, "hbm_roofline_frac_back_to_back": fch * das_bytes / bb / 1e9 / HBM_PEAK_GBPS}
         g.close()
     res["graph_chunk_latency"] = lat
+    res["_check"] = check
     res["graph_chunk_latency_note"] = ("one separation-only HIP graph launch per chunk + torch.cuda.synchronize(), host clock, 200 chunks; a chunk of F frames "
                                       "carries F x 10.67 ms of audio; launch-bound (SURVEY 8d: config 2 is latency-, not bandwidth-bound)")
     c1.close()
     return res
+
+
+def das_oracle_check(das):
+    """configs[1] against the checker (after the timed region): the first call of a fresh context, all 936 frames, against the oracle's
+    delay-and-sum stream at the same angles (oracle/mca_oracle.c mca_or_das_stream: Beamformer.cpp:51-71 inside mcabeamf.cpp:77-122's loop)."""
+    from oracle import pyoracle as po
+    from mcarray_amd import synth
+    chk = das.pop("_check")
+    x = chk["pcm"].astype(np.float64)
+    for key, (got, ang) in chk["runs"].items():
+        t0 = time.perf_counter()
+        ref = po.das_stream(FS, NFFT, synth.ULA8, x, ang)
+        dt = time.perf_counter() - t0
+        err = float(np.abs(got - ref).max())
+        das[key]["oracle_check"] = {"max_abs_err": err, "of_peak": err / float(np.abs(ref).max()), "frames": len(ang), "tolerance_of_peak": 2e-5,
+                                    "ok": bool(err <= 2e-5 * np.abs(ref).max() + 1e-7),
+                                    "note": "GPU/oracle audio error on the sample: first call of a fresh context, every frame, fp32 GPU vs the fp64 oracle's "
+                                            "Beamformer stream at the same angles (tests/test_gpu_das_stream.py is the test of this)"}
+        das[key]["cpu_baseline"] = {"value": len(ang) / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "the same 936 frames, %.2f s" % dt}
 
 
 def repair_spread(args, dev, stream, local_rank, headline_ms):
@@ -444,6 +470,11 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
                 fps_all, dt_all, cores = cpu_baseline_all_cores(host, nfa)
                 cpu["all_cores"] = {"value": fps_all, "unit": "frames/s", "cores": cores,
                                     "sample": "one array per thread, %d frames each, %.1f s wall" % (nfa, dt_all)}
+        if das is not None:
+            if args.cpu_frames > 0:
+                das_oracle_check(das)
+            else:
+                das.pop("_check")
         if world == 1 and args.extras:
             # BASELINE configs[3] in the same record (its own bench line: --config mvdr)
             import copy

@@ -486,6 +486,29 @@ void mca_or_beamformer_process_frame(int fs, const double *xyz, int M, int ccs_l
     for (int i = 0; i < ccs_len; ++i) out[i] /= (double)M;                                   /* divC :70 */
 }
 
+/* The delay-and-sum stream of mcabeamf (src/programs/mcabeamf.cpp:77-122 feeds chunks to process(); the STFT engine calls the
+ * hook once per frame): Beamformer::processFrame at the caller's angle for that frame, then the engine's synthesis. */
+void mca_or_das_stream(int fs, int N, const double *xyz, int M, const double *pcm, long stride, int F,
+                       const double *doa_rad, double *tail_io, double *out_pcm)
+{
+    const int hop = N / 2, ccs = N + 2;
+    double *win = (double *)malloc(sizeof(double) * (size_t)N);
+    mca_or_hann_periodic(win, N);
+    double **fr = (double **)malloc(sizeof(double *) * (size_t)M);
+    for (int c = 0; c < M; ++c) fr[c] = (double *)malloc(sizeof(double) * (size_t)ccs);
+    double *Y = (double *)malloc(sizeof(double) * (size_t)ccs);
+    double *y = (double *)malloc(sizeof(double) * (size_t)N);
+    for (int t = 0; t < F; ++t) {
+        for (int c = 0; c < M; ++c) mca_or_stft_frame(pcm + (size_t)c * stride + (size_t)t * hop, win, N, fr[c]);
+        mca_or_beamformer_process_frame(fs, xyz, M, ccs, (const double *const *)fr, Y, doa_rad[t]);   /* Beamformer.cpp:51-71 */
+        mca_or_irfft_ccs(Y, N, y);
+        double *o = out_pcm + (size_t)t * hop;
+        for (int n = 0; n < hop; ++n) { o[n] = tail_io[n] + y[n]; tail_io[n] = y[n + hop]; }
+    }
+    for (int c = 0; c < M; ++c) free(fr[c]);
+    free(fr); free(win); free(Y); free(y);
+}
+
 /* ======================================================================= */
 /* BeamformingSeparationAndLocalisation                                     */
 /* ======================================================================= */

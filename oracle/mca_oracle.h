@@ -97,6 +97,13 @@ int mca_or_select_doa_fragile(const double *E, int D, int n_pairs, int n_sources
 /* ---- Beamformer: src/mcarray/Beamformer.cpp:51-71 ---------------------- */
 void mca_or_beamformer_process_frame(int fs, const double *xyz, int M, int fft_ccs_length,
                                      const double *const *frames, double *out, double DOA);
+/* The delay-and-sum stream at caller-given angles (BASELINE configs[1]): the loop of src/programs/mcabeamf.cpp:77-122 around a
+ * dsp::STFT whose per-frame hook calls Beamformer::processFrame (Beamformer.cpp:51-71) with doa_rad[t] -- analysis (Hann, hop N/2,
+ * [BUILD-DEFINES] SURVEY A.1), beamformer, inverse transform, overlap-add.  pcm: M rows of `stride` doubles, (F+1)*N/2 samples used;
+ * tail_io [N/2]: the overlap-add carry, read at entry and written at exit (zeros for a fresh stream; lets a stream be fed in calls).
+ * out_pcm [F*N/2]. */
+void mca_or_das_stream(int fs, int N, const double *xyz, int M, const double *pcm, long stride, int F,
+                       const double *doa_rad, double *tail_io, double *out_pcm);
 
 /* ---- BeamformingSeparationAndLocalisation:
  *      src/mcarray/BeamformingSeparationAndLocalisation.cpp:29-119 -------- */

@@ -87,6 +87,8 @@ def lib():
         L.mca_or_bsl_localise.restype = C.c_int
         L.mca_or_bsl_localise.argtypes = [C.c_void_p, C.POINTER(c_dp), c_dp, c_dp, c_dp]
         L.mca_or_bsl_separate.argtypes = [C.c_void_p, C.POINTER(c_dp)]
+        L.mca_or_das_stream.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, c_dp, C.c_long, C.c_int, c_dp, c_dp, c_dp]
+        L.mca_or_das_stream.restype = None
         L.mca_or_ssl_stream.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, c_dp, C.c_long,
                                         C.c_int, c_ip, c_dp, c_dp, c_dp, c_dp]
         L.mca_or_ssl_stream_w.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, C.c_long,
@@ -302,6 +304,24 @@ def beamformer_process_frame(fs, xyz, frames, doa):
     out = np.empty(ccs)
     rows = [frames[c] for c in range(M)]
     lib().mca_or_beamformer_process_frame(fs, _dp(a), M, ccs, _ptr_array(rows), _dp(out), float(doa))
+    return out
+
+
+def das_stream(fs, N, xyz, pcm, doa_rad, tail=None):
+    """The delay-and-sum stream at caller-given angles (mca_or_das_stream: mcabeamf.cpp:77-122 around Beamformer.cpp:51-71).
+    pcm [M][(F+1)*hop]; doa_rad scalar or [F]; tail [hop] is the overlap-add carry, updated in place (None: a fresh stream).
+    Returns out [F*hop]."""
+    a = _xyz(xyz)
+    pcm = np.ascontiguousarray(pcm, dtype=np.float64)
+    M, L = pcm.shape
+    hop = N // 2
+    F = L // hop - 1
+    doa = np.ascontiguousarray(np.broadcast_to(np.asarray(doa_rad, dtype=np.float64), (F,)))
+    if tail is None:
+        tail = np.zeros(hop)
+    assert tail.dtype == np.float64 and tail.shape == (hop,) and tail.flags["C_CONTIGUOUS"]
+    out = np.empty(F * hop)
+    lib().mca_or_das_stream(fs, N, _dp(a), M, _dp(pcm), L, F, _dp(doa), _dp(tail), _dp(out))
     return out
 
 

@@ -1,0 +1,109 @@
+"""BASELINE configs[1]: the delay-and-sum beamformer alone, as a stream at CALLER-GIVEN angles -- what the reference's mcabeamf does
+with a dsp::STFT whose per-frame hook calls mca::Beamformer::processFrame (src/programs/mcabeamf.cpp:77-122, Beamformer.cpp:51-71).
+The HIP path is mca_hip_separate_frames_dev (angles off the steering grid: k_beamform_ola / _gen) and
+mca_hip_separate_frames_bins_dev (grid angles: k_beamform_wave and its per-angle rows); the checker is the oracle's
+mca_or_das_stream (the same analysis, Beamformer::processFrame in double, inverse transform, overlap-add).  Audio within
+2e-5 * max|out| + 1e-7 (fp32 GPU against the fp64 oracle); the stream is fed in two calls so the overlap-add carries are covered."""
+import numpy as np
+import pytest
+
+from mcarray_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL_REL, TOL_ABS = 2e-5, 1e-7
+ULA4 = [0.05 * m for m in range(4)]
+
+
+def _gpu_das(ctx, pcm, doa_rad, splits, doa_bin=None):
+    """Feeds pcm [M][(F+1)*hop] in calls of `splits` frames each; doa_rad [F] float32.  doa_bin given: the grid-angle entry point."""
+    dev = torch.device("cuda:0")
+    hop = ctx.hop
+    M = pcm.shape[0]
+    got, t0 = [], 0
+    for Fc in splits:
+        chunk = torch.from_numpy(np.ascontiguousarray(pcm[None, :, t0 * hop:(t0 + Fc + 1) * hop])).to(dev)
+        rad = torch.from_numpy(np.ascontiguousarray(doa_rad[t0:t0 + Fc], dtype=np.float32).reshape(1, Fc, 1)).to(dev)
+        out = torch.full((1, 1, Fc * hop), float("nan"), dtype=torch.float32, device=dev)
+        if doa_bin is None:
+            ctx.process_frames_dev(chunk, Fc, None, rad, None, None, out, localise=False, separate=True)
+        else:
+            b = torch.from_numpy(np.ascontiguousarray(doa_bin[t0:t0 + Fc], dtype=np.int32).reshape(1, Fc, 1)).to(dev)
+            ctx.process_frames_dev(chunk, Fc, b, rad, None, None, out, localise=False, separate=True, bins_are_grid=True)
+        torch.cuda.synchronize()
+        got.append(out.cpu().numpy()[0, 0])
+        t0 += Fc
+    assert M == ctx.M
+    return np.concatenate(got)
+
+
+def _oracle_das(fs, N, xs, pcm, doa_rad, splits):
+    from oracle import pyoracle as po
+    hop = N // 2
+    tail = np.zeros(hop)
+    outs, t0 = [], 0
+    for Fc in splits:
+        outs.append(po.das_stream(fs, N, xs, pcm[:, t0 * hop:(t0 + Fc + 1) * hop].astype(np.float64), doa_rad[t0:t0 + Fc].astype(np.float64), tail))
+        t0 += Fc
+    return np.concatenate(outs)
+
+
+def _err(got, ref):
+    return float(np.abs(got - ref).max()), float(TOL_REL * np.abs(ref).max() + TOL_ABS)
+
+
+CASES = [
+    # name, mic x positions, fft size, frames per call
+    ("ULA8_936", synth.ULA8, 1024, (500, 436)),            # configs[1]: 8 mics, 48 kHz, 1024-pt, 10 s = 936 frames, in two calls
+    ("ULA16", synth.ULA16, 1024, (70, 58)),
+    ("ULA4", ULA4, 1024, (33, 95)),
+    ("REEMC_2048", synth.REEM_C, 2048, (20, 21)),          # the dead beamformer test's array and frame length (test_mcarray.cpp:640-656)
+]
+
+
+@pytest.mark.parametrize("name,xs,N,splits", CASES, ids=[c[0] for c in CASES])
+def test_das_stream_off_grid_angle_matches_oracle(name, xs, N, splits):
+    """A fixed angle that is NOT on the 0.5 degree grid, as a user of mca::Beamformer passes it (any double)."""
+    fs, F = 48000, sum(splits)
+    pcm = synth.noise_source_stream(xs, np.deg2rad(-37.0), fs, (F + 1) * (N // 2), 2100 + len(xs))
+    ang = np.full(F, np.float32(np.deg2rad(-36.3)))
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
+    got = _gpu_das(ctx, pcm, ang, splits)
+    ref = _oracle_das(fs, N, xs, pcm, ang, splits)
+    e, tol = _err(got, ref)
+    assert e <= tol, (name, e, tol)
+    assert np.abs(ref).max() > 0.05           # a real signal came out
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,xs,N,splits", CASES[:3], ids=[c[0] for c in CASES[:3]])
+def test_das_stream_angle_changing_per_frame_matches_oracle(name, xs, N, splits):
+    """Off-grid angles that change from frame to frame (a tracked source): every frame steers with its own phasors."""
+    fs, F = 48000, sum(splits)
+    pcm = synth.noise_source_stream(xs, np.deg2rad(12.0), fs, (F + 1) * (N // 2), 2200 + len(xs))
+    ang = np.deg2rad(np.linspace(-71.3, 66.7, F)).astype(np.float32)
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
+    got = _gpu_das(ctx, pcm, ang, splits)
+    ref = _oracle_das(fs, N, xs, pcm, ang, splits)
+    e, tol = _err(got, ref)
+    assert e <= tol, (name, e, tol)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,xs,N,splits", CASES[:3], ids=[c[0] for c in CASES[:3]])
+def test_das_stream_grid_angles_match_oracle(name, xs, N, splits):
+    """bins_are_grid: the caller passes grid bins and their angles (the localiser's picks, or any grid index) --
+    mca_hip_separate_frames_bins_dev, k_beamform_wave with the per-angle rows T[bin]."""
+    fs, F = 48000, sum(splits)
+    pcm = synth.noise_source_stream(xs, np.deg2rad(40.0), fs, (F + 1) * (N // 2), 2300 + len(xs))
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
+    grid = ctx.doa_grid()
+    rng = np.random.default_rng(5)
+    bins = np.where(np.arange(F) % 7 == 0, rng.integers(1, ctx.D - 1, F), 261).astype(np.int32)    # mostly bin 261 (40.5 deg), jumps in between
+    ang = grid[bins].astype(np.float32)
+    got = _gpu_das(ctx, pcm, ang, splits, doa_bin=bins)
+    ref = _oracle_das(fs, N, xs, pcm, ang, splits)
+    e, tol = _err(got, ref)
+    assert e <= tol, (name, e, tol)
+    ctx.close()

@@ -102,14 +102,14 @@ def test_graph_survives_workspace_growth_and_context_destruction():
 def test_separation_only_graph_equals_the_eager_delay_and_sum_call():
     """doa_bin NULL (round 4): the graph records mca_hip_separate_frames_dev alone -- the delay-and-sum stream of the reference's
     mcabeamf (src/programs/mcabeamf.cpp:77-122, Beamformer.cpp:51-71) chunk by chunk at a caller-given angle; bit-identical to the
-    eager calls, overlap-add carried from chunk to chunk."""
+    eager calls, overlap-add carried from chunk to chunk, and equal to the ORACLE's delay-and-sum stream at that angle."""
     import torch
     from mcarray_amd import api, synth
     fs, N, Fc, n_chunks = 48000, 1024, 8, 5
     xs = synth.ULA8
     dev = torch.device("cuda:0")
     pcm = torch.from_numpy(synth.noise_source_stream(xs, np.deg2rad(-37.0), fs, (Fc * n_chunks + 1) * 512, 21)[None]).to(dev)
-    ang = float(np.deg2rad(-36.3))                      # not a grid angle
+    ang = float(np.float32(np.deg2rad(-36.3)))          # not a grid angle (the float the GPU call receives)
     outs = {}
     for mode in ("eager", "graph"):
         ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
@@ -131,12 +131,16 @@ def test_separation_only_graph_equals_the_eager_delay_and_sum_call():
             g.close()
         ctx.close()
     assert np.array_equal(outs["eager"], outs["graph"])
+    # the oracle's Beamformer stream at the same angle (mca_or_das_stream: Beamformer.cpp:51-71 inside the loop of mcabeamf.cpp:77-122)
     from oracle import pyoracle as po
-    # the oracle's Beamformer stream at the same angle
-    ref = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
+    ref = po.das_stream(fs, N, xs, pcm[0].cpu().numpy().astype(np.float64), ang)
+    assert np.abs(outs["graph"][0, 0] - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-7
+    # and one whole call over the same stream: the run boundaries differ, fp32 rounding only
+    whole_ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)
     whole = torch.empty(1, 1, Fc * n_chunks * 512, dtype=torch.float32, device=dev)
-    ref.process_frames_dev(pcm.contiguous(), Fc * n_chunks, None, torch.full((1, Fc * n_chunks, 1), ang, dtype=torch.float32, device=dev), None, None, whole,
-                           localise=False, separate=True)
+    whole_ctx.process_frames_dev(pcm.contiguous(), Fc * n_chunks, None, torch.full((1, Fc * n_chunks, 1), ang, dtype=torch.float32, device=dev), None, None, whole,
+                                 localise=False, separate=True)
     torch.cuda.synchronize()
-    assert np.abs(whole.cpu().numpy() - outs["graph"]).max() <= 2e-6 * np.abs(outs["graph"]).max() + 1e-9   # run boundaries differ: fp32 rounding only
-    ref.close()
+    assert np.abs(whole.cpu().numpy() - outs["graph"]).max() <= 2e-6 * np.abs(outs["graph"]).max() + 1e-9
+    assert np.abs(whole.cpu().numpy()[0, 0] - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-7
+    whole_ctx.close()

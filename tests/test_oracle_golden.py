@@ -199,3 +199,20 @@ def test_silent_input_is_finite():
     r = po.ssl_stream(fs, N, synth.REEM_C, pcm, 1, 5.0, want_map=True)
     assert np.all(np.isfinite(r["energy"])) and np.all(r["energy"] == 0)
     assert np.all(r["bin"] == 1) and np.all(r["out"] == 0)
+
+
+def test_das_stream_is_the_separation_half_of_the_ssl_stream():
+    """mca_or_das_stream (mcabeamf.cpp:77-122 around Beamformer.cpp:51-71) at the angles the localiser picked reproduces the
+    audio of the whole SourceSeparationAndLocalisation stream exactly, and feeding the stream in two calls (overlap-add carry
+    handed over) changes nothing."""
+    from mcarray_amd import synth
+    fs, N, F = 48000, 1024, 24
+    xs = synth.REEM_C
+    pcm = synth.noise_source_stream(xs, np.deg2rad(20.0), fs, (F + 1) * N // 2, 3).astype(np.float64)
+    o = po.ssl_stream(fs, N, xs, pcm, 1, 5.0)
+    d = po.das_stream(fs, N, xs, pcm, o["doa"][:, 0])
+    assert np.array_equal(d, o["out"][0])
+    tail = np.zeros(N // 2)
+    a = po.das_stream(fs, N, xs, pcm[:, :(10 + 1) * 512], o["doa"][:10, 0], tail)
+    b = po.das_stream(fs, N, xs, pcm[:, 10 * 512:], o["doa"][10:, 0], tail)
+    assert np.array_equal(np.concatenate([a, b]), d)
