@@ -50,6 +50,8 @@ struct Knobs {
     bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
+    bool no_dyn = false;               // MCA_HIP_NO_DYN: k_stft_phat_wave with one static run per wave (round 4) instead of the run queue
+    int dyn_len0 = 0;                  // MCA_HIP_DYN_LEN0: length of the first (longest) runs of the queue (0: half a wave's share, at most 16)
 };
 
 // Per-call workspace (everything a stream call allocates besides the per-array state, which lives in the context).  A call
@@ -134,6 +136,8 @@ struct mca_hip_ctx {
     // adaptive SRP precision: fp16 coarse scan (one plane) + exact repair (hi + lo planes)
     int tab_planes = 1;            // planes of the steering tables (2: FP16X3 and ADAPTIVE)
     unsigned long long *d_rstats = nullptr;
+    unsigned *d_queue = nullptr;   // [16] run-queue words of the wave-per-run kernels (StftPhatArgs::queue), zero between launches
+    int n_cu = 256;
     unsigned long long adapt_frames_total = 0;
     float tau_en = 0.f;            // normalised energies closer than this cannot be ordered from the coarse map
     // ADAPTIVE backs off to plain FP16X3 (the arithmetic its repair pass reproduces) while most rows need the repair -- noise
@@ -204,7 +208,7 @@ void free_ctx(mca_hip_ctx *c)
     F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt); F(c->d_bftab); F(c->d_Bm); F(c->d_Btm); F(c->d_mrank);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
-    F(c->d_rstats); F(c->d_gate_state);
+    F(c->d_rstats); F(c->d_gate_state); F(c->d_queue);
     if (c->h_probe) (void)hipHostFree(c->h_probe);
     for (Workspace &w : c->lanes) w.release();
     for (auto &e : c->io_ev) if (e) (void)hipEventDestroy(e);
@@ -253,6 +257,8 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.repair_ksplit = (int)geti(measure_env("MCA_HIP_REPAIR_KSPLIT"), 0);
     k.v2_min_rows = (int)geti(measure_env("MCA_HIP_V2_MIN_ROWS"), 0);
     k.repick_grid = (int)geti(measure_env("MCA_HIP_REPICK_GRID"), 256);
+    k.no_dyn = measure_env("MCA_HIP_NO_DYN") != nullptr;
+    k.dyn_len0 = (int)geti(measure_env("MCA_HIP_DYN_LEN0"), 0);
     return k;
 }
 
@@ -708,6 +714,23 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
             while (!env && w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
             gw = dim3(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
         }
+        // Dynamic runs (round 5): with one static run per wave the kernel is exactly one round of resident waves, and the SIMDs whose
+        // waves are done wait for the slowest (SQ counters: the average wave lives 85 % of the kernel).  Large calls launch the resident
+        // set once -- two workgroups per CU -- and the waves take runs that get shorter towards the end off a device-side counter.
+        const int wg_per_cu = M == 4 ? 3 : 2;                                        // (by registers: 164 ... 175 / 233 ... 253)
+        const long long share = a.list ? 0 : (long long)grid.y * a.n_frames / ((long long)wg_per_cu * c->n_cu * 4);   // frames per wave
+        if (!a.list && !c->kn.no_dyn && !c->kn.spw_fpw && share >= 8 && a.n_frames >= 64) {
+            int len0 = c->kn.dyn_len0 > 0 ? c->kn.dyn_len0 : 16;
+            while (!c->kn.dyn_len0 && len0 > 1 && len0 > share / 2) len0 >>= 1;
+            w.queue = c->d_queue;
+            w.q_sh0 = 0;
+            while ((1 << (w.q_sh0 + 1)) <= len0) ++w.q_sh0;
+            w.q_arrays = (int)grid.y;
+            int t0, t1, t2, t3, t4;
+            w.q_total = dyn_run(0x7fffffff, a.n_frames, w.q_arrays, w.q_sh0, t0, t1, t2, t3, t4);
+            w.fpb = 1 << w.q_sh0;                                                          // (sizes the Nyquist slots of the unmerged kernels)
+            gw = dim3(wg_per_cu * c->n_cu, 1);
+        }
         const bool mg = w.mrank != nullptr && !a.list;
         const int nrank = 2 * (M - 1) * 64 * 4 + 8, regw = mg ? std::max(F1K_SCRATCH, (w.n_merged + 63) & ~63) : F1K_SCRATCH;
         // (the merged kernel keeps its Nyquist bins in registers: with its 15.5 KiB regions two workgroups just fit the 160 KiB of a CU)
@@ -841,6 +864,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
     mca_hip_ctx *c = new mca_hip_ctx();
     c->cfg = *cfg;
     c->kn = read_knobs(*cfg);
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->M = cfg->n_mics; c->S = cfg->n_sources; c->N = cfg->fft_size; c->K = c->N / 2 + 1; c->prec = cfg->srp_precision;
     c->xyz.assign(cfg->mic_xyz, cfg->mic_xyz + 3 * c->M);
     c->cfg.mic_xyz = nullptr;
@@ -945,7 +969,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
         (rc = zalloc((void **)&c->d_vdone[0], na * 8)) || (rc = zalloc((void **)&c->d_vdone[1], na * 8)) ||
         (rc = zalloc((void **)&c->d_silence, na * 4)) || (rc = zalloc((void **)&c->d_g2_post0, na * 4)) ||
-        (rc = zalloc((void **)&c->d_rstats, 16)) ||
+        (rc = zalloc((void **)&c->d_rstats, 16)) || (rc = zalloc((void **)&c->d_queue, 64)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;

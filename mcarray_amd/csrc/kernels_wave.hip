@@ -459,10 +459,24 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
 
     // regular mode: wave w of workgroup b takes the run of p.fpb frames number 4 b + w.  List mode (repair pass of the adaptive
     // SRP precision): workgroup b walks the listed groups of REPAIR_GROUP = 4 frames, wave w takes frame w of a group.
+    // Dynamic runs (p.queue; see StftPhatArgs): the wave takes its runs off the device-side counter; the request for the next run goes
+    // out at the top of a run's last frame and is read when the run is done.
     const int li_end = p.list ? min(n_list_now, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
-    for (int li = p.list ? p.list0 + (int)blockIdx.x : 0; li < li_end; li += li_step) {
+    unsigned rq = 0, rq_pending = 0;
+    if (p.queue) {
+        if (lane == 0) rq_pending = atomicAdd(p.queue, 1u);
+        rq = __builtin_amdgcn_readfirstlane(rq_pending);
+    }
+    for (int li = p.list ? p.list0 + (int)blockIdx.x : 0; p.queue ? rq < (unsigned)p.q_total : li < li_end; li += li_step) {
         int a = blockIdx.y;
         int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+        if (p.queue) {
+            int rr = 0, rpa = 1, f_first = 0, len = 1, f_last = 0;
+            dyn_run((int)rq, p.n_frames, p.q_arrays, p.q_sh0, rr, rpa, f_first, len, f_last);
+            a = __builtin_amdgcn_readfirstlane(rr / rpa);                     // (the division runs on the vector ALU: back to scalar registers, or every address below turns into vector code)
+            f_begin = f_first + (rr - a * rpa) * len;
+            f_end = min(f_begin + len, f_last);
+        }
         long long row_base = (long long)a * p.n_frames;     // A row of frame f = row_base + f
         if (p.list) {
             const int e = li == p.list0 + (int)blockIdx.x ? e_first : p.list[li];
@@ -471,7 +485,10 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
             row_base = (long long)(li - p.list0) * REPAIR_GROUP - g_begin;
             f_begin = g_begin + wave; f_end = min(f_begin + 1, p.n_frames);
         }
-        if (f_begin >= f_end) continue;
+        if (f_begin >= f_end) {
+            if (p.queue) break;                     // (cannot happen: every listed run holds a frame)
+            continue;
+        }
         const float *base = p.pcm + (long long)a * p.array_stride + lane;
         float xa[16], xb[16];
         auto load_pair = [&](int f, int pr) {
@@ -490,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         load_pair(frame_of(0), 0);
         for (int fi = 0; fi < nfr; ++fi) {
             const int f = frame_of(fi);
+            if (p.queue && fi == nfr - 1 && lane == 0) rq_pending = atomicAdd(p.queue, 1u);     // the next run: asked for a frame ahead of its use
             float2 Xh[MT][8], zn[NP];
             v2f ptime = {0.f, 0.f};                                                // POWER: sum of the squared windowed samples (Parseval)
 #pragma unroll
@@ -657,6 +675,12 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
             for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, 0u, g * KG + FFT_H, out[g], p.Kp);
         }
         wave_lds_fence();
+        if (p.queue) rq = __builtin_amdgcn_readfirstlane(rq_pending);
+    }
+    // the last wave to leave zeroes the counters (every wave has made its last request by then)
+    if (p.queue && lane == 0) {
+        __threadfence();
+        if (atomicAdd(p.queue + 1, 1u) == gridDim.x * gridDim.y * 4u - 1u) { p.queue[0] = 0u; p.queue[1] = 0u; }
     }
 }
 

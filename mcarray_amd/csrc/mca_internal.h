@@ -58,11 +58,34 @@ struct StftPhatArgs {
     const unsigned short *mrank; int n_merged;   // k_stft_phat_wave, merged index (ULA, one fp16 plane): rank of the product m = k (j - i)
                              // among the n_merged distinct ones, [(M - 1) * 512 + 1]; NULL: per-group index g * 513 + k
     int no_phat;             // 1: gcc_weighting NONE -- the pair products of the spectra themselves (k_stft_phat_wave, fp32 rows only)
+    // k_stft_phat_wave, dynamic runs (round 5): queue != NULL -- the grid is one resident wave set and every wave takes runs of frames off
+    // a device-side counter until none is left: queue[0] next run, queue[1] waves that have left (the last one zeroes both: the words
+    // are clean for the next launch, recorded graphs included).  The runs get shorter towards the end (dyn_run below: 8, 4, 2, 1 frames
+    // at the bench shape), so that the waves finish within about a frame of each other whatever their individual speed.
+    unsigned *queue;
+    int q_sh0, q_total, q_arrays;   // log2 of the first runs' length, number of runs, arrays of the launch
     unsigned char *unsure;   // k_stft_phat_wave16 in the adaptive coarse pass, else NULL: [arrays][total_frames] 1 = a channel's DC or Nyquist bin of this
                              // frame is at the rounding level of the transform.  PHAT keeps only the SIGN of such a bin, and the exact rows of 16
                              // microphones come from another kernel (k_stft_phat<16>) that need not round it the same way: k_scan_pick repairs the
                              // frame and the six after it whatever the map says ("A limit of PHAT itself")
 };
+
+// The run schedule of the dynamic mode, the same arithmetic on the host (the number of runs) and in the kernel (run r -> array, frames):
+// per array, half of the frames that are left go in runs of 2^sh frames, then sh drops by one; the last phase takes one frame at a
+// time.  Runs are numbered phase by phase, array-major inside a phase.  Shifts and multiplies only (scalar ALU) up to the one division
+// by the caller.  Returns the number of runs when r is past the end (a, f_begin, f_end untouched).
+__host__ __device__ inline int dyn_run(int r, int n_frames, int n_arrays, int sh0, int &rr, int &rpa, int &f_first, int &len, int &f_last)
+{
+    int f0 = 0, first = 0;
+    for (int sh = sh0; ; --sh) {
+        const bool lastph = sh <= 0;
+        const int nfr = lastph ? n_frames - f0 : (((n_frames - f0) >> 1) >> sh) << sh;
+        const int n = lastph ? nfr : nfr >> sh;
+        if (r >= first && r < first + n * n_arrays) { rr = r - first; rpa = n; f_first = f0; len = lastph ? 1 : 1 << sh; f_last = f0 + nfr; return -1; }
+        first += n * n_arrays; f0 += nfr;
+        if (lastph) return first;
+    }
+}
 
 __device__ __forceinline__ void store_a(float *row, const StftPhatArgs &, int cidx, float2 v)
 {

@@ -428,6 +428,64 @@ int mca_or_select_doa_fragile(const double *Ein, int D, int numPairs, int numOfS
     return fragile;
 }
 
+/* The same classifier with eps scaled by the LOCAL magnitude of what is compared (round 5): a first difference
+ * En[j+1] - En[j] is "within eps of zero" if |df| <= eps_rel * max(1, |En[j]|, |En[j+1]|); two candidate values tie if they are
+ * within eps_rel * max(1, |v1|, |v2|); a zero pick is open if a candidate lies within eps_rel (absolute: the values are near zero).
+ * For rows with max |En| <= 1 this IS the absolute bar; where En is large (it reaches K / 30) an fp32 pipeline resolves
+ * |En| * 6e-8, and only the comparisons that involve such values get the wider bar -- not every comparison of the row. */
+int mca_or_select_doa_fragile_local(const double *Ein, int D, int numPairs, int numOfSources, double eps_rel)
+{
+    if (D < 3) return 0;
+    double *E = (double *)malloc(sizeof(double) * (size_t)D);
+    double *df = (double *)malloc(sizeof(double) * (size_t)D);
+    double *de = (double *)malloc(sizeof(double) * (size_t)D);      /* the bar of df[j] */
+    double *fd = (double *)malloc(sizeof(double) * (size_t)D);
+    double *ff = (double *)malloc(sizeof(double) * (size_t)D);
+    double *sd = (double *)malloc(sizeof(double) * (size_t)D);
+    const double minEnergyInDOA = -15 * numPairs;
+    for (int i = 0; i < D; ++i) E[i] = (Ein[i] - minEnergyInDOA) / (-2 * minEnergyInDOA);
+    for (int i = 0; i < D - 1; ++i) {
+        df[i] = E[i + 1] - E[i]; fd[i] = (df[i] < 0.0) ? 1.0 : 0.0;
+        double m = fabs(E[i]) > fabs(E[i + 1]) ? fabs(E[i]) : fabs(E[i + 1]);
+        de[i] = eps_rel * (m > 1.0 ? m : 1.0);
+    }
+    median3(fd, ff, D - 1);
+    double zmin = 1e300;
+    int n_unc = 0;
+    double *uval = (double *)malloc(sizeof(double) * (size_t)D);    /* |E[i+1]| of the uncertain positions */
+    for (int i = 0; i < D - 2; ++i) {
+        sd[i] = (ff[i + 1] - ff[i]) * E[i + 1];
+        int unc = 0;
+        for (int c = -1; c <= 2; ++c) {
+            int j = i + c; if (j < 0) j = 0; if (j > D - 2) j = D - 2;
+            if (fabs(df[j]) <= de[j]) unc = 1;
+        }
+        const double ae = fabs(E[i + 1]);
+        if (unc) uval[n_unc++] = ae;
+        if (ff[i + 1] != ff[i] && ae < zmin) zmin = ae;
+    }
+    int fragile = 0;
+    double prev = 0.0, v_last = 0.0;
+    for (int s = 0; s < numOfSources + 1; ++s) {
+        double max = sd[0]; int maxIdx = 0;
+        for (int i = 1; i < D - 2; ++i) if (sd[i] > max) { max = sd[i]; maxIdx = i; }
+        sd[maxIdx] = 0;
+        double m = fabs(prev) > fabs(max) ? fabs(prev) : fabs(max);
+        if (s > 0 && prev > 0.0 && prev - max <= eps_rel * (m > 1.0 ? m : 1.0)) fragile = 1;           /* (a) */
+        prev = max;
+        if (s < numOfSources) v_last = max;
+    }
+    for (int u = 0; u < n_unc; ++u) {                                                                   /* (b) */
+        if (v_last > 0.0) {
+            double m = uval[u] > v_last ? uval[u] : v_last;
+            if (uval[u] >= v_last - eps_rel * (m > 1.0 ? m : 1.0)) fragile = 1;
+        } else fragile = 1;
+    }
+    if (v_last <= eps_rel && zmin <= eps_rel) fragile = 1;                                              /* (c) */
+    free(E); free(df); free(de); free(fd); free(ff); free(sd); free(uval);
+    return fragile;
+}
+
 void mca_or_steering_process_frame(mca_or_steering *s, const double *const *frames,
                                    double *DOA, double *prob, int *doa_bin, int numOfSources,
                                    double *energy_out, double *corr_out)

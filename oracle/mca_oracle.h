@@ -93,6 +93,8 @@ void mca_or_select_doa(const double *E, int D, int n_pairs, float step, int n_so
 /* 1 if perturbations of the normalised energies of up to eps/2 could change a pick (peak ties, sign-chain ties, zero picks):
  * the classifier of single- vs double-precision bin differences used by the tests; see mca_oracle.c */
 int mca_or_select_doa_fragile(const double *E, int D, int n_pairs, int n_sources, double eps);
+/* the same with eps relative to the LOCAL magnitude of every comparison: eps_rel * max(1, |values compared|) */
+int mca_or_select_doa_fragile_local(const double *E, int D, int n_pairs, int n_sources, double eps_rel);
 
 /* ---- Beamformer: src/mcarray/Beamformer.cpp:51-71 ---------------------- */
 void mca_or_beamformer_process_frame(int fs, const double *xyz, int M, int fft_ccs_length,

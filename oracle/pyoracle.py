@@ -80,6 +80,8 @@ def lib():
         L.mca_or_select_doa.argtypes = [c_dp, C.c_int, C.c_int, C.c_float, C.c_int, c_dp, c_dp, c_ip]
         L.mca_or_select_doa_fragile.restype = C.c_int
         L.mca_or_select_doa_fragile.argtypes = [c_dp, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.mca_or_select_doa_fragile_local.restype = C.c_int
+        L.mca_or_select_doa_fragile_local.argtypes = [c_dp, C.c_int, C.c_int, C.c_int, C.c_double]
         L.mca_or_beamformer_process_frame.argtypes = [C.c_int, c_dp, C.c_int, C.c_int, C.POINTER(c_dp), c_dp, C.c_double]
         L.mca_or_bsl_create.restype = C.c_void_p
         L.mca_or_bsl_create.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_double]
@@ -294,6 +296,12 @@ def select_doa_fragile(E, n_pairs, n_sources=1, eps=1e-6):
     energies (peak ties, sign-chain ties, zero picks): mca_or_select_doa_fragile."""
     E = np.ascontiguousarray(E, dtype=np.float64)
     return bool(lib().mca_or_select_doa_fragile(_dp(E), len(E), int(n_pairs), int(n_sources), float(eps)))
+
+
+def select_doa_fragile_local(E, n_pairs, n_sources=1, eps_rel=1e-6):
+    """mca_or_select_doa_fragile_local: the same classifier, every comparison at eps_rel x max(1, |values compared|)."""
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    return bool(lib().mca_or_select_doa_fragile_local(_dp(E), len(E), int(n_pairs), int(n_sources), float(eps_rel)))
 
 
 def beamformer_process_frame(fs, xyz, frames, doa):

@@ -2,8 +2,8 @@
 the CPU oracle and the committed golden vectors.  Run on the MI355X box with `-m gpu`.
 
 Tolerances (fp32 GPU vs fp64 oracle), written where they are used:
-  * DOA bin: bit-exact, except frames the oracle itself flags as fragile (mca_or_select_doa_fragile at 1e-6 of the row's
-    largest normalised energy: peak ties, sign-chain ties, zero picks -- tests/parity_helpers.py), which are counted and bounded.
+  * DOA bin: bit-exact, except frames the oracle itself flags as fragile (mca_or_select_doa_fragile_local at 1e-6 x max(1, |the
+    normalised energies compared|): peak ties, sign-chain ties, zero picks -- tests/parity_helpers.py), which are counted and bounded.
   * energy map E_t[d]: |gpu - oracle| <= TOL_E * max|E| with TOL_E = 2e-5 (fp32), 2e-5 (fp16x3), 2e-4 (fp16)
   * beamformed audio: |gpu - oracle| <= 2e-5 * max|out| + 1e-7
 """
@@ -981,11 +981,13 @@ def test_several_sources_share_the_forward_transforms(M, S, step):
     rb = ctx.process_frames_host(pcm[None, :, cut * 512:], want_energy=True)
     r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "out")}
     o = po.ssl_stream(fs, N, xs, pcm.astype(np.float64), S, step, want_map=True)
-    ties = _assert_bins(r["bin"][0], o["bin"], o["energy"], ctx.P, max_ties=3)
-    if not ties:
-        nout = o["out"].shape[0]                                # min(M, S) separated channels
-        assert nout == min(M, S)
-        assert np.abs(r["out"][0][:nout] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    _assert_bins(r["bin"][0], o["bin"], o["energy"], ctx.P, max_ties=3)
+    nout = o["out"].shape[0]                                    # min(M, S) separated channels
+    assert nout == min(M, S)
+    # every hop of every source whose bins agree (all of them unless a tie was counted above): never skipped as a whole
+    from parity_helpers import assert_audio_where_bins_agree
+    compared = assert_audio_where_bins_agree(r["out"][0][:nout], o["out"], r["bin"][0], o["bin"], 512)
+    assert compared >= nout * (F - 8)
     ctx.close()
 
 
@@ -1014,6 +1016,6 @@ def test_sixteen_microphone_wave_analysis_matches_oracle(gate):
     from parity_helpers import fragile
     for t in np.nonzero(r["bin"][0][:, 0] != o["bin"][:, 0])[0]:
         assert fragile(o["energy"][t], ctx.P, 1, 2e-4), "frame %d: gpu %d oracle %d" % (t, r["bin"][0][t, 0], o["bin"][t, 0])
-    if np.array_equal(r["bin"][0], o["bin"]):
-        assert np.abs(r["out"][0] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    from parity_helpers import assert_audio_where_bins_agree
+    assert_audio_where_bins_agree(r["out"][0], o["out"], r["bin"][0], o["bin"], 512)
     ctx.close()

@@ -55,3 +55,27 @@ def test_second_source_tie_and_zero_pick():
     assert po.select_doa_fragile(E, P, 2, 1e-6)
     flat = np.full(D, -15.0 * P + 30.0 * P * 0.5)          # no peak at all: every first difference is zero
     assert po.select_doa_fragile(flat, P, 1, 1e-6)
+
+
+def test_local_bar_is_the_absolute_bar_where_energies_are_small_and_relative_where_they_are_large():
+    """mca_or_select_doa_fragile_local (round 5): eps x max(1, |values compared|).  A near-tie of 3e-6 between two peaks of
+    normalised energy 5 is a tie (fp32 resolves 4.8e-7 there); the same 3e-6 between peaks of energy 0.6 is not, even when another
+    part of the row is large -- round 4's row-relative bar called that one a tie as well."""
+    from parity_helpers import row_eps
+    P, D = 28, 361
+    x = np.arange(D)
+
+    def row(h1, h2):
+        En = 0.1 + 1e-4 * x + h1 * np.exp(-0.5 * ((x - 100) / 6.0) ** 2) + (h2 - 0.015) * np.exp(-0.5 * ((x - 250) / 6.0) ** 2)   # (0.015: the slope's share at 250)
+        return En * 30.0 * P - 15.0 * P
+    hi = row(5.0, 5.0 - 3e-6)
+    assert not po.select_doa_fragile(hi, P, 1, 1e-6)            # absolute: pinned
+    assert po.select_doa_fragile_local(hi, P, 1, 1e-6)          # 3e-6 <= 1e-6 x 5
+    lo = row(0.5, 0.5 - 3e-6)
+    assert not po.select_doa_fragile_local(lo, P, 2, 1e-6) and not po.select_doa_fragile(lo, P, 2, 1e-6)
+    spike = lo.copy()
+    spike[5] = (17.0 * 30 - 15) * P                             # one large value on the slope: no candidate (median-3 removes a lone sign), but max |En| = 17
+    assert row_eps(spike, P) > 1e-5
+    assert po.select_doa_fragile(spike, P, 2, row_eps(spike, P))              # round 4's bar: the two 0.6 peaks tie (3e-6 < 1.7e-5)
+    assert not po.select_doa_fragile_local(spike, P, 2, 1e-6)                 # this bar: pinned (3e-6 between values of 0.6)
+    assert po.select_doa_fragile_local(row(0.5, 0.5 - 5e-7), P, 2, 1e-6)      # and 5e-7 is a tie under every bar
