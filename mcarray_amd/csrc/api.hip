@@ -50,7 +50,9 @@ struct Knobs {
     bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
-    bool no_dyn = false;               // MCA_HIP_NO_DYN: k_stft_phat_wave with one static run per wave (round 4) instead of the run queue
+    bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
+    bool dyn_flat = false;             // MCA_HIP_DYN_FLAT: every run of the queue has the first runs' length
+    const char *wave_clock = nullptr;  // MCA_HIP_WAVE_CLOCK=<file>: entry / exit clocks of every wave of the last k_stft_phat_wave launch, written at destruction
     int dyn_len0 = 0;                  // MCA_HIP_DYN_LEN0: length of the first (longest) runs of the queue (0: half a wave's share, at most 16)
 };
 
@@ -136,6 +138,7 @@ struct mca_hip_ctx {
     // adaptive SRP precision: fp16 coarse scan (one plane) + exact repair (hi + lo planes)
     int tab_planes = 1;            // planes of the steering tables (2: FP16X3 and ADAPTIVE)
     unsigned long long *d_rstats = nullptr;
+    unsigned long long *d_wave_clock = nullptr; int wave_clock_n = 0;   // (measurement) StftPhatArgs::wave_clock of the last regular launch
     unsigned *d_queue = nullptr;   // [16] run-queue words of the wave-per-run kernels (StftPhatArgs::queue), zero between launches
     int n_cu = 256;
     unsigned long long adapt_frames_total = 0;
@@ -204,6 +207,15 @@ double distance(const std::vector<double> &xyz, int i, int j)                   
 void free_ctx(mca_hip_ctx *c)
 {
     if (!c) return;
+    if (c->d_wave_clock && c->kn.wave_clock) {                      // (measurement builds only)
+        std::vector<unsigned long long> h(3 * (size_t)c->wave_clock_n);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), c->d_wave_clock, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = std::fopen(c->kn.wave_clock, "w")) {
+                for (int i = 0; i < c->wave_clock_n; ++i) std::fprintf(f, "%d %llu %llu %llu\n", i, h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+                std::fclose(f);
+            }
+        (void)hipFree(c->d_wave_clock);
+    }
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->d_window); F(c->d_tw); F(c->d_grid); F(c->d_delays); F(c->d_micx); F(c->d_pairs); F(c->d_B); F(c->d_Bt); F(c->d_bftab); F(c->d_Bm); F(c->d_Btm); F(c->d_mrank);
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
@@ -257,8 +269,10 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.repair_ksplit = (int)geti(measure_env("MCA_HIP_REPAIR_KSPLIT"), 0);
     k.v2_min_rows = (int)geti(measure_env("MCA_HIP_V2_MIN_ROWS"), 0);
     k.repick_grid = (int)geti(measure_env("MCA_HIP_REPICK_GRID"), 256);
-    k.no_dyn = measure_env("MCA_HIP_NO_DYN") != nullptr;
+    k.dyn = measure_env("MCA_HIP_DYN") != nullptr;
     k.dyn_len0 = (int)geti(measure_env("MCA_HIP_DYN_LEN0"), 0);
+    k.dyn_flat = measure_env("MCA_HIP_DYN_FLAT") != nullptr;
+    k.wave_clock = measure_env("MCA_HIP_WAVE_CLOCK");
     return k;
 }
 
@@ -714,12 +728,17 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
             while (!env && w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
             gw = dim3(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
         }
-        // Dynamic runs (round 5): with one static run per wave the kernel is exactly one round of resident waves, and the SIMDs whose
-        // waves are done wait for the slowest (SQ counters: the average wave lives 85 % of the kernel).  Large calls launch the resident
-        // set once -- two workgroups per CU -- and the waves take runs that get shorter towards the end off a device-side counter.
+        // Dynamic runs (round 5, measurement builds only: MCA_HIP_DYN).  With one static run per wave the kernel is exactly one round of
+        // resident waves and the average wave lives 85 % of the kernel (SQ counters), which looked like SIMDs waiting for the slowest wave.
+        // The waves' exit clocks (MCA_HIP_WAVE_CLOCK) say otherwise: the spread is not between waves of equal standing -- the FIRST workgroup
+        // of every CU (arrays 0..3 of the bench shape) is done at 180 us, the SECOND (arrays 4..7) at 244 us, 4 us apart inside a workgroup:
+        // the CU issues oldest-first, the younger workgroup gets what is left and then runs alone at 83 % of the two-wave rate
+        // (HISTORY.md section 8: one workgroup per CU).  Perfect balance is worth 11 of 290 us.  A queue of runs per WAVE (tickets in
+        // arrival order) costs more than that: waves of a workgroup no longer stream neighbouring frames, and the same 16-frame runs take
+        // 357 instead of 287 us; runs of 8 / 4 / 2 / 1 frames 357 / 343 / 375 / 515 us (profiles/r05_run_queue_negative.log).
         const int wg_per_cu = M == 4 ? 3 : 2;                                        // (by registers: 164 ... 175 / 233 ... 253)
         const long long share = a.list ? 0 : (long long)grid.y * a.n_frames / ((long long)wg_per_cu * c->n_cu * 4);   // frames per wave
-        if (!a.list && !c->kn.no_dyn && !c->kn.spw_fpw && share >= 8 && a.n_frames >= 64) {
+        if (!a.list && c->kn.dyn && !c->kn.spw_fpw && share >= 8 && a.n_frames >= 64) {
             int len0 = c->kn.dyn_len0 > 0 ? c->kn.dyn_len0 : 16;
             while (!c->kn.dyn_len0 && len0 > 1 && len0 > share / 2) len0 >>= 1;
             w.queue = c->d_queue;
@@ -727,9 +746,16 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
             while ((1 << (w.q_sh0 + 1)) <= len0) ++w.q_sh0;
             w.q_arrays = (int)grid.y;
             int t0, t1, t2, t3, t4;
-            w.q_total = dyn_run(0x7fffffff, a.n_frames, w.q_arrays, w.q_sh0, t0, t1, t2, t3, t4);
+            w.q_flat = c->kn.dyn_flat ? 1 : 0;
+            w.q_total = dyn_run(0x7fffffff, a.n_frames, w.q_arrays, w.q_sh0, t0, t1, t2, t3, t4, w.q_flat);
             w.fpb = 1 << w.q_sh0;                                                          // (sizes the Nyquist slots of the unmerged kernels)
             gw = dim3(wg_per_cu * c->n_cu, 1);
+        }
+        if (c->kn.wave_clock && !a.list) {
+            if (!c->d_wave_clock) HIP_TRY(c, hipMalloc((void **)&c->d_wave_clock, 3 * 8 * 16384));
+            HIP_TRY(c, hipMemsetAsync(c->d_wave_clock, 0, 3 * 8 * 16384, st));
+            c->wave_clock_n = std::min<int>(16384, (int)(gw.x * gw.y * 4));
+            if ((int)(gw.x * gw.y * 4) <= 16384) w.wave_clock = c->d_wave_clock;
         }
         const bool mg = w.mrank != nullptr && !a.list;
         const int nrank = 2 * (M - 1) * 64 * 4 + 8, regw = mg ? std::max(F1K_SCRATCH, (w.n_merged + 63) & ~63) : F1K_SCRATCH;

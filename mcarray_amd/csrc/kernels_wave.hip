@@ -463,6 +463,8 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
     // out at the top of a run's last frame and is read when the run is done.
     const int li_end = p.list ? min(n_list_now, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
     unsigned rq = 0, rq_pending = 0;
+    const unsigned long long clock_in = p.wave_clock ? wall_clock64() : 0ull;
+    int runs_taken = 0;
     if (p.queue) {
         if (lane == 0) rq_pending = atomicAdd(p.queue, 1u);
         rq = __builtin_amdgcn_readfirstlane(rq_pending);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
         if (p.queue) {
             int rr = 0, rpa = 1, f_first = 0, len = 1, f_last = 0;
-            dyn_run((int)rq, p.n_frames, p.q_arrays, p.q_sh0, rr, rpa, f_first, len, f_last);
+            dyn_run((int)rq, p.n_frames, p.q_arrays, p.q_sh0, rr, rpa, f_first, len, f_last, p.q_flat);
             a = __builtin_amdgcn_readfirstlane(rr / rpa);                     // (the division runs on the vector ALU: back to scalar registers, or every address below turns into vector code)
             f_begin = f_first + (rr - a * rpa) * len;
             f_end = min(f_begin + len, f_last);
@@ -676,6 +678,11 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         }
         wave_lds_fence();
         if (p.queue) rq = __builtin_amdgcn_readfirstlane(rq_pending);
+        ++runs_taken;
+    }
+    if (p.wave_clock && lane == 0) {
+        unsigned long long *wc = p.wave_clock + 3ull * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
+        wc[0] = clock_in; wc[1] = wall_clock64(); wc[2] = (unsigned long long)runs_taken;
     }
     // the last wave to leave zeroes the counters (every wave has made its last request by then)
     if (p.queue && lane == 0) {

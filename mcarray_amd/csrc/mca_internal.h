@@ -64,6 +64,8 @@ struct StftPhatArgs {
     // at the bench shape), so that the waves finish within about a frame of each other whatever their individual speed.
     unsigned *queue;
     int q_sh0, q_total, q_arrays;   // log2 of the first runs' length, number of runs, arrays of the launch
+    int q_flat;                     // (measurement) 1: every run has the first runs' length
+    unsigned long long *wave_clock; // (measurement, make MEASURE=1 + MCA_HIP_WAVE_CLOCK) [waves][3]: wall_clock64 at entry and exit, runs taken
     unsigned char *unsure;   // k_stft_phat_wave16 in the adaptive coarse pass, else NULL: [arrays][total_frames] 1 = a channel's DC or Nyquist bin of this
                              // frame is at the rounding level of the transform.  PHAT keeps only the SIGN of such a bin, and the exact rows of 16
                              // microphones come from another kernel (k_stft_phat<16>) that need not round it the same way: k_scan_pick repairs the
@@ -74,9 +76,14 @@ struct StftPhatArgs {
 // per array, half of the frames that are left go in runs of 2^sh frames, then sh drops by one; the last phase takes one frame at a
 // time.  Runs are numbered phase by phase, array-major inside a phase.  Shifts and multiplies only (scalar ALU) up to the one division
 // by the caller.  Returns the number of runs when r is past the end (a, f_begin, f_end untouched).
-__host__ __device__ inline int dyn_run(int r, int n_frames, int n_arrays, int sh0, int &rr, int &rpa, int &f_first, int &len, int &f_last)
+__host__ __device__ inline int dyn_run(int r, int n_frames, int n_arrays, int sh0, int &rr, int &rpa, int &f_first, int &len, int &f_last, int flat = 0)
 {
     int f0 = 0, first = 0;
+    if (flat) {
+        const int n = (n_frames + (1 << sh0) - 1) >> sh0;
+        if (r < n * n_arrays) { rr = r; rpa = n; f_first = 0; len = 1 << sh0; f_last = n_frames; return -1; }
+        return n * n_arrays;
+    }
     for (int sh = sh0; ; --sh) {
         const bool lastph = sh <= 0;
         const int nfr = lastph ? n_frames - f0 : (((n_frames - f0) >> 1) >> sh) << sh;
