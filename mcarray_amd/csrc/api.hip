@@ -51,6 +51,7 @@ struct Knobs {
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
     bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
+    bool spw_xcd = false;              // MCA_HIP_SPW_XCD: StftPhatArgs::xcd_map
     bool dyn_flat = false;             // MCA_HIP_DYN_FLAT: every run of the queue has the first runs' length
     const char *wave_clock = nullptr;  // MCA_HIP_WAVE_CLOCK=<file>: entry / exit clocks of every wave of the last k_stft_phat_wave launch, written at destruction
     int dyn_len0 = 0;                  // MCA_HIP_DYN_LEN0: length of the first (longest) runs of the queue (0: half a wave's share, at most 16)
@@ -272,6 +273,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.dyn = measure_env("MCA_HIP_DYN") != nullptr;
     k.dyn_len0 = (int)geti(measure_env("MCA_HIP_DYN_LEN0"), 0);
     k.dyn_flat = measure_env("MCA_HIP_DYN_FLAT") != nullptr;
+    k.spw_xcd = measure_env("MCA_HIP_SPW_XCD") != nullptr;
     k.wave_clock = measure_env("MCA_HIP_WAVE_CLOCK");
     return k;
 }
@@ -751,6 +753,7 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
             w.fpb = 1 << w.q_sh0;                                                          // (sizes the Nyquist slots of the unmerged kernels)
             gw = dim3(wg_per_cu * c->n_cu, 1);
         }
+        w.xcd_map = c->kn.spw_xcd ? 1 : 0;
         if (c->kn.wave_clock && !a.list) {
             if (!c->d_wave_clock) HIP_TRY(c, hipMalloc((void **)&c->d_wave_clock, 3 * 8 * 16384));
             HIP_TRY(c, hipMemsetAsync(c->d_wave_clock, 0, 3 * 8 * 16384, st));

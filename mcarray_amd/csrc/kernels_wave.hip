@@ -471,7 +471,9 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
     }
     for (int li = p.list ? p.list0 + (int)blockIdx.x : 0; p.queue ? rq < (unsigned)p.q_total : li < li_end; li += li_step) {
         int a = blockIdx.y;
-        int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+        // (measurement: xcd_map -- consecutive workgroups go to consecutive XCDs; give every XCD one contiguous piece of the array instead)
+        const int bxm = (p.xcd_map && (gridDim.x & 7) == 0) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        int f_begin = (bxm * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
         if (p.queue) {
             int rr = 0, rpa = 1, f_first = 0, len = 1, f_last = 0;
             dyn_run((int)rq, p.n_frames, p.q_arrays, p.q_sh0, rr, rpa, f_first, len, f_last, p.q_flat);

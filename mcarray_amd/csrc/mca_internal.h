@@ -65,6 +65,7 @@ struct StftPhatArgs {
     unsigned *queue;
     int q_sh0, q_total, q_arrays;   // log2 of the first runs' length, number of runs, arrays of the launch
     int q_flat;                     // (measurement) 1: every run has the first runs' length
+    int xcd_map;                    // (measurement) 1: workgroups of one XCD (linear id mod 8) take neighbouring runs of frames
     unsigned long long *wave_clock; // (measurement, make MEASURE=1 + MCA_HIP_WAVE_CLOCK) [waves][3]: wall_clock64 at entry and exit, runs taken
     unsigned char *unsure;   // k_stft_phat_wave16 in the adaptive coarse pass, else NULL: [arrays][total_frames] 1 = a channel's DC or Nyquist bin of this
                              // frame is at the rounding level of the transform.  PHAT keeps only the SIGN of such a bin, and the exact rows of 16

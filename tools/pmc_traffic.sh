@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of every mca:: kernel from rocprofv3 PMC counters, two separate passes (FETCH_SIZE costs 3 of the
 # 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots").  usage: tools/pmc_traffic.sh <precision> <outdir>
-prec=${1:-fp16x3}; out=${2:-gpurun_out/pmc_traffic}; extra=${3:-}       # extra: more bench.py flags, e.g. "--arrays 128 --frames 256"
+prec=${1:-fp16x3}; out=${2:-gpurun_out/pmc_traffic}; extra=${3:-}       # extra: more bench.py flags, e.g. "--arrays 128 --frames 256" or "--config mvdr"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -21,3 +21,5 @@ for ctr in ("FETCH_SIZE","WRITE_SIZE"):
 json.dump(res,open("$out/traffic_$prec.json","w"),indent=1)
 for k,v in res.items(): print(k[:60], {c:(round(x["sum"]/x["dispatches"],1), x["dispatches"]) for c,x in v.items()})
 PY
+# the raw rocprofv3 output stays on the box (gpurun merges at most 64 MiB back): the summaries above are what is kept
+rm -rf $out/FETCH_SIZE $out/WRITE_SIZE
