@@ -721,10 +721,12 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
     float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
     float *wtab = reinterpret_cast<float *>(tab + F1K_TWORDS + 4 * F1K_SCRATCH);   // [64 lanes][16]: the lane's window samples w[lane + 64 i]
     float2 *nyq = reinterpret_cast<float2 *>(wtab + 1024) + wave * (p.fpb * NP);  // [fpb][NP] Z_p[512] of the run's frames
-    // (unsure frames, see StftPhatArgs: per frame and pair the power of bin 64 as the scale, per frame whether a DC bin fell below it)
+    // (unsure frames, see StftPhatArgs: per frame and pair the channels' MEAN bin power as the scale -- Parseval: sum_n (w x)^2, wave-reduced;
+    // round 4 took the power of bin 64 alone, which a notch or a tone at 3 kHz makes arbitrarily small or large, ADVICE r4 --, per frame
+    // whether a DC bin fell below it)
     float2 *nref = reinterpret_cast<float2 *>(wtab + 1024) + 4 * (p.fpb * NP) + wave * (p.fpb * NP);
     float *dcbad = reinterpret_cast<float *>(reinterpret_cast<float2 *>(wtab + 1024) + 8 * (p.fpb * NP)) + wave * p.fpb;
-    constexpr float UNSURE = 1e-10f;                                               // power ratio: 1e-5 of the amplitude of bin 64
+    constexpr float UNSURE = 1e-10f;                                               // power ratio: 1e-5 of the channel's rms bin amplitude in this frame
     for (int e = tid; e < 1024; e += 256) wtab[(e & 63) * 16 + (e >> 6)] = p.window[e];
     f1k_table_init(tab, tid, 256);
     F1kLane lc;
@@ -772,9 +774,13 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
                 z[4 * i4] = win_lo(xa[4 * i4], xb[4 * i4], w01); z[4 * i4 + 1] = win_hi(xa[4 * i4 + 1], xb[4 * i4 + 1], w01);
                 z[4 * i4 + 2] = win_lo(xa[4 * i4 + 2], xb[4 * i4 + 2], w23); z[4 * i4 + 3] = win_hi(xa[4 * i4 + 3], xb[4 * i4 + 3], w23);
             }
-            if (POWER) {
+            float ref_a = 0.f, ref_b = 0.f;                                         // |2 X|^2 of an average bin of the two channels (p.unsure only)
+            if (POWER || p.unsure) {
+                v2f pz = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { const v2f zv = to_v2f(z[i]); asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(ptime) : "v"(zv)); }
+                for (int i = 0; i < 16; ++i) { const v2f zv = to_v2f(z[i]); asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(pz) : "v"(zv)); }
+                if (POWER) { ptime.x += pz.x; ptime.y += pz.y; }
+                if (p.unsure) { ref_a = 4.f * wave_sum64(pz.x); ref_b = 4.f * wave_sum64(pz.y); }
             }
             fft1024c<false, 3>(z, buf, lane, tab, lc, [&]() {
                 const bool lastp = pr == NP - 1, last = lastp && fi + 1 >= nfr;
@@ -812,9 +818,9 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
                 Xh[2 * pr][s] = __builtin_convertvector(va, h2);
                 Xh[2 * pr + 1][s] = __builtin_convertvector(vb, h2);
                 if (s == 0) { pw0a = pwa; pw0b = pwb; }
-                if (s == 1 && p.unsure && lane == 0) {                             // lane 0: bin 0 (s = 0) against bin 64 (s = 1)
-                    nref[(f - f_begin) * NP + pr] = make_float2(pwa, pwb);
-                    dc_unsure = dc_unsure || (pw0a < UNSURE * pwa) || (pw0b < UNSURE * pwb);
+                if (s == 0 && p.unsure && lane == 0) {                             // lane 0 holds bin 0: against the channel's mean bin power
+                    nref[(f - f_begin) * NP + pr] = make_float2(ref_a, ref_b);
+                    dc_unsure = dc_unsure || (pw0a < UNSURE * ref_a) || (pw0b < UNSURE * ref_b);
                 }
             }
         }
