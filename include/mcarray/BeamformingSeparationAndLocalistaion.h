@@ -24,6 +24,7 @@ public:
           _sampleRate(sampleRate), _fftCCSLength(fftCCSLength), _usePowerFloor(usePowerFloor), _numOfSources(numOfSources),
           _ctx(new detail::HipContext(sampleRate, microphonePositions, fftCCSLength - 2, doaStepDeg, static_cast<int>(numOfSources), usePowerFloor))
     {
+        // (limit of this build, MCA_MAX_SOURCES = 4; the reference has none: BeamformingSeparationAndLocalisation.cpp:113-118 loops min(M, S))
         if (numOfSources < 1 || numOfSources > 4) throw MCArrayException("numOfSources must be in [1,4]");
         for (unsigned c = 0; c < _nchannels; ++c) _inputFrames.push_back(SignalPtr(new BaseType[_fftCCSLength]));
         _currentDOA.reset(new BaseType[_numOfSources]);

@@ -24,7 +24,10 @@ public:
     }
     virtual ~SteeringBeamforming() {}
 
-    // wienerCoefs is accepted and ignored, like the reference (SteeringBeamforming.cpp:114)
+    // wienerCoefs is accepted and ignored, like the reference (SteeringBeamforming.cpp:114).
+    // LIMIT of this build: numOfSources is 1 ... 4 (MCA_MAX_SOURCES, mcarray_amd/csrc/mca_internal.h: the per-frame pick buffers, the state
+    // blob and the overlap-add carries of the stream kernels are sized by it); the reference's loop (SteeringBeamforming.cpp:185-194) takes
+    // any count.  A larger value throws MCArrayException (MCA_HIP_ERR_INVALID_ARGUMENT from the C ABI) -- it is never truncated silently.
     void processFrame(const SignalVector &analysisFrames, SignalPtr DOA, SignalPtr prob, int numOfSources, SignalVector &wienerCoefs)
     {
         (void)wienerCoefs;

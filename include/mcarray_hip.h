@@ -101,7 +101,8 @@ typedef struct {
     int n_mics;                /* M, 2..16 */
     const double *mic_xyz;     /* [M][3] metres, ArrayDescription coordinates (ArrayDescription.h:31-92) */
     double doa_step_deg;       /* SteeringBeamforming.cpp:39 hard-codes 5.0; BASELINE uses 0.5 */
-    int n_sources;             /* numOfSources, 1..4 */
+    int n_sources;             /* numOfSources, 1..4 (a limit of this build -- the reference's loops, SteeringBeamforming.cpp:185-194, take any count;
+                                  more is refused with MCA_HIP_ERR_INVALID_ARGUMENT, never truncated) */
     int use_power_floor;       /* usePowerFloor (reference default true, SourceSeparationAndLocalisation.h:47): the stream API
                                   then runs the power gate of BeamformingSeparationAndLocalisation.cpp:55-87 on the GPU;
                                   the frame API exposes mca_hip_fft_log_power for the caller's gate */
