@@ -51,6 +51,7 @@ struct Knobs {
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
     bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
+    int spw_lds_pad = 0;               // MCA_HIP_SPW_LDS_PAD: KiB of unused LDS added to every k_stft_phat_wave launch (fewer workgroups per CU: occupancy A/B, tools/third_wave.sh)
     bool spw_xcd = false;              // MCA_HIP_SPW_XCD: StftPhatArgs::xcd_map
     bool dyn_flat = false;             // MCA_HIP_DYN_FLAT: every run of the queue has the first runs' length
     const char *wave_clock = nullptr;  // MCA_HIP_WAVE_CLOCK=<file>: entry / exit clocks of every wave of the last k_stft_phat_wave launch, written at destruction
@@ -274,6 +275,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.dyn_len0 = (int)geti(measure_env("MCA_HIP_DYN_LEN0"), 0);
     k.dyn_flat = measure_env("MCA_HIP_DYN_FLAT") != nullptr;
     k.spw_xcd = measure_env("MCA_HIP_SPW_XCD") != nullptr;
+    k.spw_lds_pad = (int)geti(measure_env("MCA_HIP_SPW_LDS_PAD"), 0);
     k.wave_clock = measure_env("MCA_HIP_WAVE_CLOCK");
     return k;
 }
@@ -763,7 +765,7 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
         const bool mg = w.mrank != nullptr && !a.list;
         const int nrank = 2 * (M - 1) * 64 * 4 + 8, regw = mg ? std::max(F1K_SCRATCH, (w.n_merged + 63) & ~63) : F1K_SCRATCH;
         // (the merged kernel keeps its Nyquist bins in registers: with its 15.5 KiB regions two workgroups just fit the 160 KiB of a CU)
-        const size_t smw = (size_t)(F1K_TWORDS + (mg ? nrank / 4 : 0) + 4 * regw + (mg ? 0 : 4 * w.fpb * (M / 2))) * sizeof(float2);
+        const size_t smw = (size_t)(F1K_TWORDS + (mg ? nrank / 4 : 0) + 4 * regw + (mg ? 0 : 4 * w.fpb * (M / 2))) * sizeof(float2) + (size_t)c->kn.spw_lds_pad * 1024;
         const bool pl2 = a.a_planes == 2, pw = a.power != nullptr;
 #define LAUNCH_K(K)                                                                                                 \
         do {                                                                                                         \
