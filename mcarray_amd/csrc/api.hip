@@ -51,6 +51,8 @@ struct Knobs {
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
     bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
+    int bfw_skew = -1;                 // MCA_HIP_BFW_SKEW: BeamformWaveArgs::skew (-1: the shipped rule, 0: off)
+    int spw_skew = -1;                 // MCA_HIP_SPW_SKEW: StftPhatArgs::skew (-1: the shipped rule, 0: off)
     int spw_lds_pad = 0;               // MCA_HIP_SPW_LDS_PAD: KiB of unused LDS added to every k_stft_phat_wave launch (fewer workgroups per CU: occupancy A/B, tools/third_wave.sh)
     bool spw_xcd = false;              // MCA_HIP_SPW_XCD: StftPhatArgs::xcd_map
     bool dyn_flat = false;             // MCA_HIP_DYN_FLAT: every run of the queue has the first runs' length
@@ -276,6 +278,8 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.dyn_flat = measure_env("MCA_HIP_DYN_FLAT") != nullptr;
     k.spw_xcd = measure_env("MCA_HIP_SPW_XCD") != nullptr;
     k.spw_lds_pad = (int)geti(measure_env("MCA_HIP_SPW_LDS_PAD"), 0);
+    k.spw_skew = (int)geti(measure_env("MCA_HIP_SPW_SKEW"), -1);
+    k.bfw_skew = (int)geti(measure_env("MCA_HIP_BFW_SKEW"), -1);
     k.wave_clock = measure_env("MCA_HIP_WAVE_CLOCK");
     return k;
 }
@@ -756,6 +760,17 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
             gw = dim3(wg_per_cu * c->n_cu, 1);
         }
         w.xcd_map = c->kn.spw_xcd ? 1 : 0;
+        // One resident round of two workgroups per CU (the bench shapes: 8 x 4096 and 128 x 256 frames of 8 microphones): the CU issues
+        // oldest-first, so the workgroup it got first finishes early and the other then runs alone at 83 % of the two-wave rate.  The first
+        // half of every array's run groups -- dispatched first -- takes more frames per wave (StftPhatArgs::skew).
+        if (!a.list && !w.queue && c->kn.spw_skew != 0 && M == 8 && (gw.x & 1) == 0 && (long long)gw.x * gw.y == 2LL * c->n_cu &&
+            (long long)gw.x * 4 * w.fpb == a.n_frames) {
+            const int sk = c->kn.spw_skew > 0 ? c->kn.spw_skew : (3 * w.fpb + 8) / 16;      // 16 frames per wave: 19 / 13 (measured 1 ... 4: 3 is best)
+            if (sk > 0 && sk < w.fpb) {
+                w.skew = sk;
+                gw = dim3(gw.y, gw.x);             // (arrays, run groups): the first half of the run groups of EVERY array is dispatched first
+            }
+        }
         if (c->kn.wave_clock && !a.list) {
             if (!c->d_wave_clock) HIP_TRY(c, hipMalloc((void **)&c->d_wave_clock, 3 * 8 * 16384));
             HIP_TRY(c, hipMemsetAsync(c->d_wave_clock, 0, 3 * 8 * 16384, st));
@@ -765,7 +780,7 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
         const bool mg = w.mrank != nullptr && !a.list;
         const int nrank = 2 * (M - 1) * 64 * 4 + 8, regw = mg ? std::max(F1K_SCRATCH, (w.n_merged + 63) & ~63) : F1K_SCRATCH;
         // (the merged kernel keeps its Nyquist bins in registers: with its 15.5 KiB regions two workgroups just fit the 160 KiB of a CU)
-        const size_t smw = (size_t)(F1K_TWORDS + (mg ? nrank / 4 : 0) + 4 * regw + (mg ? 0 : 4 * w.fpb * (M / 2))) * sizeof(float2) + (size_t)c->kn.spw_lds_pad * 1024;
+        const size_t smw = (size_t)(F1K_TWORDS + (mg ? nrank / 4 : 0) + 4 * regw + (mg ? 0 : 4 * (w.fpb + w.skew) * (M / 2))) * sizeof(float2) + (size_t)c->kn.spw_lds_pad * 1024;
         const bool pl2 = a.a_planes == 2, pw = a.power != nullptr;
 #define LAUNCH_K(K)                                                                                                 \
         do {                                                                                                         \
@@ -1551,9 +1566,17 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         }
         const int wgs = (var & 2) ? (n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1) : ((n_frames + wa.ft - 1) / wa.ft + 3) / 4;
         const size_t smem = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2) + ((var & 2) ? 4 * FFT_H * sizeof(float) : 0);
+        // one resident round of (nearly) two workgroups per CU: the older workgroup of every CU takes longer runs (BeamformWaveArgs::skew)
+        dim3 gb(wgs, n_arrays, c->S);
+        if ((var & 2) && !abl && c->kn.bfw_skew != 0 && c->S == 1 && (wgs & 1) == 0 && wa.ft >= 8 &&
+            (long long)wgs * n_arrays > (long long)c->n_cu * 3 / 2 && (long long)wgs * n_arrays <= 2LL * c->n_cu) {
+            wa.skew = c->kn.bfw_skew > 0 ? c->kn.bfw_skew : (3 * wa.ft + 8) / 16;
+            if (wa.skew >= wa.ft) wa.skew = 0;
+            else gb = dim3(n_arrays, wgs, c->S);
+        }
         time_begin(c, MCA_HIP_K_BEAMFORM, st);
-#define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa); \
-                            else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa); break;
+#define BFW_CASE(V) case V: if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, V, 0>), gb, dim3(256), smem, st, wa); \
+                            else hipLaunchKernelGGL((k_beamform_wave<false, V, 0>), gb, dim3(256), smem, st, wa); break;
 #ifdef MCA_MEASURE
         if (abl == 1) hipLaunchKernelGGL((k_beamform_wave<false, 14, 1>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);
         else if (abl == 2) hipLaunchKernelGGL((k_beamform_wave<false, 14, 2>), dim3(wgs, n_arrays, c->S), dim3(256), smem, st, wa);

@@ -91,13 +91,18 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
     __syncthreads();
     if (T1REG) lc.load_t1(tab, lane);
 
-    const int a = blockIdx.y;
+    const int a = p.skew ? blockIdx.x : blockIdx.y;
     const long long as = (long long)a * p.S + blockIdx.z;                // (array, source): output channel, overlap-add carry
     int t0, t1;
     if (HANDOFF) {
-        const int w0 = (int)blockIdx.x * (4 * p.ft - 1);                 // the workgroup's first frame
-        t0 = wave == 0 ? w0 : w0 + wave * p.ft - 1;
-        t1 = min(w0 + (wave + 1) * p.ft - 1, p.n_frames);
+        int w0 = (int)blockIdx.x * (4 * p.ft - 1), ft = p.ft;            // the workgroup's first frame, frames per wave
+        if (p.skew) {
+            const int g = blockIdx.y, half = gridDim.y >> 1, hi = p.ft + p.skew, lo = p.ft - p.skew;
+            ft = g < half ? hi : lo;
+            w0 = g < half ? g * (4 * hi - 1) : half * (4 * hi - 1) + (g - half) * (4 * lo - 1);
+        }
+        t0 = wave == 0 ? w0 : w0 + wave * ft - 1;
+        t1 = min(w0 + (wave + 1) * ft - 1, p.n_frames);
     } else {
         t0 = ((int)blockIdx.x * 4 + wave) * p.ft;
         t1 = min(t0 + p.ft, p.n_frames);
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
     const int regw = MERGE ? max(F1K_SCRATCH, nmp) : F1K_SCRATCH;                  // float2 words per wave
     float2 *wbase = tab + F1K_TWORDS + (MERGE ? NRANK / 4 : 0);
     float2 *buf = wbase + wave * regw;
-    float2 *nyq = wbase + 4 * regw + wave * (p.fpb * NP);                         // [fpb][NP] Z_p[512] of the run's frames (not MERGE)
+    float2 *nyq = wbase + 4 * regw + wave * ((p.fpb + p.skew) * NP);              // [fpb (+ skew)][NP] Z_p[512] of the run's frames (not MERGE)
     // list mode: the length of the list and this workgroup's first entry are requested before the tables are built (the barrier
     // below would hold the loads back: three dependent round trips -- length, entry, samples -- in front of a single frame per wave)
     const int n_list_now = p.list ? *p.n_list : 0;
@@ -474,6 +479,12 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         // (measurement: xcd_map -- consecutive workgroups go to consecutive XCDs; give every XCD one contiguous piece of the array instead)
         const int bxm = (p.xcd_map && (gridDim.x & 7) == 0) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
         int f_begin = (bxm * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+        if (p.skew) {
+            const int g = blockIdx.y, half = gridDim.y >> 1, hi = p.fpb + p.skew, lo = p.fpb - p.skew;
+            a = blockIdx.x;
+            if (g < half) { f_begin = (g * 4 + wave) * hi; f_end = f_begin + hi; }
+            else { f_begin = half * 4 * hi + ((g - half) * 4 + wave) * lo; f_end = f_begin + lo; }
+        }
         if (p.queue) {
             int rr = 0, rpa = 1, f_first = 0, len = 1, f_last = 0;
             dyn_run((int)rq, p.n_frames, p.q_arrays, p.q_sh0, rr, rpa, f_first, len, f_last, p.q_flat);

@@ -66,6 +66,12 @@ struct StftPhatArgs {
     int q_sh0, q_total, q_arrays;   // log2 of the first runs' length, number of runs, arrays of the launch
     int q_flat;                     // (measurement) 1: every run has the first runs' length
     int xcd_map;                    // (measurement) 1: workgroups of one XCD (linear id mod 8) take neighbouring runs of frames
+    int skew;                       // > 0 (round 5; a launch that is exactly one resident round of two workgroups per CU): grid (arrays, run groups),
+                                    // and the run groups of the first half -- dispatched first: the OLDER workgroup of every CU, which the CU's
+                                    // oldest-first issue favours (its waves were done at 180 us, the younger one's at 244: profiles/
+                                    // r05_run_queue_negative.log) -- take fpb + skew frames per wave, the others fpb - skew, so that both finish
+                                    // together (19 / 13 frames: 302 -> 281 us per 32 768 frames, profiles/r05_skew.log).  The rows do not
+                                    // depend on which wave forms them: the same bits.
     unsigned long long *wave_clock; // (measurement, make MEASURE=1 + MCA_HIP_WAVE_CLOCK) [waves][3]: wall_clock64 at entry and exit, runs taken
     unsigned char *unsure;   // k_stft_phat_wave16 in the adaptive coarse pass, else NULL: [arrays][total_frames] 1 = a channel's DC or Nyquist bin of this
                              // frame is at the rounding level of the transform.  PHAT keeps only the SIGN of such a bin, and the exact rows of 16
@@ -252,6 +258,8 @@ struct BeamformWaveArgs {
     float *out;              // [arrays][S][n_frames*hop]
     const float *tail_in;    // [arrays][S][hop] overlap-add carry at entry
     float *tail_out;         // at exit
+    int skew;                // k_beamform_wave with the hand-off, > 0 (round 5, as StftPhatArgs::skew): grid (arrays, workgroups, sources); the first half
+                             // of an array's workgroups -- dispatched first, the older workgroup of every CU -- run ft + skew frames per wave, the others ft - skew
 };
 
 struct Gcc2ScanArgs {
