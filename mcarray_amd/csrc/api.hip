@@ -51,6 +51,7 @@ struct Knobs {
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
     bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
+    int spw_waves = 4;                 // MCA_HIP_SPW_WAVES: 8 = the regular launches of k_stft_phat_wave as one workgroup of eight waves per CU
     int bfw_skew = -1;                 // MCA_HIP_BFW_SKEW: BeamformWaveArgs::skew (-1: the shipped rule, 0: off)
     int spw_skew = -1;                 // MCA_HIP_SPW_SKEW: StftPhatArgs::skew (-1: the shipped rule, 0: off)
     int spw_lds_pad = 0;               // MCA_HIP_SPW_LDS_PAD: KiB of unused LDS added to every k_stft_phat_wave launch (fewer workgroups per CU: occupancy A/B, tools/third_wave.sh)
@@ -280,6 +281,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.spw_lds_pad = (int)geti(measure_env("MCA_HIP_SPW_LDS_PAD"), 0);
     k.spw_skew = (int)geti(measure_env("MCA_HIP_SPW_SKEW"), -1);
     k.bfw_skew = (int)geti(measure_env("MCA_HIP_BFW_SKEW"), -1);
+    k.spw_waves = (int)geti(measure_env("MCA_HIP_SPW_WAVES"), 4);
     k.wave_clock = measure_env("MCA_HIP_WAVE_CLOCK");
     return k;
 }
@@ -771,6 +773,10 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
                 gw = dim3(gw.y, gw.x);             // (arrays, run groups): the first half of the run groups of EVERY array is dispatched first
             }
         }
+        // (measurement) MCA_HIP_SPW_WAVES=8: the same runs as ONE workgroup of eight waves per CU -- waves of one age, no skew needed
+        int nwv = 4;
+        if (!a.list && !w.queue && c->kn.spw_waves == 8 && (gw.x & 1) == 0 && !w.skew) { nwv = 8; gw = dim3(gw.x / 2, gw.y); }
+        else if (!a.list && !w.queue && c->kn.spw_waves == 8 && w.skew) { w.skew = 0; gw = dim3(gw.y / 2, gw.x); nwv = 8; }   // (the skew rule had swapped the grid)
         if (c->kn.wave_clock && !a.list) {
             if (!c->d_wave_clock) HIP_TRY(c, hipMalloc((void **)&c->d_wave_clock, 3 * 8 * 16384));
             HIP_TRY(c, hipMemsetAsync(c->d_wave_clock, 0, 3 * 8 * 16384, st));
@@ -780,12 +786,12 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
         const bool mg = w.mrank != nullptr && !a.list;
         const int nrank = 2 * (M - 1) * 64 * 4 + 8, regw = mg ? std::max(F1K_SCRATCH, (w.n_merged + 63) & ~63) : F1K_SCRATCH;
         // (the merged kernel keeps its Nyquist bins in registers: with its 15.5 KiB regions two workgroups just fit the 160 KiB of a CU)
-        const size_t smw = (size_t)(F1K_TWORDS + (mg ? nrank / 4 : 0) + 4 * regw + (mg ? 0 : 4 * (w.fpb + w.skew) * (M / 2))) * sizeof(float2) + (size_t)c->kn.spw_lds_pad * 1024;
+        const size_t smw = (size_t)(F1K_TWORDS + (mg ? nrank / 4 : 0) + nwv * regw + (mg ? 0 : nwv * (w.fpb + w.skew) * (M / 2))) * sizeof(float2) + (size_t)c->kn.spw_lds_pad * 1024;
         const bool pl2 = a.a_planes == 2, pw = a.power != nullptr;
 #define LAUNCH_K(K)                                                                                                 \
         do {                                                                                                         \
             if (smw > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw)); \
-            hipLaunchKernelGGL(K, gw, dim3(256), smw, st, w);                                                        \
+            hipLaunchKernelGGL(K, gw, dim3(64 * nwv), smw, st, w);                                                   \
         } while (0)
 #define LAUNCH_W2(MT, U, PL2, NP)                                                                                  \
         do {                                                                                                         \

@@ -421,7 +421,7 @@ __device__ __forceinline__ float wave_sum64(float v)
 // rank[m] -- every instruction hits 64 different words and the instructions of a wave execute in order, so the sums are
 // formed in a fixed order --, and the region is read back as the row: n_merged instead of (M - 1) * 513 complex values.
 template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT, bool MERGE>
-__global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
+__global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 4 or 8 waves (256 registers either way: two waves per SIMD)
 {
     static_assert(!MERGE || (ULA && !PL2 && !NOPHAT && sizeof(OutT) == 2), "the merged index serves the one-plane fp16 rows of a ULA");
     constexpr int NP = MT / 2, NOUT = PairOut<MT, ULA>::N;
@@ -429,23 +429,24 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *tab = reinterpret_cast<float2 *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)blockDim.x >> 6, nthr = (int)blockDim.x;                   // waves per workgroup
     // LDS: twiddles | MERGE: rank table | per wave: transform scratch (MERGE: also the merged sums, whichever is larger) | Nyquist bins
     const unsigned short *rankl = reinterpret_cast<const unsigned short *>(tab + F1K_TWORDS);
     const int nmp = MERGE ? (p.n_merged + 63) & ~63 : 0;                           // merged sums, rounded up to whole wave rows
     const int regw = MERGE ? max(F1K_SCRATCH, nmp) : F1K_SCRATCH;                  // float2 words per wave
     float2 *wbase = tab + F1K_TWORDS + (MERGE ? NRANK / 4 : 0);
     float2 *buf = wbase + wave * regw;
-    float2 *nyq = wbase + 4 * regw + wave * ((p.fpb + p.skew) * NP);              // [fpb (+ skew)][NP] Z_p[512] of the run's frames (not MERGE)
+    float2 *nyq = wbase + nw * regw + wave * ((p.fpb + p.skew) * NP);              // [fpb (+ skew)][NP] Z_p[512] of the run's frames (not MERGE)
     // list mode: the length of the list and this workgroup's first entry are requested before the tables are built (the barrier
     // below would hold the loads back: three dependent round trips -- length, entry, samples -- in front of a single frame per wave)
     const int n_list_now = p.list ? *p.n_list : 0;
     const int e_first = (p.list && p.list0 + (int)blockIdx.x < n_list_now) ? p.list[p.list0 + (int)blockIdx.x] : 0;
-    f1k_table_init(tab, tid, 256);
+    f1k_table_init(tab, tid, nthr);
     if (MERGE) {
         // per lane, spacing g and half h: the region offsets (in words) of its four products k g, k = lam + 64 (4 h + s):
         // [2 (g - 1) + h][lane][4] u16 -- one ds_read_b64 per batch; behind them rank[512 g], the Nyquist bin's
         unsigned short *ot = reinterpret_cast<unsigned short *>(tab + F1K_TWORDS);
-        for (int e = tid; e < 2 * (MT - 1) * 64 * 4; e += 256) {
+        for (int e = tid; e < 2 * (MT - 1) * 64 * 4; e += nthr) {
             const int s4 = e & 3, ln = (e >> 2) & 63, gh = e >> 8, g = (gh >> 1) + 1, h = gh & 1;
             const int lm = ln <= 32 ? ln : 96 - ln;
             ot[e] = p.mrank[(lm + 64 * (4 * h + s4)) * g];
@@ -478,12 +479,12 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         int a = blockIdx.y;
         // (measurement: xcd_map -- consecutive workgroups go to consecutive XCDs; give every XCD one contiguous piece of the array instead)
         const int bxm = (p.xcd_map && (gridDim.x & 7) == 0) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-        int f_begin = (bxm * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+        int f_begin = (bxm * nw + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
         if (p.skew) {
             const int g = blockIdx.y, half = gridDim.y >> 1, hi = p.fpb + p.skew, lo = p.fpb - p.skew;
             a = blockIdx.x;
-            if (g < half) { f_begin = (g * 4 + wave) * hi; f_end = f_begin + hi; }
-            else { f_begin = half * 4 * hi + ((g - half) * 4 + wave) * lo; f_end = f_begin + lo; }
+            if (g < half) { f_begin = (g * nw + wave) * hi; f_end = f_begin + hi; }
+            else { f_begin = half * nw * hi + ((g - half) * nw + wave) * lo; f_end = f_begin + lo; }
         }
         if (p.queue) {
             int rr = 0, rpa = 1, f_first = 0, len = 1, f_last = 0;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         // whose row pitch is a power of two plus a little (128 arrays x 257 half frames: 2^19 + 2^11 bytes) put the loads of
         // all resident waves onto the same few memory channels (measured: 0.33 instead of 0.27 ms per 32 768 frames).
         const int nfr = f_end - f_begin;
-        const int rot = p.list ? 0 : (int)((unsigned)(5 * a + 3 * ((int)blockIdx.x * 4 + wave)) % (unsigned)nfr);
+        const int rot = p.list ? 0 : (int)((unsigned)(5 * a + 3 * ((int)blockIdx.x * nw + wave)) % (unsigned)nfr);
         auto frame_of = [&](int i) { const int j = i + rot; return f_begin + (j >= nfr ? j - nfr : j); };
         load_pair(frame_of(0), 0);
         for (int fi = 0; fi < nfr; ++fi) {
@@ -694,13 +695,13 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave(StftPhatArgs p)
         ++runs_taken;
     }
     if (p.wave_clock && lane == 0) {
-        unsigned long long *wc = p.wave_clock + 3ull * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
+        unsigned long long *wc = p.wave_clock + 3ull * ((blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)nw + wave);
         wc[0] = clock_in; wc[1] = wall_clock64(); wc[2] = (unsigned long long)runs_taken;
     }
     // the last wave to leave zeroes the counters (every wave has made its last request by then)
     if (p.queue && lane == 0) {
         __threadfence();
-        if (atomicAdd(p.queue + 1, 1u) == gridDim.x * gridDim.y * 4u - 1u) { p.queue[0] = 0u; p.queue[1] = 0u; }
+        if (atomicAdd(p.queue + 1, 1u) == gridDim.x * gridDim.y * (unsigned)nw - 1u) { p.queue[0] = 0u; p.queue[1] = 0u; }
     }
 }
 
