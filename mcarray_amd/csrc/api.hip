@@ -714,8 +714,14 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
             StftPhatArgs w = a;
             w.fpb = 16;
             while (w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
-            const dim3 gw(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
-            const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 2 * 4 * w.fpb * 8) * sizeof(float2) + (1024 + 4 * w.fpb) * sizeof(float);   // (+ the scales and DC marks of unsure frames)
+            dim3 gw(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
+            // (one resident round of two workgroups per CU: the older workgroup's waves take more frames, StftPhatArgs::skew)
+            if (c->kn.spw_skew != 0 && (gw.x & 1) == 0 && (long long)gw.x * gw.y == 2LL * c->n_cu && (long long)gw.x * 4 * w.fpb == a.n_frames) {
+                const int sk = c->kn.spw_skew > 0 ? c->kn.spw_skew : (3 * w.fpb + 8) / 16;
+                if (sk > 0 && sk < w.fpb) { w.skew = sk; gw = dim3(gw.y, gw.x); }
+            }
+            const int fpa = w.fpb + w.skew;
+            const size_t smw = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 2 * 4 * fpa * 8) * sizeof(float2) + (1024 + 4 * fpa) * sizeof(float);   // (+ the scales and DC marks of unsure frames)
             if (a.power) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_wave16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw));
                 hipLaunchKernelGGL(k_stft_phat_wave16<true>, gw, dim3(256), smw, st, w);

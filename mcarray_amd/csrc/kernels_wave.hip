@@ -732,12 +732,13 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
     float *wtab = reinterpret_cast<float *>(tab + F1K_TWORDS + 4 * F1K_SCRATCH);   // [64 lanes][16]: the lane's window samples w[lane + 64 i]
-    float2 *nyq = reinterpret_cast<float2 *>(wtab + 1024) + wave * (p.fpb * NP);  // [fpb][NP] Z_p[512] of the run's frames
+    const int fpa = p.fpb + p.skew;                                                // frames a wave's LDS slots hold (StftPhatArgs::skew)
+    float2 *nyq = reinterpret_cast<float2 *>(wtab + 1024) + wave * (fpa * NP);    // [fpb][NP] Z_p[512] of the run's frames
     // (unsure frames, see StftPhatArgs: per frame and pair the channels' MEAN bin power as the scale -- Parseval: sum_n (w x)^2, wave-reduced;
     // round 4 took the power of bin 64 alone, which a notch or a tone at 3 kHz makes arbitrarily small or large, ADVICE r4 --, per frame
     // whether a DC bin fell below it)
-    float2 *nref = reinterpret_cast<float2 *>(wtab + 1024) + 4 * (p.fpb * NP) + wave * (p.fpb * NP);
-    float *dcbad = reinterpret_cast<float *>(reinterpret_cast<float2 *>(wtab + 1024) + 8 * (p.fpb * NP)) + wave * p.fpb;
+    float2 *nref = reinterpret_cast<float2 *>(wtab + 1024) + 4 * (fpa * NP) + wave * (fpa * NP);
+    float *dcbad = reinterpret_cast<float *>(reinterpret_cast<float2 *>(wtab + 1024) + 8 * (fpa * NP)) + wave * fpa;
     constexpr float UNSURE = 1e-10f;                                               // power ratio: 1e-5 of the channel's rms bin amplitude in this frame
     for (int e = tid; e < 1024; e += 256) wtab[(e & 63) * 16 + (e >> 6)] = p.window[e];
     f1k_table_init(tab, tid, 256);
@@ -750,8 +751,13 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
     // (the window is read from LDS per pair: 16 registers that the 128 of packed spectra do not leave room for)
     const float4 *wq = reinterpret_cast<const float4 *>(wtab + lane * 16);
 
-    const int a = blockIdx.y;
-    const int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+    const int a = p.skew ? blockIdx.x : blockIdx.y;
+    int f_begin = ((int)blockIdx.x * 4 + wave) * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
+    if (p.skew) {                                                                 // (see StftPhatArgs::skew)
+        const int g = blockIdx.y, half = gridDim.y >> 1, hi = p.fpb + p.skew, lo = p.fpb - p.skew;
+        if (g < half) { f_begin = (g * 4 + wave) * hi; f_end = f_begin + hi; }
+        else { f_begin = half * 4 * hi + ((g - half) * 4 + wave) * lo; f_end = f_begin + lo; }
+    }
     if (f_begin >= f_end) return;                                                 // (no barrier below)
     const long long row_base = (long long)a * p.n_frames;
     const float *base = p.pcm + (long long)a * p.array_stride + lane;

@@ -75,7 +75,8 @@ if os.path.exists(log):
     if lines:
         open(os.path.join(P, "%s_bench_mvdr.json" % tag), "w").write(lines[-1])
 for name in ("adaptive_check.json", "precision_report.json", "host_path.log", "bench_128x256.json", "bench_single_stream.json", "shapes.log", "gputest.log", "fallback.log",
-             "bench_driver_cmd.json", "bench_warmup0.json", "bench_warmup1.json", "kernel_stats_driver_cmd.csv", "stream_latency.log"):
+             "bench_driver_cmd.json", "bench_warmup0.json", "bench_warmup1.json", "kernel_stats_driver_cmd.csv", "stream_latency.log",
+             "repair_breakdown.log", "timeline.log"):
     src = os.path.join(G, "final", name)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(P, "%s_%s" % (tag, name)))

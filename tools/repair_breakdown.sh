@@ -5,7 +5,14 @@ mkdir -p gpurun_out/rb
 run() {   # name, bench flags
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rb/$1 -- python3 bench.py --steps 30 --warmup 10 --cpu-frames 0 --single-stream 0 --extras 0 $2 > gpurun_out/rb/$1.log 2>&1
   python3 tools/summarize_rocprof.py gpurun_out/rb/$1 gpurun_out/rb/$1.csv > /dev/null
-  echo "== $1: bench.py $2"; cut -d, -f1,2,4 gpurun_out/rb/$1.csv | grep -v "non-mca\|k_bf_table" | sed 's/"//g' | awk -F, '{printf "%-90s %5s launches %9.1f us\n", substr($1,1,90), $2, $3/1000}'
+  echo "== $1: bench.py $2"
+  python3 - <<PY
+import csv
+for r in csv.DictReader(open("gpurun_out/rb/$1.csv")):
+    if "non-mca" in r["Name"] or "k_bf_table" in r["Name"] or not r["AverageNs"]: continue
+    n=r["Name"]; n=n[n.find("k_"):][:60]
+    print("%-62s %5s launches %9.1f us" % (n, r["Calls"], float(r["AverageNs"])/1e3))
+PY
   rm -rf gpurun_out/rb/$1
 }
 run bench_8x4096 ""
