@@ -174,8 +174,9 @@ def valu_roofline(kernel_substrings, avg_ms, which="adaptive", exclude=()):
         if not clock:      # (round 4's file has no durations: the busy cycles of that pass over THIS run's launch)
             clock = v["SQ_BUSY_CYCLES"] / 32.0 / (avg_ms * 1e6)
             clock_src = "SQ_BUSY_CYCLES / 32 of the committed pass / this run's average launch"
-        floor_ms = v["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * clock * 1e9) * 1e3
-        return {"bound": "valu", "insts_valu_per_launch": v["SQ_INSTS_VALU"], "cycles_per_wave_instruction": 4, "simds": N_SIMD, "clock_ghz": clock,
+        per_step = v.get("dispatches_in_pass", 3) / float(v.get("steps_in_pass", 3))      # launches of this kernel per step (MVDR's solve: a main and a tail launch)
+        floor_ms = v["SQ_INSTS_VALU"] * per_step * 4.0 / (N_SIMD * clock * 1e9) * 1e3
+        return {"bound": "valu", "insts_valu_per_launch": v["SQ_INSTS_VALU"], "launches_per_step": per_step, "cycles_per_wave_instruction": 4, "simds": N_SIMD, "clock_ghz": clock,
                 "clock_source": clock_src, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
                 "valu_busy_in_counter_pass": v["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / (v["SQ_BUSY_CYCLES"] / 32.0) if v.get("SQ_BUSY_CYCLES") else None,
                 "source": "profiles/%s_pmc_sq_%s.json, %s (committed SQ pass of the same command on an MI355X; not this run)" % (tag, which, best[0][:60])}

@@ -47,6 +47,7 @@ struct Knobs {
     bool force_generic = false;        // MCA_HIP_FORCE_GENERIC: the any-length kernels at N = 1024 too (parity test of both)
     bool scan_carry = false;           // MCA_HIP_SCAN_CARRY / cfg.scan_carry
     // measurement only (-DMCA_MEASURE)
+    bool gemm_ks2 = false;             // MCA_HIP_GEMM_KS2: two K halves for 16 384 ... 32 767 rows (round 4) instead of four quarters
     bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
@@ -264,6 +265,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.no_fused_partial = measure_env("MCA_HIP_NO_FUSED_PARTIAL") != nullptr;
     k.gemm_v1 = measure_env("MCA_HIP_GEMM_V1") != nullptr;
     k.gemm_v2 = measure_env("MCA_HIP_GEMM_V2") != nullptr;
+    k.gemm_ks2 = measure_env("MCA_HIP_GEMM_KS2") != nullptr;
     k.v1_nosplit = measure_env("MCA_HIP_V1_NOSPLIT") != nullptr;
     k.no_n512 = measure_env("MCA_HIP_NO_N512") != nullptr;
     k.no_sub2 = measure_env("MCA_HIP_NO_SUB2") != nullptr;
@@ -445,7 +447,11 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
     // there: 134 vs 156 us, and leave the scan's chunk results), from 32 768 rows with the hi + lo planes (343 vs 299 us at 16 384)
     g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= (long long)c->v2_min_rows * (c->a_planes == 2 ? 2 : 1) && !c->kn.gemm_v1;
     if (g.v2) {
-        g.ksplit = rows >= 65536 ? 1 : 2;   // 256 x 384 tiles need >= ~256 workgroups to fill the chip
+        // 256 x 384 tiles need >= ~256 workgroups to fill the chip: one K range from 65 536 rows, two halves from 32 768, and below that four
+        // quarters where the contraction is deep (round 5: 16 microphones, 15 392 terms per row -- 16 384 rows were 128 workgroups on half
+        // the CUs: 0.280 -> 0.183 ms + 0.021 for k_sum_planes, which folds the four partial maps before the scan; with the 3 968 merged terms
+        // of 8 microphones the fold costs what the quarters save: 75 -> 54 + 22 us, profiles/r05_gemm_ksplit4.log)
+        g.ksplit = rows >= 65536 ? 1 : (rows >= 32768 || c->kn.gemm_ks2 || cur_kp(c) < 8192 ? 2 : 4);
     } else {
         // 128 x 192 tiles: small batches (a single stream) would leave most CUs idle and walk the whole K range
         // in a handful of workgroups (0.29 ms however few frames); split K until ~512 workgroups exist, keeping

@@ -23,7 +23,9 @@ for p in ("p1","p2"):
             k=r["Kernel_Name"]
             if "mca" not in k: continue
             agg[(k,r["Counter_Name"])]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
-        for (k,c),v in agg.items(): res[k][c]=v/cnt[(k,c)]
+        for (k,c),v in agg.items():
+            res[k][c]=v/cnt[(k,c)]
+            res[k]['dispatches_in_pass']=cnt[(k,c)]; res[k]['steps_in_pass']=3      # (--steps 2 --warmup 1)
 for f in glob.glob("$out/p1/**/*kernel_trace.csv",recursive=True):
     dur=collections.defaultdict(float); n=collections.Counter()
     for r in csv.DictReader(open(f)):
