@@ -46,6 +46,8 @@ struct Knobs {
     long long ws_max_bytes = 4LL << 30;   // MCA_HIP_WS_MAX_MB: A-operand workspace budget per slice of frames (tests force the sliced path)
     bool force_generic = false;        // MCA_HIP_FORCE_GENERIC: the any-length kernels at N = 1024 too (parity test of both)
     bool scan_carry = false;           // MCA_HIP_SCAN_CARRY / cfg.scan_carry
+    bool lazy_ks_shape = false;        // (measurement) MCA_HIP_LAZY_KS_SHAPE: the repair contraction's K segments by the call's shape also with lazy tails
+    bool lazy_tails = true;            // MCA_HIP_ADAPT_LAZY=0: every adaptive call repairs its own last rows for the state it hands over (round 4)
     // measurement only (-DMCA_MEASURE)
     bool gemm_ks2 = false;             // MCA_HIP_GEMM_KS2: two K halves for 16 384 ... 32 767 rows (round 4) instead of four quarters
     bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
@@ -145,6 +147,15 @@ struct mca_hip_ctx {
     int tab_planes = 1;            // planes of the steering tables (2: FP16X3 and ADAPTIVE)
     unsigned long long *d_rstats = nullptr;
     unsigned long long *d_wave_clock = nullptr; int wave_clock_n = 0;   // (measurement) StftPhatArgs::wave_clock of the last regular launch
+    // lazy tails (mca_internal.h, HIST_FRAMES): what the last lazy adaptive call left for the next one, double buffered like d_E
+    float *d_hist_pcm[2] = {nullptr, nullptr};     // [max_arrays][M][HIST_SAMPLES]
+    float *d_hist_C[2] = {nullptr, nullptr};       // [max_arrays][HIST_FRAMES][Dp] coarse rows (patched where a repair pass recomputed them)
+    float *d_ehist[2] = {nullptr, nullptr};        // [max_arrays][D] the energies in front of them
+    int hist_cur = 0, hist_n = 0;                  // the buffers that hold the pending history, the arrays it covers
+    bool hist_pending = false;                     // the state in d_E is coarse: exact = settle_history, or the next lazy call's own repair pass
+    bool lazy_now = false;                         // (localise_impl) this call leaves its tails to the next: the coarse analysis keeps the PCM
+    bool host_call = false;                        // inside a host-pointer entry point: its calls keep the eager form (the pageable and the page-locked path return the same bits)
+    bool lazy_entry = false;                       // this API call may leave its tails to the next (device-pointer stream calls outside captures)
     unsigned *d_queue = nullptr;   // [16] run-queue words of the wave-per-run kernels (StftPhatArgs::queue), zero between launches
     int n_cu = 256;
     unsigned long long adapt_frames_total = 0;
@@ -227,6 +238,7 @@ void free_ctx(mca_hip_ctx *c)
     F(c->d_E[0]); F(c->d_E[1]); F(c->d_tail[0]); F(c->d_tail[1]); F(c->d_doa[0]); F(c->d_doa[1]); F(c->d_vdone[0]); F(c->d_vdone[1]); F(c->d_g2_vidx); F(c->d_g2_nv); F(c->d_g2_rad); F(c->d_g2_prob);
     F(c->d_g2_reset); F(c->d_g2_post0); F(c->d_silence);
     F(c->d_rstats); F(c->d_gate_state); F(c->d_queue);
+    for (int i = 0; i < 2; ++i) { F(c->d_hist_pcm[i]); F(c->d_hist_C[i]); F(c->d_ehist[i]); }
     if (c->h_probe) (void)hipHostFree(c->h_probe);
     for (Workspace &w : c->lanes) w.release();
     for (auto &e : c->io_ev) if (e) (void)hipEventDestroy(e);
@@ -256,6 +268,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     if (const char *v = env_str("MCA_HIP_WS_MAX_MB")) k.ws_max_bytes = (long long)std::atoll(v) << 20;
     k.force_generic = env_str("MCA_HIP_FORCE_GENERIC") != nullptr;
     k.scan_carry = cfg.scan_carry != 0 || env_str("MCA_HIP_SCAN_CARRY") != nullptr;
+    if (const char *v = env_str("MCA_HIP_ADAPT_LAZY")) k.lazy_tails = std::atoi(v) != 0;
     // measurement only: constants unless the library was built with -DMCA_MEASURE
     k.no_merge = measure_env("MCA_HIP_NO_MERGE") != nullptr;
     k.repair_items = (int)geti(measure_env("MCA_HIP_REPAIR_ITEMS"), 768);
@@ -281,6 +294,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.dyn_flat = measure_env("MCA_HIP_DYN_FLAT") != nullptr;
     k.spw_xcd = measure_env("MCA_HIP_SPW_XCD") != nullptr;
     k.spw_lds_pad = (int)geti(measure_env("MCA_HIP_SPW_LDS_PAD"), 0);
+    k.lazy_ks_shape = measure_env("MCA_HIP_LAZY_KS_SHAPE") != nullptr;
     k.spw_skew = (int)geti(measure_env("MCA_HIP_SPW_SKEW"), -1);
     k.bfw_skew = (int)geti(measure_env("MCA_HIP_BFW_SKEW"), -1);
     k.spw_waves = (int)geti(measure_env("MCA_HIP_SPW_WAVES"), 4);
@@ -561,6 +575,13 @@ bool adaptive_shape(const mca_hip_ctx *c, int n_arrays, int n_frames)
            rows >= c->kn.adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
 }
 bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames) { return adaptive_shape(c, n_arrays, n_frames) && !c->adapt_suspended; }
+// lazy tails: contexts whose adaptive calls may leave the repair of their last rows to the next call -- no power gate (the rows a frame
+// depends on are then simply the 16 before it), the wave-per-run analysis (4 / 8 microphones at 1024 samples: it keeps the PCM and reads it back)
+bool lazy_context(const mca_hip_ctx *c)
+{
+    return c->prec == MCA_HIP_SRP_ADAPTIVE && c->kn.lazy_tails && !c->cfg.use_power_floor && (c->M == 8 || c->M == 4) && !c->generic && !c->n512 &&
+           !c->kn.stft_wg && c->cfg.gcc_weighting == MCA_HIP_GCC_PHAT && c->stream_ok;
+}
 
 // Called once at the top of an eager stream call (not per piece of a call, not while a graph is recorded): reads what the
 // adaptive calls that have finished by now reported and decides whether this call runs coarse + repair or plain FP16X3.
@@ -612,6 +633,9 @@ void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
 int repair_ksplit_for(const mca_hip_ctx *c, int n_arrays)
 {
     if (c->kn.repair_ksplit > 0) return std::min(c->kn.repair_ksplit, REPAIR_KSPLIT_MAX);
+    // lazy tails: no array lists its last rows as a matter of course -- the list is as long as the content makes it, and the device-side
+    // rule (repair_ksplit_eff) halves the segments when it is long
+    if (lazy_context(c) && !c->kn.lazy_ks_shape) return REPAIR_KSPLIT_MAX;
     const long long arrays = c->plan_arrays > 0 ? c->plan_arrays : n_arrays;
     const long long tail_rows = arrays * (REPAIR_WARM + 1 + REPAIR_GROUP);
     return tail_rows <= 1024 ? 32 : (tail_rows <= 2560 ? 16 : 8);
@@ -620,7 +644,7 @@ int repair_ksplit_for(const mca_hip_ctx *c, int n_arrays)
 // rows of one repair pass (the two-plane A rows of all listed groups may not fit the workspace budget at once)
 long long repair_pass_rows(const mca_hip_ctx *c, int n_arrays, int n_frames)
 {
-    const long long gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
+    const long long gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP + HIST_UNITS;     // (+ the history units of the lazy tails)
     const long long all = (long long)n_arrays * gpa * REPAIR_GROUP;
     long long cap = ws_max_bytes(c) / ((long long)2 * c->Kp * 2) / 128 * 128;
     // (the repair contraction always leaves REPAIR_KSPLIT partial maps: Cx is sized for the worst case, all rows listed --
@@ -632,7 +656,7 @@ long long repair_pass_rows(const mca_hip_ctx *c, int n_arrays, int n_frames)
 int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chunks)
 {
     const size_t nf = (size_t)n_arrays * n_frames, nc = (size_t)n_arrays * n_chunks;
-    const size_t ng = (size_t)n_arrays * ((n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP);
+    const size_t ng = (size_t)n_arrays * ((n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP + HIST_UNITS);     // (+ the history units of the lazy tails)
     if (nf > c->ws().adapt_frames) {
         if (c->ws().d_flags) (void)hipFree(c->ws().d_flags);
         c->ws().d_flags = nullptr; c->ws().adapt_frames = 0;
@@ -881,6 +905,8 @@ int check_stream_args(mca_hip_ctx *c, const float *pcm, long long array_stride, 
 
 extern "C" {
 
+static int settle_history(mca_hip_ctx *c, hipStream_t st);    // lazy tails: exact state from the kept history (defined with localise_impl)
+
 const char *mca_hip_version(void) { return "mcarray-hip 0.1.0 (gfx950)"; }
 
 const char *mca_hip_last_error(const mca_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -1038,6 +1064,11 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
     }
+    if (lazy_context(c)) {
+        for (int i = 0; i < 2; ++i)
+            if ((rc = zalloc((void **)&c->d_hist_pcm[i], na * c->M * HIST_SAMPLES * 4)) || (rc = zalloc((void **)&c->d_hist_C[i], na * HIST_FRAMES * c->Dp * 4)) ||
+                (rc = zalloc((void **)&c->d_ehist[i], na * c->D * 4))) { g_create_error = c->err; free_ctx(c); return rc; }
+    }
     if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->kn.fb_enabled) {
         if (hipHostMalloc((void **)&c->h_probe, 32, hipHostMallocDefault) == hipSuccess) std::memset(c->h_probe, 0, 32);
         else { c->h_probe = nullptr; (void)hipGetLastError(); }                    // (no page-locked memory: the mode never backs off)
@@ -1095,6 +1126,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     }
     HIP_TRY(c, hipMemsetAsync(c->d_silence, 0, na * 4, st));
     c->adapt_suspended = false; c->fb_state = 0; c->fb_left = 0; c->fb_backoff = 8;     // new streams: the adaptive mode starts afresh
+    c->hist_pending = false;                                                              // ... and no call owes the next one its last rows
     // the self-cleaning words of the adaptive path (a call that failed half way may have left some set)
     for (Workspace &w : c->lanes) {
         if (w.d_need) HIP_TRY(c, hipMemsetAsync(w.d_need, 0, w.adapt_groups * 4, st));
@@ -1153,6 +1185,11 @@ int mca_hip_state_save(mca_hip_ctx *c, void *blob, long long blob_bytes)
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
     if (!blob || blob_bytes < mca_hip_state_size(c)) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "state blob is NULL or smaller than mca_hip_state_size()");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->hist_pending) {                        // lazy tails: the blob holds the exact state, as the eager form's would
+        HIP_TRY(c, hipDeviceSynchronize());
+        const int rc = settle_history(c, nullptr);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipDeviceSynchronize());
     StateHeader h{STATE_MAGIC, STATE_VERSION, c->M, c->D, c->S, c->H, c->cfg.max_arrays, c->cfg.use_power_floor, delays_hash(c), c->gcc2_frames_done};
     unsigned char *out = static_cast<unsigned char *>(blob);
@@ -1182,6 +1219,7 @@ int mca_hip_state_load(mca_hip_ctx *c, const void *blob, long long blob_bytes)
         HIP_TRY(c, hipMemcpy(p.ptr, in, p.bytes, hipMemcpyHostToDevice)); in += p.bytes;
     }
     c->gcc2_frames_done = h.gcc2_frames_done;
+    c->hist_pending = false;                      // (a blob holds the exact state)
     return MCA_HIP_OK;
 }
 
@@ -1252,6 +1290,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         sa.no_phat = c->cfg.gcc_weighting == MCA_HIP_GCC_NONE ? 1 : 0;
         if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 1 && wave16_applies(c)) sa.unsure = c->ws().d_unsure;   // (adaptive coarse pass)
+        if (c->lazy_now) sa.hist_out = c->d_hist_pcm[c->hist_cur ^ 1];       // lazy tails: the call's last frames of PCM stay behind
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         if (c->n512) {
             // 512-sample frames: two frames of up to 8 channels per pass on the wave-level transform
@@ -1364,6 +1403,56 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
     return MCA_HIP_OK;
 }
 
+// Lazy tails (mca_internal.h, HIST_FRAMES): the repair of a call's last rows is left to the call that needs them.  Settling the debt --
+// for every consumer of the state that is not the next lazy call itself (an FP16X3 call of the same context, another array count,
+// state_save, a recorded graph): the previous call's last HIST_FRAMES rows of EVERY array are recomputed exactly from the kept PCM (the
+// repair pass's own kernels on a list of all history units) and the state becomes what the eager form would have left.
+static int settle_history(mca_hip_ctx *c, hipStream_t st)
+{
+    if (!c->hist_pending) return MCA_HIP_OK;
+    c->hist_pending = false;
+    const int n = c->hist_n, units = n * HIST_UNITS, rows = units * REPAIR_GROUP, cur = c->hist_cur;
+    Workspace &w = c->lanes[0];
+    if (!w.d_list || !w.d_need || !w.d_nlist || !w.d_Ax || !w.d_Cx) return fail(c, MCA_HIP_ERR_HIP, "lazy tails: the adaptive workspace is gone");
+    const int planes_before = c->a_planes;
+    set_call_planes(c, 2);
+    hipLaunchKernelGGL(k_hist_list, dim3((units + 255) / 256), dim3(256), 0, st, w.d_list, w.d_nlist, w.d_need, units);
+    StftPhatArgs sa{};
+    sa.pcm = c->d_hist_pcm[cur]; sa.array_stride = (long long)c->M * HIST_SAMPLES; sa.mic_stride = HIST_SAMPLES;
+    sa.M = c->M; sa.n_frames = HIST_FRAMES; sa.frame0 = 0; sa.fpb = REPAIR_GROUP; sa.total_frames = HIST_FRAMES;
+    sa.window = c->d_window; sa.A = w.d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
+    sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
+    sa.list = w.d_list; sa.n_list = w.d_nlist; sa.list0 = 0; sa.list_cap = units; sa.groups_per_array = HIST_UNITS;
+    sa.hist_in = c->d_hist_pcm[cur]; sa.hist_base = 0;
+    const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
+    int rc = launch_stft<_Float16>(c, sa, dim3(std::min(units, 512), 1), smem1, st);
+    if (!rc) {
+        const int cap = (rows + 127) / 128 * 128;
+        GemmArgs ga{};
+        ga.A = w.d_Ax; ga.B = c->d_B; ga.C = w.d_Cx; ga.Bt = c->d_Bt;
+        ga.rows = cap; ga.chunk_frames = cap; ga.total_frames = cap; ga.frame0 = 0;
+        ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = (long long)cap * c->Dp;
+        ga.n_list = w.d_nlist; ga.list0 = 0;
+        ga.repair_ksplit = repair_ksplit_for(c, n); ga.repair_items = c->kn.repair_items;
+        const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
+        const long long max_work = (long long)(cap / 128) * col_tiles * ga.repair_ksplit;
+        dim3 gg((unsigned)std::min<long long>(max_work, 768));
+        if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
+        RepairPatchArgs pp{};
+        pp.Cx = w.d_Cx; pp.pass_rows = cap; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit; pp.items = ga.repair_items;
+        pp.list = w.d_list; pp.n_list = w.d_nlist; pp.list0 = 0; pp.groups_per_array = HIST_UNITS; pp.need = w.d_need;
+        pp.C = w.d_C; pp.c_planes = 1; pp.c_plane_stride = 0; pp.n_frames = HIST_FRAMES; pp.Dp = c->Dp;
+        pp.hist_C = c->d_hist_C[cur]; pp.hist_base = 0;
+        hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min(rows, 2048)), dim3(128), 0, st, pp);
+        hipLaunchKernelGGL(k_hist_settle, dim3(n), dim3(std::max(round_up(c->D, 64), 64)), 0, st, c->d_ehist[cur], c->d_hist_C[cur], c->d_E[c->e_cur], w.d_nlist, c->D, c->Dp,
+                           0.8f, 1 - 0.8f);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, MCA_HIP_ERR_HIP, "lazy tails: a launch of the settling pass failed");
+    }
+    set_call_planes(c, planes_before);
+    return rc;
+}
+
 // the localisation stage of the arrays [c->a0, c->a0 + n_arrays) on the workspace of lane c->cur_lane; all pointers already
 // point at the lane's first array
 static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_stride, long long mic_stride,
@@ -1372,10 +1461,21 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     int rc;
     const size_t a0 = (size_t)c->a0;
     const bool adaptive = adaptive_applies(c, n_arrays, n_frames);
+    // Lazy tails: this call leaves the exact repair of its last rows to the next one (lazy), and repairs the previous call's last rows
+    // itself where one of its own first frames needs them (hist_valid).  Any other consumer of the state settles the debt first.
+    const bool lazy = adaptive && c->lazy_entry && !c->capturing && lazy_context(c) && c->a0 == 0 && n_frames >= 2 * SCAN_CHUNK && SCAN_CHUNK == 32;
+    const bool hist_valid = lazy && c->hist_pending && c->hist_n == n_arrays;
+    if (c->hist_pending && !hist_valid) {
+        if (c->capturing) return fail(c, MCA_HIP_ERR_HIP, "lazy tails: a recording found an unsettled state (mca_hip_graph_launch settles it first)");
+        if ((rc = settle_history(c, st))) return rc;
+    }
+    c->lazy_now = lazy;
     if (c->prec == MCA_HIP_SRP_ADAPTIVE) set_call_planes(c, adaptive ? 1 : 2);
     const int n_chunks = (n_frames + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    if (adaptive && (rc = ensure_adapt_workspace(c, n_arrays, n_frames, n_chunks))) return rc;
-    if ((rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st))) return rc;
+    if (adaptive && (rc = ensure_adapt_workspace(c, n_arrays, n_frames, n_chunks))) { c->lazy_now = false; return rc; }
+    rc = run_correlation_map(c, pcm, array_stride, mic_stride, n_arrays, n_frames, st);
+    c->lazy_now = false;
+    if (rc) return rc;
 
     const bool gate = c->cfg.use_power_floor != 0;
     time_begin(c, MCA_HIP_K_SCAN_PICK, st);
@@ -1401,6 +1501,9 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
         pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_from = c->ws().d_chunk_from; pa.last_vchunk = c->ws().d_last_vchunk; pa.stats = c->d_rstats;
         pa.unsure = wave16_applies(c) ? c->ws().d_unsure : nullptr;
+        pa.hist_base = n_arrays * gpa;
+        if (lazy) { pa.lazy = 1; pa.hist_C_out = c->d_hist_C[c->hist_cur ^ 1]; pa.e_hist_out = c->d_ehist[c->hist_cur ^ 1]; }
+        if (hist_valid) { pa.hist_valid = 1; pa.hist_C_in = c->d_hist_C[c->hist_cur]; pa.e_hist_in = c->d_ehist[c->hist_cur]; }
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
             c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
@@ -1443,7 +1546,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         time_begin(c, MCA_HIP_K_REPAIR, st);
         const long long pass_rows = repair_pass_rows(c, n_arrays, n_frames);
         const int pass_groups = (int)(pass_rows / REPAIR_GROUP);
-        const long long all_groups = (long long)n_arrays * gpa;
+        const long long all_groups = (long long)n_arrays * (gpa + (hist_valid ? HIST_UNITS : 0));     // (the list cannot be longer)
         set_call_planes(c, 2);
         for (long long g0 = 0; g0 < all_groups; g0 += pass_groups) {
             StftPhatArgs sa{};
@@ -1452,6 +1555,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             sa.window = c->d_window; sa.A = c->ws().d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
             sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
             sa.list = c->ws().d_list; sa.n_list = c->ws().d_nlist; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = gpa;
+            if (hist_valid) { sa.hist_in = c->d_hist_pcm[c->hist_cur]; sa.hist_base = n_arrays * gpa; }
             const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
             // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
             if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, 512), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
@@ -1470,6 +1574,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             pp.Cx = c->ws().d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit; pp.items = ga.repair_items;
             pp.list = c->ws().d_list; pp.n_list = c->ws().d_nlist; pp.list0 = (int)g0; pp.groups_per_array = gpa; pp.need = c->ws().d_need;
             pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames; pp.Dp = c->Dp;
+            if (hist_valid) { pp.hist_C = c->d_hist_C[c->hist_cur]; pp.hist_base = n_arrays * gpa; }
             hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);
         }
         set_call_planes(c, 1);
@@ -1488,6 +1593,8 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         HIP_TRY(c, hipGetLastError());
         c->adapt_frames_total += (unsigned long long)n_arrays * n_frames;
     }
+    if (lazy) { c->hist_cur ^= 1; c->hist_n = n_arrays; c->hist_pending = true; }
+    else c->hist_pending = false;                // (settled above, or consumed by an eager adaptive call: its own last frame was repaired)
     c->ws().last_a0 = c->a0; c->ws().last_arrays = n_arrays;
     return MCA_HIP_OK;
 }
@@ -1697,7 +1804,9 @@ int mca_hip_localise_frames_dev(mca_hip_ctx *c, const float *pcm, long long arra
     if (!doa_bin) return fail(c, MCA_HIP_ERR_INVALID_ARGUMENT, "doa_bin_dev is NULL");
     c->n_lanes_last = 1; c->cur_lane = 0; c->a0 = 0;
     adapt_policy_begin(c, n_arrays, n_frames);
+    c->lazy_entry = !c->host_call;
     rc = localise_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, (hipStream_t)stream);
+    c->lazy_entry = false;
     if (rc) return rc;
     c->last_arrays = n_arrays; c->last_frames = n_frames;
     c->e_cur ^= 1;
@@ -1747,7 +1856,9 @@ int mca_hip_process_frames_dev(mca_hip_ctx *c, const float *pcm, long long array
     if ((rc = ensure_bf_table(c))) return rc;
     c->n_lanes_last = 1; c->cur_lane = 0; c->a0 = 0;
     adapt_policy_begin(c, n_arrays, n_frames);
+    c->lazy_entry = !c->host_call;
     rc = localise_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_bin, doa_rad, prob, energy, (hipStream_t)stream);
+    c->lazy_entry = false;
     if (!rc) rc = separate_impl(c, pcm, array_stride, mic_stride, n_arrays, n_frames, doa_rad, out_pcm, (hipStream_t)stream, doa_bin);
     if (rc) return rc;
     c->last_arrays = n_arrays; c->last_frames = n_frames;
@@ -1840,6 +1951,10 @@ int mca_hip_graph_launch(mca_hip_graph *g, void *stream)
     mca_hip_ctx *c = g->c;
     if (!c) { g_create_error = "mca_hip_graph_launch: the context of this graph has been destroyed"; return MCA_HIP_ERR_INVALID_ARGUMENT; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (g->doa_bin && c->hist_pending) {          // lazy tails: a recording takes the state as exact
+        const int rc = settle_history(c, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     if (g->ws_gen != c->ws_gen) {
         // an eager call with more arrays / frames reallocated the workspace since the recording: the recorded kernels
         // would run on freed memory.  Make sure the workspace (still) fits this graph's shape, then record afresh.
@@ -1935,7 +2050,9 @@ int process_frames_host_impl(mca_hip_ctx *c, const SampleT *pcm, int n_arrays, i
         } else {
             HIP_TRY(c, hipMemcpy(d_pcm, pcm, n_pcm * 4, hipMemcpyHostToDevice));
         }
+        c->host_call = true;
         rc = mca_hip_localise_frames_dev(c, d_pcm, as, ms, n_arrays, n_frames, d_bin, d_rad, d_prob, d_en, nullptr);
+        c->host_call = false;
         if (!rc && out_pcm) rc = separate_frames_dev_bins(c, d_pcm, as, ms, n_arrays, n_frames, d_rad, d_out, nullptr, d_bin);
         if (rc) return rc;
         HIP_TRY(c, hipDeviceSynchronize());

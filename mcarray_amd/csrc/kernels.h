@@ -12,6 +12,8 @@ __global__ void k_scan_carry(ScanPickArgs p);
 template <int PL, int MODE> __global__ void k_scan_pick(ScanPickArgs p);   // PL: positions per lane of the peak pick (2 / 6 / 8, by D)
 template <int PL> __global__ void k_scan_repick(ScanPickArgs p);
 __global__ void k_repair_patch(RepairPatchArgs p);
+__global__ void k_hist_list(int *list, int *n_list, int *need, int n_units);      // lazy tails (round 5): settle_history
+__global__ void k_hist_settle(const float *e_hist, const float *hist_C, float *state, int *n_list, int D, int Dp, float mu, float omu);
 __global__ void k_gate(GateArgs p);
 __global__ void k_doa_fill(DoaFillArgs p);
 template <int CPW, int OCC> __global__ void k_beamform_ola(BeamformArgs p);

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     if (MODE == 1 && p.lookback > 0 && (int)blockIdx.x == p.n_chunks - 1 && d == 0) p.last_vchunk[a] = p.n_chunks - 1;
     // MODE 1: the array's last frame that advances the recursion (this chunk holds it) is always repaired
     int t_force = -1;
-    if (MODE == 1 && (int)blockIdx.x == last_vchunk) {
+    if (MODE == 1 && (int)blockIdx.x == last_vchunk && !p.lazy) {        // (lazy tails: the next call repairs this call's last rows if it needs them)
         const int u = t_start + lane;
         const unsigned long long m = __ballot(u < t_end && (!vc || vc[u] != 0));
         if (m) t_force = t_start + 63 - __clzll((long long)m);
@@ -647,6 +647,12 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                         if ((vmask >> (t - ts)) & 1u) E = iir_step(mu, E, omu, c8[i]);   // :134-140
                         if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
                         sEn[(t - ts) * Dl + d] = normalised_energy(E, mn, nd, nr);   // :155-156
+                        if (MODE == 1 && p.lazy) {
+                            // lazy tails: the coarse rows of the call's last HIST_FRAMES frames and the energies in front of them
+                            const int j = t - (p.n_frames - HIST_FRAMES);
+                            if (j >= 0) p.hist_C_out[((long long)a * HIST_FRAMES + j) * p.Dp + d] = c8[i];
+                            else if (j == -1) p.e_hist_out[(long long)a * D + d] = E;
+                        }
                     }
                 }
             }
@@ -688,14 +694,15 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 // the rows this frame's energy depends on: its own and those of the REPAIR_WARM frames before it that advanced
                 // the recursion (all of them without the gate, the voiced ones with it), 64 frames per step backwards
                 int remaining = REPAIR_WARM + 1, u_min = t;
-                for (int hi = t; hi >= 0 && remaining > 0; hi -= 64) {
+                const int u_lo = (p.hist_valid && !vc) ? -HIST_FRAMES : 0;         // lazy tails: the rows before the call are the previous call's last ones
+                for (int hi = t; hi >= u_lo && remaining > 0; hi -= 64) {
                     const int u = hi - 63 + lane;                        // lane 63 = frame hi
-                    const bool on = u >= 0 && (!vc || vc[u] != 0);
+                    const bool on = u >= u_lo && (u < 0 || !vc || vc[u] != 0);
                     const unsigned long long m = __ballot(on);
                     const int above = lane < 63 ? __popcll(m >> (lane + 1)) : 0;   // advancing frames after u in this window
                     const bool take = on && above < remaining;
                     if (take) {
-                        const int e = a * p.groups_per_array + u / REPAIR_GROUP;
+                        const int e = u >= 0 ? a * p.groups_per_array + u / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + u) / REPAIR_GROUP;
                         if (atomicExch(&p.need[e], 1) == 0) {
                             p.list[atomicAdd(p.n_list, 1)] = e;
                             atomicAdd(&p.stats[1], 1ull);
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                 if (lane == 0) {
                     // the second pick of this chunk restarts from the (coarse) start value of the chunk that holds the earliest of those rows
                     const int ci = a * p.n_chunks + (int)blockIdx.x;
-                    if (atomicMin(&p.chunk_from[ci], u_min / p.chunk) >= p.n_chunks) p.clist[atomicAdd(p.n_clist, 1)] = ci;   // the chunk's first flagged frame
+                    if (atomicMin(&p.chunk_from[ci], u_min < 0 ? -1 : u_min / p.chunk) >= p.n_chunks) p.clist[atomicAdd(p.n_clist, 1)] = ci;   // the chunk's first flagged frame (-1: from the history)
                     atomicAdd(&p.stats[0], 1ull);
                 }
             }
@@ -812,7 +819,17 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
             csum_rows(r0, C, [&](int i) { return (long long)(cprev * REPICK_B + i) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
             csum_rows(r1, C, [&](int i) { return (long long)min(t_start + i, te - 1) * p.Dp + d; }, p.c_planes, p.c_plane_stride);
             E = e1;
-            if (c_from < chunk) {
+            if (c_from < 0) {
+                // lazy tails: a flagged frame among the call's first REPAIR_WARM ones -- the walk starts in front of the PREVIOUS call's last
+                // HIST_FRAMES rows (patched where this call's repair pass recomputed them) from the energies that call left there
+                // (into the registers of the rows requested above: this is chunk 0, they are its own rows a second time)
+                E = p.e_hist_in[(long long)a * D + d];
+                static_assert(HIST_FRAMES <= REPICK_B, "the history rows reuse the previous chunk's registers");
+#pragma unroll
+                for (int j = 0; j < HIST_FRAMES; ++j) r0[j] = p.hist_C_in[((long long)a * HIST_FRAMES + j) * p.Dp + d];
+#pragma unroll
+                for (int j = 0; j < HIST_FRAMES; ++j) E = iir_step(mu, E, omu, r0[j]);
+            } else if (c_from < chunk) {
                 E = e0;
 #pragma unroll
                 for (int i = 0; i < REPICK_B; ++i) E = iir_step(mu, E, omu, r0[i]);     // (a whole chunk: it is not the array's last)
@@ -863,9 +880,14 @@ __global__ __launch_bounds__(128) void k_repair_patch(RepairPatchArgs p)
     for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
         const int g = r / REPAIR_GROUP, j = r - g * REPAIR_GROUP;
         const int e = p.list[p.list0 + g];
-        const int a = e / p.groups_per_array, f = (e - a * p.groups_per_array) * REPAIR_GROUP + j;
         if (j == 0 && threadIdx.x == 0) p.need[e] = 0;
-        if (f >= p.n_frames) continue;
+        // lazy tails: a row of the previous call's last frames goes into the history's own map (one plane), where k_scan_repick walks it
+        const bool hist = p.hist_C != nullptr && e >= p.hist_base;
+        const int eu = hist ? e - p.hist_base : e, upa = hist ? HIST_UNITS : p.groups_per_array;
+        const int a = eu / upa, f = (eu - a * upa) * REPAIR_GROUP + j;
+        if (f >= (hist ? HIST_FRAMES : p.n_frames)) continue;
+        float *drow = hist ? p.hist_C + ((long long)a * HIST_FRAMES + f) * p.Dp : p.C + ((long long)a * p.n_frames + f) * p.Dp;
+        const int zero_planes = hist ? 1 : p.c_planes;
         for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
         const float *src = p.Cx + (long long)r * p.Dp + c4 * 4;
         float4 v = *reinterpret_cast<const float4 *>(src);
@@ -882,11 +904,38 @@ __global__ __launch_bounds__(128) void k_repair_patch(RepairPatchArgs p)
             const float4 w = *reinterpret_cast<const float4 *>(src + z * plane_x_stride);
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
-        float *dst = p.C + ((long long)a * p.n_frames + f) * p.Dp + c4 * 4;
+        float *dst = drow + c4 * 4;
         *reinterpret_cast<float4 *>(dst) = v;
-        for (int pl = 1; pl < p.c_planes; ++pl) *reinterpret_cast<float4 *>(dst + pl * p.c_plane_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pl = 1; pl < zero_planes; ++pl) *reinterpret_cast<float4 *>(dst + pl * p.c_plane_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+}
+
+// --------------------------------------------------------------------------------------
+// Lazy tails, settling the debt (api.hip, settle_history): a consumer of the state that is not the lazy path itself -- an FP16X3 call of
+// the same context, state_save, a recorded graph -- needs the EXACT energies the eager form would have left.  k_hist_list puts every
+// history unit of the arrays on the repair list; the list-mode analysis, the repair contraction and k_repair_patch then recompute the
+// previous call's last HIST_FRAMES rows into the history map; k_hist_settle walks them from the energies in front of them.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hist_list(int *list, int *n_list, int *need, int n_units)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_units) { list[i] = i; need[i] = 1; }
+    if (i == 0) *n_list = n_units;
+}
+// grid (arrays), >= D threads: E = 0.8f E + 0.2f C over the HIST_FRAMES exact rows (:134-140), the state a call's repaired last frame leaves
+__global__ __launch_bounds__(512) void k_hist_settle(const float *e_hist, const float *hist_C, float *state, int *n_list, int D, int Dp, float mu, float omu)
+{
+    const int a = blockIdx.x, d = threadIdx.x;
+    if (a == 0 && d == 0) *n_list = 0;                                  // (no second pick ran to empty the list)
+    if (d >= D) return;
+    float E = e_hist[(long long)a * D + d];
+    float h[HIST_FRAMES];
+#pragma unroll
+    for (int j = 0; j < HIST_FRAMES; ++j) h[j] = hist_C[((long long)a * HIST_FRAMES + j) * Dp + d];
+#pragma unroll
+    for (int j = 0; j < HIST_FRAMES; ++j) E = iir_step(mu, E, omu, h[j]);
+    state[(long long)a * D + d] = E;
 }
 
 // --------------------------------------------------------------------------------------

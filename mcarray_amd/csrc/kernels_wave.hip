@@ -494,22 +494,27 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
             f_end = min(f_begin + len, f_last);
         }
         long long row_base = (long long)a * p.n_frames;     // A row of frame f = row_base + f
+        bool hist_unit = false;                                // list mode, lazy tails: a unit of the PREVIOUS call's last frames (StftPhatArgs::hist_in)
         if (p.list) {
             const int e = li == p.list0 + (int)blockIdx.x ? e_first : p.list[li];
-            a = e / p.groups_per_array;
-            const int g_begin = (e - a * p.groups_per_array) * REPAIR_GROUP;
+            hist_unit = p.hist_in != nullptr && e >= p.hist_base;
+            const int eu = hist_unit ? e - p.hist_base : e, upa = hist_unit ? HIST_UNITS : p.groups_per_array;
+            a = eu / upa;
+            const int g_begin = (eu - a * upa) * REPAIR_GROUP;
             row_base = (long long)(li - p.list0) * REPAIR_GROUP - g_begin;
-            f_begin = g_begin + wave; f_end = min(f_begin + 1, p.n_frames);
+            f_begin = g_begin + wave; f_end = min(f_begin + 1, hist_unit ? HIST_FRAMES : p.n_frames);
         }
         if (f_begin >= f_end) {
             if (p.queue) break;                     // (cannot happen: every listed run holds a frame)
             continue;
         }
-        const float *base = p.pcm + (long long)a * p.array_stride + lane;
+        const float *base = hist_unit ? p.hist_in + (long long)a * MT * HIST_SAMPLES + lane : p.pcm + (long long)a * p.array_stride + lane;
+        const long long mstride = hist_unit ? (long long)HIST_SAMPLES : p.mic_stride;
+        const int fr0 = hist_unit ? 0 : p.frame0;
         float xa[16], xb[16];
         auto load_pair = [&](int f, int pr) {
-            const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)(p.frame0 + f) * FFT_H;
-            const float *pb = pa + p.mic_stride;
+            const float *pa = base + (long long)(2 * pr) * mstride + (long long)(fr0 + f) * FFT_H;
+            const float *pb = pa + mstride;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
         };
@@ -535,6 +540,20 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
                 for (int i = 1; i < 15; i += 2) { oa = or3(oa, __float_as_uint(xa[i]), __float_as_uint(xa[i + 1])); ob = or3(ob, __float_as_uint(xb[i]), __float_as_uint(xb[i + 1])); }
                 oa |= __float_as_uint(xa[15]); ob |= __float_as_uint(xb[15]);
                 const bool alive_a = __any((oa << 1) != 0), alive_b = __any((ob << 1) != 0);
+                if (p.hist_out) {
+                    // lazy tails: the call's last HIST_FRAMES frames of PCM stay behind for the next call's repair pass (frame j of the
+                    // history = samples [512 j, 512 j + 1024) of a channel's HIST_SAMPLES)
+                    const int j = p.frame0 + f - (p.total_frames - HIST_FRAMES);
+                    if (j >= 0) {
+                        float *ha = p.hist_out + ((long long)a * MT + 2 * pr) * HIST_SAMPLES + j * FFT_H + lane;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { ha[64 * i] = xa[i]; ha[HIST_SAMPLES + 64 * i] = xb[i]; }
+                        if (j == HIST_FRAMES - 1) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { ha[FFT_H + 64 * i] = xa[8 + i]; ha[HIST_SAMPLES + FFT_H + 64 * i] = xb[8 + i]; }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
                 if (POWER) {

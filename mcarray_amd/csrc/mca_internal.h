@@ -37,6 +37,13 @@ constexpr int REPAIR_WARM = MCA_REPAIR_WARM;   // exact rows recomputed BEFORE a
                                   // 16 and with 24 rows -- 61 picks on 43 frames, all 43 ties at the parity bar's level -- profiles/
                                   // r04_adaptive_check.json / _warm24.json; 24 rows cost +12 % / +30 % repair time at 8 x 4096 / 128 x 256.)
 constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mode pass of a k_stft_phat workgroup
+// Lazy tails (round 5; ADAPTIVE, ungated, the wave-per-run analysis): a call does NOT recompute its last REPAIR_WARM + 1 rows exactly for the
+// state it hands over.  It keeps what the NEXT call needs to do so -- the last HIST_FRAMES frames of PCM (HIST_SAMPLES per channel), their
+// coarse map rows and the energies in front of them -- and the next call lists them as repair units only when one of its first
+// REPAIR_WARM frames is flagged (a few arrays per call instead of all of them: 2 560 of the 3 492 rows a 128 x 256 call recomputed).
+// History units are numbered behind the call's own: hist_base + array * HIST_UNITS + u, frames 4 u .. 4 u + 3 of the history.
+constexpr int HIST_FRAMES = REPAIR_WARM, HIST_UNITS = HIST_FRAMES / REPAIR_GROUP, HIST_SAMPLES = (HIST_FRAMES + 1) * 512;
+static_assert(HIST_FRAMES % REPAIR_GROUP == 0, "history = whole repair units");
 
 struct StftPhatArgs {
     const float *pcm;
@@ -55,6 +62,9 @@ struct StftPhatArgs {
     // list mode (k_stft_phat only; the repair pass of the adaptive SRP precision): workgroup b takes the REPAIR_GROUP frames of
     // list[list0 + b] = array * groups_per_array + group and writes A rows b * REPAIR_GROUP ...; b >= *n_list - list0 exits
     const int *list; const int *n_list; int list0, list_cap, groups_per_array;   // list_cap: groups of this pass at most
+    // lazy tails (see HIST_FRAMES): the coarse launch keeps the call's last HIST_FRAMES frames of PCM in hist_out [arrays][M][HIST_SAMPLES];
+    // the list-mode launch of the NEXT call reads the units >= hist_base from hist_in (the same layout)
+    float *hist_out; const float *hist_in; int hist_base;
     const unsigned short *mrank; int n_merged;   // k_stft_phat_wave, merged index (ULA, one fp16 plane): rank of the product m = k (j - i)
                              // among the n_merged distinct ones, [(M - 1) * 512 + 1]; NULL: per-group index g * 513 + k
     int no_phat;             // 1: gcc_weighting NONE -- the pair products of the spectra themselves (k_stft_phat_wave, fp32 rows only)
@@ -176,6 +186,14 @@ struct ScanPickArgs {
     int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
     unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
     const unsigned char *unsure;  // [arrays][n_frames] or NULL: frames the coarse analysis could not vouch for (StftPhatArgs::unsure): flagged with their six successors
+    // lazy tails (see HIST_FRAMES).  lazy: the call's last frame is not flagged for the state's sake; k_scan_pick leaves the coarse rows of
+    // the last HIST_FRAMES frames in hist_C_out [arrays][HIST_FRAMES][Dp] and the energies in front of them in e_hist_out [arrays][D].
+    // hist_valid: the previous call did so (hist_C_in, e_hist_in): a flagged frame t < REPAIR_WARM lists the history units its rows
+    // t - REPAIR_WARM .. -1 live in (numbered from hist_base), and k_scan_repick starts chunk 0 from e_hist_in over the history rows
+    // (chunk_from = -1).
+    int lazy, hist_valid, hist_base;
+    float *hist_C_out, *e_hist_out;
+    const float *hist_C_in, *e_hist_in;
 };
 
 // The repair contraction runs on however many rows the coarse pass listed (a device-side count): the K range is what
@@ -208,6 +226,7 @@ struct RepairPatchArgs {
     float *C;                // [c_planes][arrays][n_frames][Dp]: plane 0 takes the exact row, the others zeros
     int c_planes; long long c_plane_stride;
     int n_frames, Dp;
+    float *hist_C; int hist_base;   // lazy tails: the rows of the units >= hist_base go to hist_C [arrays][HIST_FRAMES][Dp] (one plane)
 };
 
 struct GateArgs {

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5: lazy tails (shipped) against every call repairing its own last rows (MCA_HIP_ADAPT_LAZY=0): the bench line's headline, the literal configs[2] call and the repair spread
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+for lazy in 0 1 0 1; do
+  MCA_HIP_ADAPT_LAZY=$lazy python bench.py --steps 100 --warmup 20 --cpu-frames 0 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
+  python - $lazy <<PY
+import json,sys
+d=json.load(open('/tmp/ab.json'))
+print('lazy %s  headline %6.2f M frames/s  %.4f ms  ' % (sys.argv[1], d['value']/1e6, d['ms_per_step']), {k: round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items() if v['launches']}, ' repair rows', d['repair']['recomputed_fraction'])
+s=d['config']['single_stream_4096']; print('        1 x 4096 per call: %.4f ms (graph replay %.4f)' % (s['ms_per_call'], s['graph_replay']['ms_per_call']))
+for sp in d['repair_spread']: print('        %-78s %.4f ms per 32768 frames  %.3f x  repair %.3f ms  recomputed %.4f' % (sp['input'][:78], sp['ms_per_32768_frames'], sp['vs_headline'], sp['repair_ms'], sp['recomputed_fraction']))
+PY
+done

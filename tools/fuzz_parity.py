@@ -1,6 +1,7 @@
 """Randomised parity sweep of the stream API against the CPU oracle (a one-off check, not part of the test suite):
 random channel counts, geometries, frame lengths, frame counts, DOA grids, source counts, SRP precisions, chunked calls.
-usage (GPU box): python tools/fuzz_parity.py [cases] [seed]"""
+usage (GPU box): python tools/fuzz_parity.py [cases] [seed] [fp32|fp16x3|fp16|adaptive|lazy]
+(lazy: 4 / 8 microphones through the device-pointer entry point in several calls per stream -- the form lazy tails apply to)"""
 import os
 import sys
 
@@ -55,7 +56,27 @@ def dump_case(fs, N, xs, step, S, gate, pcm, a, t, cut, r, o, P):
             break
 
 
-def main(cases, seed, only_prec=None, adaptive_shapes=False):
+def dev_stream(ctx, pcm, sizes, hop, S):
+    """the stream through mca_hip_process_frames_dev in consecutive calls of sizes[i] frames (device pointers: the form lazy tails apply to)"""
+    import torch
+    dev = torch.device("cuda:0")
+    A = pcm.shape[0]
+    parts, t0 = {"bin": [], "energy": [], "out": []}, 0
+    for Fi in sizes:
+        x = torch.from_numpy(np.ascontiguousarray(pcm[:, :, t0 * hop:(t0 + Fi + 1) * hop])).to(dev)
+        b = torch.empty(A, Fi, S, dtype=torch.int32, device=dev)
+        r = torch.empty(A, Fi, S, dtype=torch.float32, device=dev)
+        q = torch.empty(A, Fi, S, dtype=torch.float32, device=dev)
+        e = torch.empty(A, Fi, ctx.D, dtype=torch.float32, device=dev)
+        o = torch.empty(A, S, Fi * hop, dtype=torch.float32, device=dev)
+        ctx.process_frames_dev(x, Fi, b, r, q, e, o)
+        torch.cuda.synchronize()
+        parts["bin"].append(b.cpu().numpy()); parts["energy"].append(e.cpu().numpy()); parts["out"].append(o.cpu().numpy())
+        t0 += Fi
+    return {k: np.concatenate(v, axis=2 if k == "out" else 1) for k, v in parts.items()}
+
+
+def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False):
     rng = np.random.default_rng(seed)
     bad = 0
     n_adaptive = n_ties = n_abs = 0
@@ -76,7 +97,17 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False):
             M = int(rng.choice([3, 3, 4, 5, 8, 8, 16]))
             xs = (0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))
             fs, N, gate, F = 48000, 1024, False, int(rng.integers(64, 200))
-        pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(rng.uniform(-80, 80)), fs, (F + 1) * N // 2, int(rng.integers(1, 1 << 30)))
+        sizes = None
+        if lazy:                                                     # lazy tails: 4 / 8 microphones, device pointers, calls of >= 64 frames (and a short one now and then)
+            M = int(rng.choice([4, 8, 8]))
+            xs = (0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))
+            S = int(rng.choice([1, 1, 2]))
+            sizes = [int(rng.choice([64, 65, 96, 127, 160, 16])) for _ in range(int(rng.integers(2, 6)))]
+            F = sum(sizes)
+            os.environ["MCA_HIP_ADAPT_TAU_SCALE"] = str(int(rng.choice([1, 10, 40])))
+            os.environ["MCA_HIP_ADAPT_MIN_ROWS"] = "64"              # every call of >= 64 frames is an adaptive one, also of a single array
+        pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(rng.uniform(-80, 80)), fs, (F + 1) * N // 2, int(rng.integers(1, 1 << 30)),
+                                                  **({"snr_db": float(rng.choice([30.0, 10.0, 3.0]))} if lazy else {}))
                         for _ in range(A)]).astype(np.float32)
         tag = "case %d: M=%d %s fs=%d N=%d step=%.1f S=%d A=%d F=%d prec=%d gate=%d" % (case, M, "ula" if ula else "irr", fs, N, step, S, A, F, prec, gate)
         if os.environ.get("MCA_FUZZ_ONLY") and case not in [int(x) for x in os.environ["MCA_FUZZ_ONLY"].split(",")]:
@@ -88,7 +119,10 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False):
             ctx.reset_timing()
             cut = int(rng.integers(0, F)) if F > 1 and rng.integers(0, 2) else 0
             hop = N // 2
-            if cut:
+            if sizes:
+                cut = 0
+                r = dev_stream(ctx, pcm, sizes, hop, S)
+            elif cut:
                 ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * hop], want_energy=True)
                 rb = ctx.process_frames_host(pcm[:, :, cut * hop:], want_energy=True)
                 r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out")}
@@ -124,7 +158,7 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False):
             if st and st["frames"]:
                 n_adaptive += 1
             n_ties += ties
-            print("ok  ", tag, "ties", ties, "cut", cut, "repair", st)
+            print("ok  ", tag, "ties", ties, "cut", sizes if sizes else cut, "repair", st)
             ctx.close()
         except Exception as e:  # noqa: BLE001
             bad += 1
@@ -136,5 +170,6 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False):
 
 
 if __name__ == "__main__":
-    only = {"fp32": api.SRP_FP32, "fp16x3": api.SRP_FP16X3, "fp16": api.SRP_FP16, "adaptive": api.SRP_ADAPTIVE}.get(sys.argv[3]) if len(sys.argv) > 3 else None
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1, only, len(sys.argv) > 4) else 0)
+    only = {"fp32": api.SRP_FP32, "fp16x3": api.SRP_FP16X3, "fp16": api.SRP_FP16, "adaptive": api.SRP_ADAPTIVE, "lazy": api.SRP_ADAPTIVE}.get(sys.argv[3]) if len(sys.argv) > 3 else None
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1, only, len(sys.argv) > 4,
+                       lazy=len(sys.argv) > 3 and sys.argv[3] == "lazy") else 0)
