@@ -297,11 +297,13 @@ def repair_spread(args, dev, stream, local_rank, headline_ms):
         torch.cuda.synchronize()
         nl, ms = ctx.get_timing(api.K_REPAIR)
         rs = ctx.repair_stats() if args.precision == "adaptive" else {"frames": 0, "flagged": 0, "recomputed": 0}
+        rc = ctx.repair_columns() if args.precision == "adaptive" else {"candidate_columns": 0, "whole_row_frames": 0}
         ctx.set_timing(False)
         ms_step = e / n * 1e3 * (8 * 4096) / (A * F)
         out.append({"input": name, "arrays": A, "frames": F, "value": A * F * n / e, "unit": "frames/s", "ms_per_32768_frames": ms_step,
                     "vs_headline": headline_ms / ms_step, "repair_ms": ms / max(1, nl), "flagged_fraction": rs["flagged"] / max(1, rs["frames"]),
-                    "recomputed_fraction": rs["recomputed"] / max(1, rs["frames"])})
+                    "recomputed_fraction": rs["recomputed"] / max(1, rs["frames"]),
+                    "columns_per_flagged_frame": rc["candidate_columns"] / max(1, rs["flagged"]), "whole_row_frames": rc["whole_row_frames"]})
         ctx.close()
         del pcm, b, r, q, o
     return out
@@ -421,8 +423,12 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
     repair = None
     if args.precision == "adaptive":
         rs = ctx.repair_stats()
+        rc = ctx.repair_columns()
         repair = dict(rs, flagged_fraction=rs["flagged"] / max(1, rs["frames"]), recomputed_fraction=rs["recomputed"] / max(1, rs["frames"]),
-                      note="frames whose peak pick was repeated on exactly recomputed rows / rows recomputed (includes the last frame of every array and call)")
+                      columns_per_flagged_frame=rc["candidate_columns"] / max(1, rs["flagged"]), whole_row_frames=rc["whole_row_frames"],
+                      note="frames whose peak pick was repeated on exactly recomputed values / rows the exact analysis was run for; the exact contraction "
+                           "runs at the candidate columns of the flagged frames (of D = 361; whole_row_frames took all of them).  Device-pointer calls "
+                           "leave the exact repair of their last 16 rows to the next call (lazy tails): no frame is flagged for the state's sake")
     # per-kernel table: a separate pass with every group bracketed (outside the timed region)
     table_steps = max(1, min(args.steps, 50))
     ctx.set_timing(True)

@@ -436,6 +436,12 @@ int mca_hip_reset_timing(mca_hip_ctx *ctx);
  * reference has no counterpart (it computes every pair and delay in double, SteeringBeamforming.cpp:104-130). */
 int mca_hip_get_repair_stats(mca_hip_ctx *ctx, unsigned long long *frames, unsigned long long *flagged_frames,
                              unsigned long long *recomputed_frames);
+/* ... and how much of those rows was recomputed (round 5, candidate columns): the exact contraction runs at the delays a flagged
+ * frame's picks can be among -- the positions whose coarse energy reaches the lowest value the exact picks can have, plus the two
+ * delays either side that feed the sign / median chain of SteeringBeamforming.cpp:159-173 -- instead of at all D of them.
+ * candidate_columns: their number summed over the flagged frames; whole_row_frames: the flagged frames that took every delay
+ * (no lower bound from the coarse row, a frame repeated for the carried state's sake, a row the coarse analysis could not vouch for). */
+int mca_hip_get_repair_columns(mca_hip_ctx *ctx, unsigned long long *candidate_columns, unsigned long long *whole_row_frames);
 
 /* library version string */
 const char *mca_hip_version(void);

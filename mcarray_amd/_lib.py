@@ -172,6 +172,7 @@ SYMBOLS = [
     ("mca_hip_host_register", C.c_int, [C.c_void_p, C.c_longlong]),
     ("mca_hip_host_unregister", C.c_int, [C.c_void_p]),
     ("mca_hip_get_repair_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    ("mca_hip_get_repair_columns", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     ("mca_hip_version", C.c_char_p, []),
 ]
 

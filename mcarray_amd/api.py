@@ -296,6 +296,12 @@ class Context:
         self._check(self._lib.mca_hip_get_repair_stats(self.h, C.byref(a), C.byref(b), C.byref(c_)))
         return {"frames": a.value, "flagged": b.value, "recomputed": c_.value}
 
+    def repair_columns(self):
+        """SRP_ADAPTIVE: dict(candidate_columns, whole_row_frames) since the last reset_timing() (mca_hip_get_repair_columns)"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self._lib.mca_hip_get_repair_columns(self.h, C.byref(a), C.byref(b)))
+        return {"candidate_columns": a.value, "whole_row_frames": b.value}
+
     def get_timing(self, kernel_id):
         n = C.c_int(0)
         ms = C.c_double(0)

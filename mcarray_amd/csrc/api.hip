@@ -47,6 +47,8 @@ struct Knobs {
     bool force_generic = false;        // MCA_HIP_FORCE_GENERIC: the any-length kernels at N = 1024 too (parity test of both)
     bool scan_carry = false;           // MCA_HIP_SCAN_CARRY / cfg.scan_carry
     bool lazy_ks_shape = false;        // (measurement) MCA_HIP_LAZY_KS_SHAPE: the repair contraction's K segments by the call's shape also with lazy tails
+    bool cand = true;                  // (measurement) MCA_HIP_CAND=0: whole rows for every listed unit (k_srp_gemm_repair + k_repair_patch, round 4)
+    int cand_grid = 512;               // (measurement) MCA_HIP_CAND_GRID: workgroups of k_srp_cand
     bool lazy_tails = true;            // MCA_HIP_ADAPT_LAZY=0: every adaptive call repairs its own last rows for the state it hands over (round 4)
     // measurement only (-DMCA_MEASURE)
     bool gemm_ks2 = false;             // MCA_HIP_GEMM_KS2: two K halves for 16 384 ... 32 767 rows (round 4) instead of four quarters
@@ -81,7 +83,7 @@ struct Workspace {
     float *d_part = nullptr, *d_estart = nullptr; int *d_nv = nullptr; size_t scan_ws_chunks = 0;
     float *d_power = nullptr; unsigned char *d_voiced = nullptr; float *d_power_out = nullptr; size_t gate_frames = 0;
     // ADAPTIVE: flags, repair list
-    unsigned char *d_flags = nullptr; int *d_chunk_from = nullptr, *d_list = nullptr, *d_need = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
+    unsigned char *d_flags = nullptr; int *d_chunk_from = nullptr, *d_list = nullptr, *d_need = nullptr; unsigned *d_umask = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
     unsigned char *d_unsure = nullptr;                // 16 microphones: frames whose DC / Nyquist bin the coarse analysis could not vouch for (StftPhatArgs::unsure)
     int *d_nlist = nullptr, *d_last_vchunk = nullptr; size_t lastv_arrays = 0;
     int last_a0 = 0, last_arrays = 0;                 // the arrays this lane ran in the last call (mca_hip_copy_gate)
@@ -89,7 +91,7 @@ struct Workspace {
     {
         auto F = [](void *q) { if (q) (void)hipFree(q); };
         F(d_A); F(d_Ax); F(d_C); F(d_Cx); F(d_part); F(d_estart); F(d_nv); F(d_power); F(d_voiced); F(d_power_out);
-        F(d_flags); F(d_chunk_from); F(d_list); F(d_need); F(d_nlist); F(d_last_vchunk); F(d_unsure);
+        F(d_flags); F(d_chunk_from); F(d_list); F(d_need); F(d_umask); F(d_nlist); F(d_last_vchunk); F(d_unsure);
         *this = Workspace();
     }
 };
@@ -272,6 +274,8 @@ Knobs read_knobs(const mca_hip_config &cfg)
     // measurement only: constants unless the library was built with -DMCA_MEASURE
     k.no_merge = measure_env("MCA_HIP_NO_MERGE") != nullptr;
     k.repair_items = (int)geti(measure_env("MCA_HIP_REPAIR_ITEMS"), 768);
+    k.cand = geti(measure_env("MCA_HIP_CAND"), 1) != 0;
+    k.cand_grid = (int)geti(measure_env("MCA_HIP_CAND_GRID"), 512);
     k.stft_wg = measure_env("MCA_HIP_STFT_WG") != nullptr;
     k.bf_ola = measure_env("MCA_HIP_BF_OLA") != nullptr;
     k.bf_occ2 = measure_env("MCA_HIP_BF_OCC2") != nullptr;
@@ -680,7 +684,11 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
         c->ws().d_list = c->ws().d_need = nullptr; c->ws().adapt_groups = 0;
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_list, ng * 4));
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_need, ng * 4));
-        HIP_TRY(c, hipMemset(c->ws().d_need, 0, ng * 4));                 // test-and-set words; released by k_repair_patch
+        HIP_TRY(c, hipMemset(c->ws().d_need, 0, ng * 4));                 // test-and-set words; released by k_repair_patch / k_scan_repick
+        if (c->ws().d_umask) (void)hipFree(c->ws().d_umask);
+        c->ws().d_umask = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_umask, ng * (c->Dp / 32) * 4));
+        HIP_TRY(c, hipMemset(c->ws().d_umask, 0, ng * (c->Dp / 32) * 4));   // candidate columns per unit; cleared by k_scan_repick
         HIP_TRY(c, hipDeviceSynchronize());
         c->ws().adapt_groups = ng; ++c->ws_gen;
     }
@@ -1059,7 +1067,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         (rc = zalloc((void **)&c->d_doa[0], na * 4)) || (rc = zalloc((void **)&c->d_doa[1], na * 4)) ||
         (rc = zalloc((void **)&c->d_vdone[0], na * 8)) || (rc = zalloc((void **)&c->d_vdone[1], na * 8)) ||
         (rc = zalloc((void **)&c->d_silence, na * 4)) || (rc = zalloc((void **)&c->d_g2_post0, na * 4)) ||
-        (rc = zalloc((void **)&c->d_rstats, 16)) || (rc = zalloc((void **)&c->d_queue, 64)) ||
+        (rc = zalloc((void **)&c->d_rstats, 32)) || (rc = zalloc((void **)&c->d_queue, 64)) ||
         (rc = zalloc((void **)&c->d_E64[0], c->D * 8)) || (rc = zalloc((void **)&c->d_E64[1], c->D * 8)) ||
         (rc = zalloc((void **)&c->d_res, (2 * MCA_MAX_SOURCES + 1) * 8)) || (rc = zalloc((void **)&c->d_bins, MCA_MAX_SOURCES * 4))) {
         g_create_error = c->err; free_ctx(c); return rc;
@@ -1130,6 +1138,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     // the self-cleaning words of the adaptive path (a call that failed half way may have left some set)
     for (Workspace &w : c->lanes) {
         if (w.d_need) HIP_TRY(c, hipMemsetAsync(w.d_need, 0, w.adapt_groups * 4, st));
+        if (w.d_umask) HIP_TRY(c, hipMemsetAsync(w.d_umask, 0, w.adapt_groups * (c->Dp / 32) * 4, st));
         if (w.d_chunk_from) HIP_TRY(c, hipMemsetAsync(w.d_chunk_from, 0x7f, w.adapt_chunks * 4, st));
         if (w.d_nlist) HIP_TRY(c, hipMemsetAsync(w.d_nlist, 0, 16, st));
     }
@@ -1504,6 +1513,10 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         pa.hist_base = n_arrays * gpa;
         if (lazy) { pa.lazy = 1; pa.hist_C_out = c->d_hist_C[c->hist_cur ^ 1]; pa.e_hist_out = c->d_ehist[c->hist_cur ^ 1]; }
         if (hist_valid) { pa.hist_valid = 1; pa.hist_C_in = c->d_hist_C[c->hist_cur]; pa.e_hist_in = c->d_ehist[c->hist_cur]; }
+        // candidate columns where whole-row frames are the exception: lazy calls (no frame is repeated for the state's sake) of contexts
+        // whose coarse analysis marks no unsure rows, one source (wave_candidates bounds the first pick); a unit that wants every column
+        // costs k_srp_cand the whole steering table
+        if (c->kn.cand && lazy && !pa.unsure && c->S == 1 && c->Dp / 32 <= CAND_WORDS_MAX) { pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32; }
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
             c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
@@ -1559,6 +1572,18 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
             // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
             if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, 512), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
+            if (pa.umask) {
+                // candidate columns: the exact values where the flagged frames need them, straight into the map (no partial maps, no patch)
+                CandArgs ca{};
+                ca.A = c->ws().d_Ax; ca.B = c->d_B; ca.Kp = c->Kp; ca.Dp = c->Dp; ca.a_row_elems = c->a_row_elems;
+                ca.list = c->ws().d_list; ca.n_list = c->ws().d_nlist; ca.list0 = (int)g0; ca.pass_rows = (int)pass_rows;
+                ca.umask = c->ws().d_umask; ca.umask_words = pa.umask_words; ca.groups_per_array = gpa; ca.n_frames = n_frames;
+                ca.C = c->ws().d_C; ca.c_planes = c->ws().c_planes; ca.c_plane_stride = c->ws().c_plane;
+                if (hist_valid) { ca.hist_C = c->d_hist_C[c->hist_cur]; ca.hist_base = n_arrays * gpa; }
+                const long long max_items = pass_rows / REPAIR_GROUP * CAND_SLOTS;
+                hipLaunchKernelGGL(k_srp_cand, dim3((unsigned)std::min<long long>(max_items, std::max(1, c->kn.cand_grid))), dim3(1024), 0, st, ca);
+                continue;
+            }
             GemmArgs ga{};
             ga.A = c->ws().d_Ax; ga.B = c->d_B; ga.C = c->ws().d_Cx; ga.Bt = c->d_Bt;
             ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
@@ -1610,6 +1635,18 @@ int mca_hip_get_repair_stats(mca_hip_ctx *c, unsigned long long *frames, unsigne
     if (frames) *frames = c->adapt_frames_total;
     if (flagged_frames) *flagged_frames = st[0];
     if (recomputed_frames) *recomputed_frames = st[1] * REPAIR_GROUP;
+    return MCA_HIP_OK;
+}
+
+int mca_hip_get_repair_columns(mca_hip_ctx *c, unsigned long long *candidate_columns, unsigned long long *whole_row_frames)
+{
+    if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    unsigned long long st[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpy(st, c->d_rstats, sizeof(st), hipMemcpyDeviceToHost));
+    if (candidate_columns) *candidate_columns = st[2];
+    if (whole_row_frames) *whole_row_frames = st[3];
     return MCA_HIP_OK;
 }
 
@@ -2423,7 +2460,7 @@ int mca_hip_reset_timing(mca_hip_ctx *c)
     if (!c) return MCA_HIP_ERR_INVALID_ARGUMENT;
     int rc = drain_events(c);
     for (int i = 0; i < MCA_HIP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_launches[i] = 0; }
-    if (c->d_rstats) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipMemset(c->d_rstats, 0, 16)); }
+    if (c->d_rstats) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipMemset(c->d_rstats, 0, 32)); }
     c->adapt_frames_total = 0;
     c->fb_groups_prev = 0; c->fb_frames_prev = 0; c->fb_seq_seen = c->fb_calls;   // (the reports in flight belong to the old totals)
     // ... including a probe's, if the back-off is waiting for one: that report will never count as fresh, so the wait ends here

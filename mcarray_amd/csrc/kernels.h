@@ -33,6 +33,7 @@ template <bool SPLIT, int BN> __global__ void k_srp_gemm_f16(GemmArgs p);
 template <bool SPLIT> __global__ void k_srp_gemm_f16_v2(GemmArgs p);
 __global__ void k_srp_gemm_f16_v3(GemmArgs p);      // one plane, v_mfma_f32_16x16x32_f16
 template <int BN> __global__ void k_srp_gemm_repair(GemmArgs p);
+__global__ void k_srp_cand(CandArgs p);
 
 template <typename T> struct C2;
 template <typename T>

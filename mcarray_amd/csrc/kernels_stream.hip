@@ -551,6 +551,73 @@ __device__ __forceinline__ bool wave_pick_pl(const float *En, int D, int S, floa
     return sens;
 }
 
+// The candidate columns of a flagged frame (CandArgs in mca_internal.h has the argument), by one wave, into cm[words] (LDS, one bit per
+// column).  full: every column (a frame flagged for the state's sake or on an unsure row).  Returns whether every column was taken.
+// The lower bound v of the exact S-th pick comes from GUARANTEED peaks: with every first difference within tau of zero taken as of
+// either sign, the median-filtered sign chain (:161-165) has a lowest and a highest possible value at every position; where it is
+// pinned to "rising" at i and pinned to "falling" at i + g (g <= 3, nothing pinned in between), the exact chain steps up somewhere in
+// i .. i + g - 1, i.e. the exact map has a peak there whose value is at least the smallest coarse energy of those positions (- tau / 2).
+// A flat top -- two or three neighbouring delays within tau, the usual reason for a flag -- is such a window.  (Windows are disjoint, so
+// the S-th largest of their bounds would bound the S-th pick; the adaptive precision runs with one source, api.hip.)
+// (One source: the bound is the largest window's.  Written for few live registers -- every energy is read from LDS where it is used --:
+// the call sits in k_scan_pick, whose recursion phase sets the kernel's register count.)
+template <int PL>
+__device__ __forceinline__ bool wave_candidates(const float *En, int D, float tau, bool full, unsigned *cm, int words, int lane)
+{
+    constexpr int G = 3;
+    const int b = PL * lane;
+    float thr = 0.f;
+    if (!full) {
+        unsigned neg = 0u, unc = 0u;                                        // bit c: first difference j = clamp(b - 1 + c, 0, D - 2) (as wave_pick_pl)
+#pragma nounroll
+        for (int c = 0; c < PL + G + 3; ++c) {
+            const int j = min(max(b - 1 + c, 0), max(D - 2, 0));
+            const float df = En[min(j + 1, D - 1)] - En[j];
+            neg |= (df < 0.f ? 1u : 0u) << c;
+            unc |= (fabsf(df) <= tau ? 1u : 0u) << c;
+        }
+        const unsigned lo = neg & ~unc, hi = neg | unc;                     // the sign bit fd at its lowest / highest
+        const unsigned mlo = (lo & (lo >> 1)) | (lo & (lo >> 2)) | ((lo >> 1) & (lo >> 2));     // median of three, bit i: position b + i
+        const unsigned mhi = (hi & (hi >> 1)) | (hi & (hi >> 2)) | ((hi >> 1) & (hi >> 2));
+        const unsigned up = ~mhi, down = mlo, pinned = up | down;           // pinned to 0 (rising) / to 1 (falling)
+        float lv = -INFINITY;
+#pragma nounroll
+        for (int i = 0; i < PL; ++i) {
+            float mn = INFINITY;
+            bool open = ((up >> i) & 1u) != 0u;
+#pragma nounroll
+            for (int g = 1; g <= G; ++g) {
+                mn = fminf(mn, En[min(b + i + g, D - 1)]);                  // En[(b + i + g - 1) + 1]: the value of a step up at position b + i + g - 1
+                if (open && ((down >> (i + g)) & 1u) && b + i + g - 1 < D - 2) lv = fmaxf(lv, mn);
+                if ((pinned >> (i + g)) & 1u) open = false;                 // (a pinned position ends the window either way)
+            }
+        }
+        const float vcert = wave_max64(lv);
+        // no guaranteed positive peak, or one within reach of the zero entries (:188 picks the first of those): every column
+        if (!(vcert > 2.f * tau)) full = true;
+        thr = vcert - tau;
+    }
+    for (int w = lane; w < words; w += 64) {
+        const int c0 = 32 * w;
+        cm[w] = !full || c0 >= D ? 0u : (D - c0 >= 32 ? 0xffffffffu : (1u << (D - c0)) - 1u);
+    }
+    wave_lds_fence();
+    if (!full) {
+#pragma nounroll
+        for (int i = 0; i < PL; ++i) {
+            if (b + i < D - 2 && fabsf(En[min(b + i + 1, D - 1)]) >= thr) {
+                // position b + i reads En[b + i - 1 .. b + i + 3] (two first differences either side of its own two, :159-173)
+                const int lo = max(b + i - 1, 0), hi = min(b + i + 3, D - 1);
+                const unsigned long long m = ((1ull << (hi - lo + 1)) - 1ull) << (lo & 31);
+                atomicOr(&cm[lo >> 5], (unsigned)m);
+                if (m >> 32) atomicOr(&cm[(lo >> 5) + 1], (unsigned)(m >> 32));
+            }
+        }
+    }
+    wave_lds_fence();
+    return full;
+}
+
 // k_scan_pick<PL, MODE>: grid (chunks, arrays), 512 threads.  Per batch of SCAN_SUB frames: (1) thread d runs the recursion of
 // delay d and leaves the normalised energies in LDS, (2) one wave per frame picks the peaks into LDS, (3) the batch's outputs
 // are stored together.  MODE 1 (coarse pass of the adaptive SRP precision): a frame whose picks are sensitive to the fp16
@@ -568,6 +635,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     __shared__ int s_bin[SCAN_SUB * MCA_MAX_SOURCES];
     __shared__ float s_val[SCAN_SUB * MCA_MAX_SOURCES];
     __shared__ unsigned s_flagmask;                                     // MODE 1: the flags of a batch of SCAN_SUB (<= 32) frames
+    __shared__ unsigned s_cm[MODE == 1 ? 10 : 1][CAND_WORDS_MAX];       // MODE 1: the candidate columns of the flagged frame a wave is planning
     static_assert(SCAN_SUB <= 32, "one 32-bit mask per batch");
     static_assert(SCAN_CHUNK <= 64, "one ballot per chunk");
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
@@ -691,6 +759,15 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
             for (unsigned rest = fm; rest; rest &= rest - 1, ++k) {
                 if (k % nwaves != wave) continue;
                 const int t = ts + __ffs((int)rest) - 1;
+                if (p.umask) {
+                    const bool all = wave_candidates<PL>(sEn + (t - ts) * Dl, D, p.tau, t == t_force || ((um >> (t - ts)) & 0x7full) != 0, s_cm[wave], p.umask_words, lane);
+                    if (lane == 0) {
+                        int nc = 0;
+                        for (int w = 0; w < p.umask_words; ++w) nc += __popc(s_cm[wave][w]);
+                        atomicAdd(&p.stats[2], (unsigned long long)nc);
+                        if (all) atomicAdd(&p.stats[3], 1ull);
+                    }
+                }
                 // the rows this frame's energy depends on: its own and those of the REPAIR_WARM frames before it that advanced
                 // the recursion (all of them without the gate, the voiced ones with it), 64 frames per step backwards
                 int remaining = REPAIR_WARM + 1, u_min = t;
@@ -709,6 +786,14 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                         }
                     }
                     const unsigned long long mt = __ballot(take);
+                    if (p.umask && take && !(((u + HIST_FRAMES) & (REPAIR_GROUP - 1)) != 0 && lane > 0 && ((mt >> (lane - 1)) & 1ull))) {
+                        // the frame's candidate columns onto the unit (once per unit: not from a lane whose left neighbour lists the same one)
+                        const int e = u >= 0 ? a * p.groups_per_array + u / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + u) / REPAIR_GROUP;
+                        for (int w = 0; w < p.umask_words; ++w) {
+                            const unsigned m = s_cm[wave][w];
+                            if (m) atomicOr(&p.umask[(long long)e * p.umask_words + w], m);
+                        }
+                    }
                     if (mt) u_min = hi - 63 + (__ffsll((long long)mt) - 1);
                     remaining -= __popcll(m);
                 }
@@ -858,9 +943,23 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     }
     // the last workgroup to get here leaves both lists of the repair pass empty for the next call (every reader of n_list ran
     // before this kernel, every reader of n_clist is a workgroup of it that has counted itself in)
+    __shared__ int s_last;
     if (d == 0) {
         __threadfence();
-        if (atomicAdd(p.n_clist + 1, 1) == (int)gridDim.x - 1) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
+        s_last = atomicAdd(p.n_clist + 1, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+        if (p.umask) {                       // candidate columns: the units' test-and-set words and column masks (k_srp_cand only read them)
+            const int n = *p.n_list;
+            for (int i = d; i < n; i += blockDim.x) {
+                const int e = p.list[i];
+                p.need[e] = 0;
+                for (int w = 0; w < p.umask_words; ++w) p.umask[(long long)e * p.umask_words + w] = 0u;
+            }
+            __syncthreads();
+        }
+        if (d == 0) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
     }
 }
 template __global__ void k_scan_repick<2>(ScanPickArgs);

@@ -184,7 +184,7 @@ struct ScanPickArgs {
     unsigned long long *probe;    // host-mapped [3] or NULL: k_scan_repick leaves stats[0], stats[1] and probe_seq there (api.hip: adapt_policy_begin)
     unsigned long long probe_seq;
     int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
-    unsigned long long *stats;    // [2] running totals: flagged frames, listed groups
+    unsigned long long *stats;    // [4] running totals: flagged frames, listed groups, candidate columns of the flagged frames, flagged frames that took every column
     const unsigned char *unsure;  // [arrays][n_frames] or NULL: frames the coarse analysis could not vouch for (StftPhatArgs::unsure): flagged with their six successors
     // lazy tails (see HIST_FRAMES).  lazy: the call's last frame is not flagged for the state's sake; k_scan_pick leaves the coarse rows of
     // the last HIST_FRAMES frames in hist_C_out [arrays][HIST_FRAMES][Dp] and the energies in front of them in e_hist_out [arrays][D].
@@ -194,7 +194,30 @@ struct ScanPickArgs {
     int lazy, hist_valid, hist_base;
     float *hist_C_out, *e_hist_out;
     const float *hist_C_in, *e_hist_in;
+    // candidate columns (round 5): per repair unit the delays its rows are needed at, one bit per column, umask_words = Dp / 32 words
+    // per unit (k_scan_pick ORs a flagged frame's candidate columns into every unit it lists; k_srp_cand reads them; the last workgroup
+    // of k_scan_repick clears them with the units' test-and-set words).  NULL: whole rows (k_srp_gemm_repair + k_repair_patch).
+    unsigned *umask; int umask_words;
 };
+
+// k_srp_cand: the exact values of the listed rows AT THEIR CANDIDATE COLUMNS, written straight into the map.
+// Which columns: a flagged frame's S picks are, on the exact map, among the positions whose coarse |En| reaches v - tau, v the S-th
+// largest coarse peak whose four first differences are all pinned (|d| > tau) -- such a peak exists on the exact map with a value
+// >= v - tau / 2, and a position below v - tau cannot reach that -- plus the two columns either side that feed the sign / median
+// chain (:159-173) of such a position.  The second pick then runs on a row that is exact wherever it matters and coarse elsewhere.
+// Frames flagged for the state's sake (eager tails) or because the coarse analysis could not vouch for a row (unsure) take every column.
+constexpr int CAND_WORDS_MAX = 20;          // Dp <= 640 (the peak pick handles D <= 514)
+struct CandArgs {
+    const void *A;           // exact analysis rows of the listed units, fp16 hi + lo planes: [rows][a_row_elems], row = 4 x list position + frame
+    const void *B;           // steering table, fp16 hi + lo planes: [2][Dp][Kp]
+    int Kp, Dp, a_row_elems;
+    const int *list; const int *n_list; int list0, pass_rows;
+    const unsigned *umask; int umask_words;
+    int groups_per_array, n_frames;
+    float *C; int c_planes; long long c_plane_stride;       // plane 0 takes the exact value, the others zeros (as k_repair_patch)
+    float *hist_C; int hist_base;                            // lazy tails: units >= hist_base are rows of hist_C
+};
+constexpr int CAND_SLOTS = 4;
 
 // The repair contraction runs on however many rows the coarse pass listed (a device-side count): the K range is what
 // parallelises.  It is cut into a number of segments that depends on the SHAPE of the call only (api.hip, repair_ksplit_for:

@@ -38,8 +38,9 @@ def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10, gate=False, so
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     kt = {name: round(ctx.get_timing(kid)[1] / max(ctx.get_timing(kid)[0], 1), 3) for kid, name in api.KERNEL_NAMES.items() if ctx.get_timing(kid)[0]}
-    print("M=%2d fs=%6d N=%4d D=%3d S=%d%s  %3d arrays x %5d frames: %6.2f M frames/s  %.3f ms/step  %s" %
-          (M, fs, N, ctx.D, S, " gate" if gate else "", A, F, A * F / dt / 1e6, dt * 1e3, kt))
+    print("M=%2d fs=%6d N=%4d D=%3d S=%d%s  %3d arrays x %5d frames: %6.2f M frames/s  %.3f ms/step  %s%s" %
+          (M, fs, N, ctx.D, S, " gate" if gate else "", A, F, A * F / dt / 1e6, dt * 1e3, kt,
+           "  repair %s %s" % (ctx.repair_stats(), ctx.repair_columns()) if prec == api.SRP_ADAPTIVE else ""))
     ctx.close()
 
 
@@ -79,6 +80,12 @@ if __name__ == "__main__":
         run(16, 48000, 1024, 0.5, 8, 2048, prec=api.SRP_FP16, sources=True, steps=30)
         run(16, 48000, 1024, 0.5, 8, 2048, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
         run(16, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "m16a":        # the adaptive 16-microphone call alone (tools/m16_breakdown.sh runs it under rocprofv3)
+        run(16, 48000, 1024, 0.5, 8, 2048, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "s1":          # one source per array, seeds 0..7: the content with clustered near ties (bench.py's second repair_spread input)
+        run(8, 48000, 1024, 0.5, 8, 4096, S=1, sources=True, prec=api.SRP_ADAPTIVE, steps=30)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sources":
         for S in (1, 2, 3, 4):
