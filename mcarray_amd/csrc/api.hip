@@ -169,6 +169,7 @@ struct mca_hip_ctx {
     Knobs kn;
     bool adapt_suspended = false, capturing = false;
     int fb_left = 0, fb_backoff = 8, fb_state = 0;      // (adapt_policy_begin)
+    bool cand_heavy = false;                            // the last report had more than a fifth of the rows recomputed: whole-row repair kernels (adapt_policy_begin)
     unsigned long long fb_probe_seq = 0;
     unsigned long long *h_probe = nullptr;              // [3] flagged frames, listed repair units, sequence number of the call
     unsigned long long fb_calls = 0, fb_seq_seen = 0, fb_groups_prev = 0, fb_frames_prev = 0;
@@ -608,6 +609,8 @@ void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
         c->fb_seq_seen = seq; c->fb_groups_prev = groups; c->fb_frames_prev = frames;
         fresh = df > 0;
         heavy = fresh && dg * REPAIR_GROUP * 100 > df * 30;
+        // candidate columns pay while the list is short (one workgroup per unit); a call that recomputes most rows is a dense contraction again
+        if (fresh) c->cand_heavy = dg * REPAIR_GROUP * 100 > df * 20;
     }
     auto suspend = [&]() {
         c->fb_state = 1; c->adapt_suspended = true;
@@ -1133,7 +1136,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
         HIP_TRY(c, hipMemsetAsync(c->d_vdone[i], 0, na * 8, st));
     }
     HIP_TRY(c, hipMemsetAsync(c->d_silence, 0, na * 4, st));
-    c->adapt_suspended = false; c->fb_state = 0; c->fb_left = 0; c->fb_backoff = 8;     // new streams: the adaptive mode starts afresh
+    c->adapt_suspended = false; c->fb_state = 0; c->fb_left = 0; c->fb_backoff = 8; c->cand_heavy = false;     // new streams: the adaptive mode starts afresh
     c->hist_pending = false;                                                              // ... and no call owes the next one its last rows
     // the self-cleaning words of the adaptive path (a call that failed half way may have left some set)
     for (Workspace &w : c->lanes) {
@@ -1515,8 +1518,9 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         if (hist_valid) { pa.hist_valid = 1; pa.hist_C_in = c->d_hist_C[c->hist_cur]; pa.e_hist_in = c->d_ehist[c->hist_cur]; }
         // candidate columns where whole-row frames are the exception: lazy calls (no frame is repeated for the state's sake) of contexts
         // whose coarse analysis marks no unsure rows, one source (wave_candidates bounds the first pick); a unit that wants every column
-        // costs k_srp_cand the whole steering table
-        if (c->kn.cand && lazy && !pa.unsure && c->S == 1 && c->Dp / 32 <= CAND_WORDS_MAX) { pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32; }
+        // costs k_srp_cand the whole steering table.  Not while the back-off policy is probing or the last report was heavy (noise only:
+        // 45 % of the frames flagged, ten columns each -- 3.2 ms against 1.1 for the whole-row kernels)
+        if (c->kn.cand && lazy && !pa.unsure && c->S == 1 && c->Dp / 32 <= CAND_WORDS_MAX && c->fb_state == 0 && !c->cand_heavy) { pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32; }
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
             c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
