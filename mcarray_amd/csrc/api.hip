@@ -172,7 +172,7 @@ struct mca_hip_ctx {
     bool cand_heavy = false;                            // the last report had more than a fifth of the rows recomputed: whole-row repair kernels (adapt_policy_begin)
     unsigned long long fb_probe_seq = 0;
     unsigned long long *h_probe = nullptr;              // [3] flagged frames, listed repair units, sequence number of the call
-    unsigned long long fb_calls = 0, fb_seq_seen = 0, fb_groups_prev = 0, fb_frames_prev = 0;
+    unsigned long long fb_calls = 0, fb_seq_seen = 0, fb_groups_prev = 0, fb_frames_prev = 0, fb_flagged_prev = 0;
     unsigned long long fb_frames_ring[64] = {};         // adapt_frames_total after adaptive call number i + 1
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
@@ -588,9 +588,20 @@ bool lazy_context(const mca_hip_ctx *c)
            !c->kn.stft_wg && c->cfg.gcc_weighting == MCA_HIP_GCC_PHAT && c->stream_ok;
 }
 
+// Candidate columns (k_srp_cand) for this call?  Lazy calls (no frame is repeated for the state's sake) of contexts whose coarse analysis
+// marks no unsure rows, one source (wave_candidates bounds the first pick) -- a unit that wants every column costs k_srp_cand the whole
+// steering table.  Only under the AUTO back-off policy, and not while it is probing or the last report was heavy (noise only: 45 % of the
+// frames flagged, ten columns each -- 4.3 ms per call against 2.0 for the whole-row kernels): a context pinned to the mode
+// (adaptive_fallback OFF: bit-reproducible runs) keeps the whole-row kernels whatever the content.
+static bool wave16_applies(const mca_hip_ctx *c);
+static bool cand_call(const mca_hip_ctx *c, bool lazy)
+{
+    return c->kn.cand && lazy && !wave16_applies(c) && c->S == 1 && c->Dp / 32 <= CAND_WORDS_MAX && c->kn.fb_enabled && c->h_probe && c->fb_state == 0 && !c->cand_heavy;
+}
+
 // Called once at the top of an eager stream call (not per piece of a call, not while a graph is recorded): reads what the
 // adaptive calls that have finished by now reported and decides whether this call runs coarse + repair or plain FP16X3.
-//   NORMAL     adaptive; a report of more than 30 % of the rows recomputed since the last one suspends the mode for fb_backoff
+//   NORMAL     adaptive; a report of more than 30 % of the rows recomputed (or of the frames flagged) since the last one suspends the mode for fb_backoff
 //              eligible calls (8, doubling up to 256 while the probes keep reporting that)
 //   SUSPENDED  plain FP16X3, counting down; then ONE adaptive call probes
 //   WAITING    plain FP16X3 until the probe's report is in (a caller that queues many calls ahead gets it late): heavy again ->
@@ -604,11 +615,13 @@ void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
     const unsigned long long seq = __atomic_load_n(&c->h_probe[2], __ATOMIC_ACQUIRE);
     if (seq > c->fb_seq_seen && seq <= c->fb_calls && c->fb_calls - seq < 64) {
         const unsigned long long groups = __atomic_load_n(&c->h_probe[1], __ATOMIC_RELAXED), frames = c->fb_frames_ring[(seq - 1) % 64];
-        const bool fwd = groups >= c->fb_groups_prev && frames > c->fb_frames_prev;      // (the totals restart with mca_hip_reset_timing)
-        const unsigned long long dg = fwd ? groups - c->fb_groups_prev : 0, df = fwd ? frames - c->fb_frames_prev : 0;
-        c->fb_seq_seen = seq; c->fb_groups_prev = groups; c->fb_frames_prev = frames;
+        const unsigned long long flagged = __atomic_load_n(&c->h_probe[0], __ATOMIC_RELAXED);
+        const bool fwd = groups >= c->fb_groups_prev && frames > c->fb_frames_prev && flagged >= c->fb_flagged_prev;      // (the totals restart with mca_hip_reset_timing)
+        const unsigned long long dg = fwd ? groups - c->fb_groups_prev : 0, df = fwd ? frames - c->fb_frames_prev : 0, dfl = fwd ? flagged - c->fb_flagged_prev : 0;
+        c->fb_seq_seen = seq; c->fb_groups_prev = groups; c->fb_frames_prev = frames; c->fb_flagged_prev = flagged;
         fresh = df > 0;
-        heavy = fresh && dg * REPAIR_GROUP * 100 > df * 30;
+        // (... or 30 % of the frames flagged: digital silence lists no rows -- they are zero in both maps -- but every frame is planned and picked twice)
+        heavy = fresh && (dg * REPAIR_GROUP * 100 > df * 30 || dfl * 100 > df * 30);
         // candidate columns pay while the list is short (one workgroup per unit); a call that recomputes most rows is a dense contraction again
         if (fresh) c->cand_heavy = dg * REPAIR_GROUP * 100 > df * 20;
     }
@@ -1302,6 +1315,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
         sa.no_phat = c->cfg.gcc_weighting == MCA_HIP_GCC_NONE ? 1 : 0;
         if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->a_planes == 1 && wave16_applies(c)) sa.unsure = c->ws().d_unsure;   // (adaptive coarse pass)
+        if (c->lazy_now && cand_call(c, true)) sa.dead = c->ws().d_unsure;                                               // (... of a candidate-column call: frames of exact zeros)
         if (c->lazy_now) sa.hist_out = c->d_hist_pcm[c->hist_cur ^ 1];       // lazy tails: the call's last frames of PCM stay behind
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         if (c->n512) {
@@ -1516,11 +1530,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         pa.hist_base = n_arrays * gpa;
         if (lazy) { pa.lazy = 1; pa.hist_C_out = c->d_hist_C[c->hist_cur ^ 1]; pa.e_hist_out = c->d_ehist[c->hist_cur ^ 1]; }
         if (hist_valid) { pa.hist_valid = 1; pa.hist_C_in = c->d_hist_C[c->hist_cur]; pa.e_hist_in = c->d_ehist[c->hist_cur]; }
-        // candidate columns where whole-row frames are the exception: lazy calls (no frame is repeated for the state's sake) of contexts
-        // whose coarse analysis marks no unsure rows, one source (wave_candidates bounds the first pick); a unit that wants every column
-        // costs k_srp_cand the whole steering table.  Not while the back-off policy is probing or the last report was heavy (noise only:
-        // 45 % of the frames flagged, ten columns each -- 3.2 ms against 1.1 for the whole-row kernels)
-        if (c->kn.cand && lazy && !pa.unsure && c->S == 1 && c->Dp / 32 <= CAND_WORDS_MAX && c->fb_state == 0 && !c->cand_heavy) { pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32; }
+        if (cand_call(c, lazy)) { pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32; pa.dead = c->ws().d_unsure; }   // (dead: the unsure bytes, unused by these contexts)
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
             c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
@@ -2466,7 +2476,7 @@ int mca_hip_reset_timing(mca_hip_ctx *c)
     for (int i = 0; i < MCA_HIP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_launches[i] = 0; }
     if (c->d_rstats) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipMemset(c->d_rstats, 0, 32)); }
     c->adapt_frames_total = 0;
-    c->fb_groups_prev = 0; c->fb_frames_prev = 0; c->fb_seq_seen = c->fb_calls;   // (the reports in flight belong to the old totals)
+    c->fb_groups_prev = 0; c->fb_frames_prev = 0; c->fb_flagged_prev = 0; c->fb_seq_seen = c->fb_calls;   // (the reports in flight belong to the old totals)
     // ... including a probe's, if the back-off is waiting for one: that report will never count as fresh, so the wait ends here
     // and the mode resumes (the context stayed on FP16X3 until mca_hip_reset)
     if (c->fb_state == 2) { c->fb_state = 0; c->adapt_suspended = false; }

@@ -778,7 +778,9 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                     const unsigned long long m = __ballot(on);
                     const int above = lane < 63 ? __popcll(m >> (lane + 1)) : 0;   // advancing frames after u in this window
                     const bool take = on && above < remaining;
-                    if (take) {
+                    // (a frame of exact zeros: its row is zero in the coarse and in the exact map alike -- counted as a warm row, not listed)
+                    const bool listed = take && !(p.dead && u >= 0 && p.dead[(long long)a * p.n_frames + u] != 0);
+                    if (listed) {
                         const int e = u >= 0 ? a * p.groups_per_array + u / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + u) / REPAIR_GROUP;
                         if (atomicExch(&p.need[e], 1) == 0) {
                             p.list[atomicAdd(p.n_list, 1)] = e;
@@ -786,7 +788,8 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                         }
                     }
                     const unsigned long long mt = __ballot(take);
-                    if (p.umask && take && !(((u + HIST_FRAMES) & (REPAIR_GROUP - 1)) != 0 && lane > 0 && ((mt >> (lane - 1)) & 1ull))) {
+                    const unsigned long long ml = __ballot(listed);
+                    if (p.umask && listed && !(((u + HIST_FRAMES) & (REPAIR_GROUP - 1)) != 0 && lane > 0 && ((ml >> (lane - 1)) & 1ull))) {
                         // the frame's candidate columns onto the unit (once per unit: not from a lane whose left neighbour lists the same one)
                         const int e = u >= 0 ? a * p.groups_per_array + u / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + u) / REPAIR_GROUP;
                         for (int w = 0; w < p.umask_words; ++w) {

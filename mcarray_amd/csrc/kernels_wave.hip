@@ -531,6 +531,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
             if (p.queue && fi == nfr - 1 && lane == 0) rq_pending = atomicAdd(p.queue, 1u);     // the next run: asked for a frame ahead of its use
             float2 Xh[MT][8], zn[NP];
             v2f ptime = {0.f, 0.f};                                                // POWER: sum of the squared windowed samples (Parseval)
+            bool any_alive = false;                                                // (wave-uniform)
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
                 float2 z[16];
@@ -540,6 +541,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
                 for (int i = 1; i < 15; i += 2) { oa = or3(oa, __float_as_uint(xa[i]), __float_as_uint(xa[i + 1])); ob = or3(ob, __float_as_uint(xb[i]), __float_as_uint(xb[i + 1])); }
                 oa |= __float_as_uint(xa[15]); ob |= __float_as_uint(xb[15]);
                 const bool alive_a = __any((oa << 1) != 0), alive_b = __any((ob << 1) != 0);
+                any_alive = any_alive || alive_a || alive_b;
                 if (p.hist_out) {
                     // lazy tails: the call's last HIST_FRAMES frames of PCM stay behind for the next call's repair pass (frame j of the
                     // history = samples [512 j, 512 j + 1024) of a channel's HIST_SAMPLES)
@@ -600,6 +602,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
                     Xh[2 * pr + 1][s] = whiten4<NOPHAT>(b2, pwb, alive_b);
                 }
             }
+            if (p.dead && lane == 0) p.dead[(long long)a * p.total_frames + p.frame0 + f] = any_alive ? 0 : 1;
             OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f) * (long long)p.a_row_elems;
             if (MERGE) {
                 // One spacing g at a time: the products k g of a lane's eight bins -- of all lanes' bins -- are all different for a

@@ -83,6 +83,8 @@ struct StftPhatArgs {
                                     // together (19 / 13 frames: 302 -> 281 us per 32 768 frames, profiles/r05_skew.log).  The rows do not
                                     // depend on which wave forms them: the same bits.
     unsigned long long *wave_clock; // (measurement, make MEASURE=1 + MCA_HIP_WAVE_CLOCK) [waves][3]: wall_clock64 at entry and exit, runs taken
+    unsigned char *dead;     // k_stft_phat_wave in the coarse pass of a candidate-column call, else NULL: [arrays][total_frames] 1 = every channel of the frame is
+                             // exact zeros (digital silence): its row is zero in the coarse and in the exact map alike, the repair pass need not list it
     unsigned char *unsure;   // k_stft_phat_wave16 in the adaptive coarse pass, else NULL: [arrays][total_frames] 1 = a channel's DC or Nyquist bin of this
                              // frame is at the rounding level of the transform.  PHAT keeps only the SIGN of such a bin, and the exact rows of 16
                              // microphones come from another kernel (k_stft_phat<16>) that need not round it the same way: k_scan_pick repairs the
@@ -185,6 +187,7 @@ struct ScanPickArgs {
     unsigned long long probe_seq;
     int *last_vchunk;        // [arrays] chunk of the array's last frame that advanced the recursion, -1 = none (k_scan_carry)
     unsigned long long *stats;    // [4] running totals: flagged frames, listed groups, candidate columns of the flagged frames, flagged frames that took every column
+    const unsigned char *dead;    // [arrays][n_frames] or NULL: frames of exact zeros (StftPhatArgs::dead): their rows are not listed
     const unsigned char *unsure;  // [arrays][n_frames] or NULL: frames the coarse analysis could not vouch for (StftPhatArgs::unsure): flagged with their six successors
     // lazy tails (see HIST_FRAMES).  lazy: the call's last frame is not flagged for the state's sake; k_scan_pick leaves the coarse rows of
     // the last HIST_FRAMES frames in hist_C_out [arrays][HIST_FRAMES][Dp] and the energies in front of them in e_hist_out [arrays][D].

@@ -35,7 +35,35 @@ def run(prec, fallback, steps=60, A=8, F=4096):
     ctx.close()
 
 
+def onset(kind, fallback, A=8, F=4096):
+    """the first calls of a stream whose content turns bad for the adaptive mode: a source for 4 calls, then `kind` (noise only /
+    digital silence) -- each call timed on its own (the host waits for it)"""
+    os.environ["MCA_HIP_ADAPT_FALLBACK"] = "1" if fallback else "0"
+    dev = torch.device("cuda", 0)
+    import bench
+    good = bench.synth_batch(synth.ULA8, list(range(100, 100 + A)), F, dev)[0][:, :, :(F + 1) * 512].contiguous()
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    bad = (torch.randn(A, 8, (F + 1) * 512, device=dev, generator=g) * 0.1).contiguous() if kind == "noise" else torch.zeros(A, 8, (F + 1) * 512, device=dev)
+    ctx = api.Context(48000, synth.ULA8, 1024, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+    b = torch.empty(A, F, 1, dtype=torch.int32, device=dev); d = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+    pr = torch.empty(A, F, 1, dtype=torch.float32, device=dev); o = torch.empty(A, 1, F * 512, dtype=torch.float32, device=dev)
+    ms = []
+    for i in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.process_frames_dev(good if i < 4 else bad, F, b, d, pr, None, o)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    print("onset of %-7s back-off %-3s: ms per call %s" % (kind, "on" if fallback else "off", " ".join("%.2f" % m for m in ms)), flush=True)
+    ctx.close()
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "onset":
+        for kind in ("noise", "silence"):
+            for fb in (True, False):
+                onset(kind, fb)
+        sys.exit(0)
     run(api.SRP_FP16X3, False)
     run(api.SRP_ADAPTIVE, False)
     run(api.SRP_ADAPTIVE, True)

@@ -109,6 +109,12 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False):
         pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(rng.uniform(-80, 80)), fs, (F + 1) * N // 2, int(rng.integers(1, 1 << 30)),
                                                   **({"snr_db": float(rng.choice([30.0, 10.0, 3.0]))} if lazy else {}))
                         for _ in range(A)]).astype(np.float32)
+        if lazy and rng.integers(0, 3) == 0:                         # digital silence over a stretch (all channels, or one channel only)
+            lo_ = int(rng.integers(0, pcm.shape[2] // 2)); hi_ = lo_ + int(rng.integers(N, pcm.shape[2] // 2))
+            if rng.integers(0, 2):
+                pcm[:, :, lo_:hi_] = 0.0
+            else:
+                pcm[:, int(rng.integers(0, M)), lo_:hi_] = 0.0
         tag = "case %d: M=%d %s fs=%d N=%d step=%.1f S=%d A=%d F=%d prec=%d gate=%d" % (case, M, "ula" if ula else "irr", fs, N, step, S, A, F, prec, gate)
         if os.environ.get("MCA_FUZZ_ONLY") and case not in [int(x) for x in os.environ["MCA_FUZZ_ONLY"].split(",")]:
             if F > 1:
