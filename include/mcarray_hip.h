@@ -62,8 +62,19 @@ typedef enum {
                                 FP16X3's energies).  Picks that are TIES at that level -- two candidates, or a first difference
                                 against zero, closer than 1e-6 of the row's largest normalised energy: the bar of the parity tests
                                 -- may resolve differently from FP16X3 and between calls of different shapes.  Measured over 40
-                                random configurations / 696 320 frames: 41 picks on 29 frames differ from FP16X3, all 29 such ties
-                                (profiles/r04_adaptive_check.json; the warm-row count of 16 against 24: _warm24.json).
+                                random configurations / 696 320 frames: 42 picks on 30 frames differ from FP16X3, all 30 such ties
+                                (profiles/r05_adaptive_check.json; the warm-row count of 16 against 24: r04_adaptive_check_warm24.json).
+                                ROUND 5, device-pointer calls of 4 / 8-microphone contexts without the gate: (a) LAZY TAILS -- the
+                                call does not repeat its last frame for the state's sake; it keeps its last 16 frames of PCM, their
+                                coarse rows and the energies in front of them, and the next call repairs them only if one of its
+                                first 16 frames is flagged.  Every other consumer of the state (host-pointer calls, graph launches,
+                                mca_hip_state_save, calls of another batch size or too small for the mode) first makes the carried
+                                energies exact, so what they see is what the eager form left.  (b) CANDIDATE COLUMNS (AUTO policy,
+                                one source) -- a flagged frame's rows are recomputed exactly at the delays its pick can be among
+                                (those whose coarse energy reaches the lowest value the exact pick can have, and two either side),
+                                not at all D; the second pick runs on rows that are exact there and coarse elsewhere, and the
+                                optional energy map of a flagged frame is exact at those delays only.
+                                MCA_HIP_ADAPT_LAZY=0 restores the eager, whole-row form.
                                 OUTSIDE THE MODEL, in any precision: a frame in which a channel's DC or Nyquist bin -- the two real
                                 bins -- is at the rounding level of an fp32 transform (about one frame in 10^5 per 8 channels).
                                 PHAT keeps only the SIGN of such a bin, and no two implementations, the reference's double-precision
@@ -431,8 +442,9 @@ int mca_hip_set_timing_mask(mca_hip_ctx *ctx, unsigned kernel_mask);
 int mca_hip_get_timing(mca_hip_ctx *ctx, int kernel_id, int *launches, double *total_ms);
 int mca_hip_reset_timing(mca_hip_ctx *ctx);
 /* MCA_HIP_SRP_ADAPTIVE: totals since the last mca_hip_reset_timing (synchronises the device): frames that went through the
- * adaptive path, frames whose pick was flagged as sensitive to the fp16 error (includes the last frame of every array and
- * call, which is always repeated so that the carried state is exact), and frames whose rows were recomputed exactly.  The
+ * adaptive path, frames whose pick was flagged as sensitive to the fp16 error (in the eager form this includes the last frame of
+ * every array and call, which is repeated so that the carried state is exact; lazy calls flag no frame for that), and frames
+ * whose rows went through the exact analysis.  The
  * reference has no counterpart (it computes every pair and delay in double, SteeringBeamforming.cpp:104-130). */
 int mca_hip_get_repair_stats(mca_hip_ctx *ctx, unsigned long long *frames, unsigned long long *flagged_frames,
                              unsigned long long *recomputed_frames);
