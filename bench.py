@@ -560,8 +560,8 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
                      "kernels on other shapes, which also brings the clocks to their loaded state); cpu_baseline and config.mvdr_256x64 after the timed region",
             "warmup_beyond_the_declared_steps": {"seconds_of_other_configurations_before_the_warm_up": t_extras,
                                                  "note": "host seconds (context creation, input synthesis and GPU work) of the configurations above that ran ahead of the "
-                                                         "--warmup steps; with --single-stream 0 --extras 0 nothing runs there (profiles/r04_bench_warmup0.json / "
-                                                         "_warmup1.json: 35.7 / 44.7 M frames/s with 0 / 1 warm-up steps and no extras, against 45.3 M for this order)"},
+                                                         "--warmup steps; with --single-stream 0 --extras 0 nothing runs there (profiles/r05_bench_warmup0.json / "
+                                                         "_warmup1.json: 39.0 / 46.1 M frames/s with 0 / 1 warm-up steps and no extras, against 48.3 M for this order on the same box)"},
             "kernels_note": "hipEvent pairs on the launch stream: %s over the timed region, the other groups in a "
                             "pass of %d steps after it (bracketing all of them inside the timed region costs ~2.5 %%)" % (" and ".join(kt_timed), table_steps),
             "exchange": {"backend": dist.get_backend() if use_dist else None, "gather_audio": bool(args.gather_audio),
