@@ -47,7 +47,7 @@ struct Knobs {
     bool force_generic = false;        // MCA_HIP_FORCE_GENERIC: the any-length kernels at N = 1024 too (parity test of both)
     bool scan_carry = false;           // MCA_HIP_SCAN_CARRY / cfg.scan_carry
     bool lazy_ks_shape = false;        // (measurement) MCA_HIP_LAZY_KS_SHAPE: the repair contraction's K segments by the call's shape also with lazy tails
-    bool cand = true;                  // (measurement) MCA_HIP_CAND=0: whole rows for every listed unit (k_srp_gemm_repair + k_repair_patch, round 4)
+    int cand = -1;                     // MCA_HIP_ADAPT_CAND: -1 / unset = by the back-off policy's reports (cand_call), 1 = wherever the call's shape allows, 0 = never (whole-row repair kernels)
     int cand_grid = 512;               // (measurement) MCA_HIP_CAND_GRID: workgroups of k_srp_cand
     bool lazy_tails = true;            // MCA_HIP_ADAPT_LAZY=0: every adaptive call repairs its own last rows for the state it hands over (round 4)
     // measurement only (-DMCA_MEASURE)
@@ -275,7 +275,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     // measurement only: constants unless the library was built with -DMCA_MEASURE
     k.no_merge = measure_env("MCA_HIP_NO_MERGE") != nullptr;
     k.repair_items = (int)geti(measure_env("MCA_HIP_REPAIR_ITEMS"), 768);
-    k.cand = geti(measure_env("MCA_HIP_CAND"), 1) != 0;
+    if (const char *v = env_str("MCA_HIP_ADAPT_CAND")) k.cand = std::atoi(v) != 0 ? 1 : 0;
     k.cand_grid = (int)geti(measure_env("MCA_HIP_CAND_GRID"), 512);
     k.stft_wg = measure_env("MCA_HIP_STFT_WG") != nullptr;
     k.bf_ola = measure_env("MCA_HIP_BF_OLA") != nullptr;
@@ -592,11 +592,14 @@ bool lazy_context(const mca_hip_ctx *c)
 // marks no unsure rows, one source (wave_candidates bounds the first pick) -- a unit that wants every column costs k_srp_cand the whole
 // steering table.  Only under the AUTO back-off policy, and not while it is probing or the last report was heavy (noise only: 45 % of the
 // frames flagged, ten columns each -- 4.3 ms per call against 2.0 for the whole-row kernels): a context pinned to the mode
-// (adaptive_fallback OFF: bit-reproducible runs) keeps the whole-row kernels whatever the content.
+// (adaptive_fallback OFF: bit-reproducible runs) keeps the whole-row kernels whatever the content.  MCA_HIP_ADAPT_CAND=1 / 0 overrides the
+// policy (always where the shape allows / never).
 static bool wave16_applies(const mca_hip_ctx *c);
 static bool cand_call(const mca_hip_ctx *c, bool lazy)
 {
-    return c->kn.cand && lazy && !wave16_applies(c) && c->S == 1 && c->Dp / 32 <= CAND_WORDS_MAX && c->kn.fb_enabled && c->h_probe && c->fb_state == 0 && !c->cand_heavy;
+    if (c->kn.cand == 0 || !lazy || wave16_applies(c) || c->S != 1 || c->Dp / 32 > CAND_WORDS_MAX) return false;
+    if (c->kn.cand == 1) return true;                                 // MCA_HIP_ADAPT_CAND=1: whatever the content (tests, sweeps, pinned contexts that want it)
+    return c->kn.fb_enabled && c->h_probe && c->fb_state == 0 && !c->cand_heavy;
 }
 
 // Called once at the top of an eager stream call (not per piece of a call, not while a graph is recorded): reads what the

@@ -371,8 +371,10 @@ def test_lazy_tails_match_the_eager_form_and_the_oracle(force_small, monkeypatch
     def make(lazy):
         if not lazy:
             os.environ["MCA_HIP_ADAPT_LAZY"] = "0"
+        os.environ["MCA_HIP_ADAPT_CAND"] = "1"            # the lazy form with candidate columns (the context is pinned: no policy reports to go by)
         c = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A, adaptive_fallback=False)
         os.environ.pop("MCA_HIP_ADAPT_LAZY", None)
+        os.environ.pop("MCA_HIP_ADAPT_CAND", None)
         return c
     res = {}
     for lazy in (True, False):
@@ -424,3 +426,44 @@ def test_lazy_tails_match_the_eager_form_and_the_oracle(force_small, monkeypatch
         ctx.close()
     assert counts[False]["flagged"] == counts[True]["flagged"] + A * n_calls, counts
     assert counts[True]["recomputed"] + 12 * A * n_calls <= counts[False]["recomputed"], counts
+
+
+def test_candidate_columns_and_frames_of_exact_zeros(force_small, monkeypatch):
+    """Candidate columns (round 5; CandArgs in mca_internal.h): lazy calls recompute a flagged frame's rows at the delays its pick can be
+    among.  A low-SNR stream with a stretch of digital silence in the middle (every channel exact zeros: those rows are zero in the coarse
+    and in the exact map, they are counted as warm rows and not listed) and one channel muted for a while, in five device-pointer calls:
+    bins against the oracle up to oracle-fragile frames (the silent stretch has flat maps: ties by construction), audio on every hop whose
+    bins agree; mca_hip_get_repair_columns: a handful of columns per flagged frame, no frame that took every column outside the silence,
+    nothing with MCA_HIP_ADAPT_CAND=0 (whole-row kernels) -- whose bins differ from the candidate form's on oracle-fragile frames only."""
+    import os
+    fs, N, hop, A, F, n_calls = 48000, 1024, 512, 2, 128, 5
+    xs = synth.ULA8
+    total = F * n_calls
+    monkeypatch.setenv("MCA_HIP_ADAPT_TAU_SCALE", "20")
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(35.0 - 60 * a), fs, (total + 1) * hop, 5100 + a, snr_db=6.0).astype(np.float32) for a in range(A)])
+    pcm[:, :, 250 * hop:330 * hop] = 0.0                       # 80 frames of digital silence, across a call boundary
+    pcm[0, 3, 400 * hop:470 * hop] = 0.0                       # one muted channel
+    o = [po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, 0.5, want_map=True) for a in range(A)]
+    from parity_helpers import classify_bins, assert_audio_where_bins_agree
+    res = {}
+    for cand in ("1", "0"):
+        os.environ["MCA_HIP_ADAPT_CAND"] = cand
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A, adaptive_fallback=False)
+        os.environ.pop("MCA_HIP_ADAPT_CAND", None)
+        ctx.reset_timing()
+        b, audio = _dev_calls(ctx, pcm, F, n_calls, hop)
+        res[cand] = (b, audio, ctx.repair_stats(), ctx.repair_columns())
+        ctx.close()
+        for a in range(A):
+            ties, bad = classify_bins(b[a], o[a]["bin"][:, 0], o[a]["energy"], 28)
+            assert not bad, (cand, a, bad[:5])
+            assert_audio_where_bins_agree(audio[a][None], o[a]["out"], b[a], o[a]["bin"][:, 0], hop)
+    st, cols = res["1"][2], res["1"][3]
+    assert st["flagged"] > 30, st
+    assert ctx.D == 361
+    assert cols["whole_row_frames"] <= 2 * A * 80, cols          # (only frames of the silent stretch -- flat maps -- can lack a lower bound; their rows are zero: not listed)
+    narrow = st["flagged"] - cols["whole_row_frames"]
+    assert narrow > 0 and 0 < cols["candidate_columns"] - 361 * cols["whole_row_frames"] <= 40 * narrow, (st, cols)
+    assert res["0"][3] == {"candidate_columns": 0, "whole_row_frames": 0}, res["0"][3]
+    assert res["0"][2]["flagged"] == st["flagged"]               # the same frames are flagged: the coarse pass is the same
+    assert res["1"][2]["recomputed"] <= res["0"][2]["recomputed"]  # ... and the silent rows are not listed

@@ -1,10 +1,9 @@
 #!/bin/bash
 # round 5: candidate columns (shipped: k_srp_cand writes the exact values of the listed rows at the columns the flagged frames need)
-# against whole rows (MCA_HIP_CAND=0: k_srp_gemm_repair + k_repair_patch, round 4); MEASURE build
+# against whole rows (MCA_HIP_ADAPT_CAND=0: k_srp_gemm_repair + k_repair_patch, round 4); the shipped library
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-export MCA_HIP_LIB=$GRAFT_REPO_ROOT/abtest/lib_measure.so
 for cand in 0 1 0 1; do
-  MCA_HIP_CAND=$cand python bench.py --steps 100 --warmup 20 --cpu-frames 0 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
+  MCA_HIP_ADAPT_CAND=$cand python bench.py --steps 100 --warmup 20 --cpu-frames 0 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
   python - $cand <<PY
 import json,sys
 d=json.load(open('/tmp/ab.json'))
@@ -13,4 +12,3 @@ s=d['config']['single_stream_4096']; print('        1 x 4096 per call: %.4f ms (
 for sp in d['repair_spread']: print('        %-78s %.4f ms per 32768 frames  %.3f x  repair %.3f ms  recomputed %.4f  columns per flagged frame %.1f  whole-row frames %d' % (sp['input'][:78], sp['ms_per_32768_frames'], sp['vs_headline'], sp['repair_ms'], sp['recomputed_fraction'], sp['columns_per_flagged_frame'], sp['whole_row_frames']))
 PY
 done
-for cand in 0 1; do echo "MCA_HIP_CAND=$cand, 16 microphones:"; MCA_HIP_CAND=$cand python tools/bench_shapes.py m16a 2> /dev/null | grep "^M="; done
