@@ -151,7 +151,7 @@ N_SIMD = 1024                                          # 256 CUs x 4 SIMDs (MI35
 FP32_VECTOR_TFLOPS = 157.3                             # same guide: packed fp32 on the vector ALU = fp32 MFMA
 
 
-def valu_roofline(kernel_substrings, avg_ms, which="adaptive", exclude=()):
+def valu_roofline(kernel_substrings, avg_ms, which="adaptive", exclude=(), launches_per_step=1.0):
     """Issue-rate roofline of a VALU-bound kernel: a wave64 vector instruction occupies its SIMD for 4 cycles, so a launch
     that issues I wave-instructions cannot finish before I x 4 / (1024 SIMDs x clock).  I (SQ_INSTS_VALU) and the clock (SQ_BUSY_CYCLES of
     the 32 shader engines / 32 / the kernel's duration in the same pass) come from the committed rocprofv3 SQ pass of the same command
@@ -174,7 +174,9 @@ def valu_roofline(kernel_substrings, avg_ms, which="adaptive", exclude=()):
         if not clock:      # (round 4's file has no durations: the busy cycles of that pass over THIS run's launch)
             clock = v["SQ_BUSY_CYCLES"] / 32.0 / (avg_ms * 1e6)
             clock_src = "SQ_BUSY_CYCLES / 32 of the committed pass / this run's average launch"
-        per_step = v.get("dispatches_in_pass", 3) / float(v.get("steps_in_pass", 3))      # launches of this kernel per step (MVDR's solve: a main and a tail launch)
+        # launches of this kernel per step: one for the kernels of the localiser; MVDR's solve runs a main and a tail launch per step
+        # (launches_per_step None: the counter pass's dispatches over its steps -- that command has no per-kernel table pass)
+        per_step = launches_per_step if launches_per_step else v.get("dispatches_in_pass", 3) / float(v.get("steps_in_pass", 3))
         floor_ms = v["SQ_INSTS_VALU"] * per_step * 4.0 / (N_SIMD * clock * 1e9) * 1e3
         return {"bound": "valu", "insts_valu_per_launch": v["SQ_INSTS_VALU"], "launches_per_step": per_step, "cycles_per_wave_instruction": 4, "simds": N_SIMD, "clock_ghz": clock,
                 "clock_source": clock_src, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
@@ -633,7 +635,7 @@ def run_mvdr(args, world, rank, local_rank, dev, use_dist, dist):
         roof["binding"] = "valu"
         roof["flop_roofline"] = {"bound": "fp32 vector", "complex_macs_per_problem": cmac, "problems_per_step": K * S_ * F, "achieved": tf, "peak": FP32_VECTOR_TFLOPS,
                                  "unit": "TFLOP/s", "frac": tf / FP32_VECTOR_TFLOPS}
-        vr = valu_roofline(("k_mvdr_solve",), kt[dom]["avg_ms"], which="mvdr") if S_ == 256 and F == 64 else None
+        vr = valu_roofline(("k_mvdr_solve",), kt[dom]["avg_ms"], which="mvdr", launches_per_step=None) if S_ == 256 and F == 64 else None
         if vr:
             roof["valu_roofline"] = vr
         roof["note"] = ("`frac` is the HBM fraction of k_mvdr_solve's algorithmic bytes (the [bin][mic] spectra in, one beamformed bin out per problem); the kernel is "
