@@ -1594,10 +1594,10 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
                 CandArgs ca{};
                 ca.A = c->ws().d_Ax; ca.B = c->d_B; ca.Kp = c->Kp; ca.Dp = c->Dp; ca.a_row_elems = c->a_row_elems;
                 ca.list = c->ws().d_list; ca.n_list = c->ws().d_nlist; ca.list0 = (int)g0; ca.pass_rows = (int)pass_rows;
-                ca.umask = c->ws().d_umask; ca.umask_words = pa.umask_words; ca.groups_per_array = gpa; ca.n_frames = n_frames;
+                ca.umask = c->ws().d_umask; ca.umask_words = pa.umask_words; ca.need = c->ws().d_need; ca.groups_per_array = gpa; ca.n_frames = n_frames;
                 ca.C = c->ws().d_C; ca.c_planes = c->ws().c_planes; ca.c_plane_stride = c->ws().c_plane;
                 if (hist_valid) { ca.hist_C = c->d_hist_C[c->hist_cur]; ca.hist_base = n_arrays * gpa; }
-                const long long max_items = pass_rows / REPAIR_GROUP * CAND_SLOTS;
+                const long long max_items = pass_rows / REPAIR_GROUP;
                 hipLaunchKernelGGL(k_srp_cand, dim3((unsigned)std::min<long long>(max_items, std::max(1, c->kn.cand_grid))), dim3(1024), 0, st, ca);
                 continue;
             }

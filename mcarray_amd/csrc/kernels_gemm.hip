@@ -246,8 +246,9 @@ __global__ __launch_bounds__(256) void k_srp_gemm_repair(GemmArgs p)
 // the workgroup interleave the steps; their 16 x 16 partial 4 x 4 tiles are summed in LDS in a fixed order and the exact
 // values go straight into the map (plane 0; zeros into the other planes): no partial maps, no patch kernel, and a value's
 // bits depend on nothing but the row and the column.  Three products (lo hi, hi lo, hi hi) as the whole-row kernel.
-// A fixed grid walks (unit, slot): slot s of CAND_SLOTS takes the column groups s, s + CAND_SLOTS, ... -- one group (<= 8
-// columns, the usual flat-topped peak needs six) is slot 0's alone; a unit that asked for every column is shared by all slots.
+// A fixed grid walks the units; a unit's column groups (<= 8 columns each; the usual flat-topped peak needs six: one group) are
+// taken one after the other -- a unit that asked for every column (46 groups) keeps its workgroup for ~70 us; by construction
+// that is a frame whose coarse map has no guaranteed peak, and rows of exact zeros are not listed at all.
 // ---------------------------------------------------------------------------------------
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -268,10 +269,12 @@ __global__ __launch_bounds__(1024) void k_srp_cand(CandArgs p)
     const int b = lane >> 2, q = lane & 3;
     const int nst = (p.Kp + 127) / 128;
     const long long bplane = (long long)p.Dp * p.Kp;
-    for (int item = blockIdx.x; item < n_here * CAND_SLOTS; item += gridDim.x) {
-        const int slot = item / n_here, g = item - slot * n_here;     // (slot 0 of every unit first: the others mostly find nothing to do)
+    for (int g = blockIdx.x; g < n_here; g += gridDim.x) {
         const int e = p.list[p.list0 + g];
-        if (tid < words) s_mask[tid] = p.umask[(long long)e * words + tid];
+        // the unit is this workgroup's alone: its column mask is taken and cleared, its test-and-set word released (k_scan_pick of the next
+        // call finds both zero)
+        if (tid < words) { s_mask[tid] = p.umask[(long long)e * words + tid]; p.umask[(long long)e * words + tid] = 0u; }
+        if (tid == 0) p.need[e] = 0;
         __syncthreads();
         if (tid == 0) {
             int n = 0;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_srp_cand(CandArgs p)
         const int arr = eu / upa, f0 = (eu - arr * upa) * REPAIR_GROUP, f_lim = hist ? HIST_FRAMES : p.n_frames;
         float *crow0 = hist ? p.hist_C + ((long long)arr * HIST_FRAMES + f0) * p.Dp : p.C + ((long long)arr * p.n_frames + f0) * p.Dp;
         const _Float16 *pa = A + (long long)(g * REPAIR_GROUP + q) * p.a_row_elems + b * 8;
-        for (int c0 = slot * 8; c0 < ncols; c0 += CAND_SLOTS * 8) {
+        for (int c0 = 0; c0 < ncols; c0 += 8) {
             const _Float16 *pb1 = B + (long long)s_cols[min(c0 + q, ncols - 1)] * p.Kp + b * 8;
             const _Float16 *pb2 = B + (long long)s_cols[min(c0 + 4 + q, ncols - 1)] * p.Kp + b * 8;
             f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};

@@ -946,23 +946,9 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     }
     // the last workgroup to get here leaves both lists of the repair pass empty for the next call (every reader of n_list ran
     // before this kernel, every reader of n_clist is a workgroup of it that has counted itself in)
-    __shared__ int s_last;
     if (d == 0) {
         __threadfence();
-        s_last = atomicAdd(p.n_clist + 1, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (s_last) {
-        if (p.umask) {                       // candidate columns: the units' test-and-set words and column masks (k_srp_cand only read them)
-            const int n = *p.n_list;
-            for (int i = d; i < n; i += blockDim.x) {
-                const int e = p.list[i];
-                p.need[e] = 0;
-                for (int w = 0; w < p.umask_words; ++w) p.umask[(long long)e * p.umask_words + w] = 0u;
-            }
-            __syncthreads();
-        }
-        if (d == 0) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
+        if (atomicAdd(p.n_clist + 1, 1) == (int)gridDim.x - 1) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
     }
 }
 template __global__ void k_scan_repick<2>(ScanPickArgs);

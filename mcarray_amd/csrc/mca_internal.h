@@ -199,8 +199,8 @@ struct ScanPickArgs {
     float *hist_C_out, *e_hist_out;
     const float *hist_C_in, *e_hist_in;
     // candidate columns (round 5): per repair unit the delays its rows are needed at, one bit per column, umask_words = Dp / 32 words
-    // per unit (k_scan_pick ORs a flagged frame's candidate columns into every unit it lists; k_srp_cand reads them; the last workgroup
-    // of k_scan_repick clears them with the units' test-and-set words).  NULL: whole rows (k_srp_gemm_repair + k_repair_patch).
+    // per unit (k_scan_pick ORs a flagged frame's candidate columns into every unit it lists; k_srp_cand -- one workgroup per unit -- takes
+    // and clears them and releases the unit's test-and-set word).  NULL: whole rows (k_srp_gemm_repair + k_repair_patch).
     unsigned *umask; int umask_words;
 };
 
@@ -216,12 +216,12 @@ struct CandArgs {
     const void *B;           // steering table, fp16 hi + lo planes: [2][Dp][Kp]
     int Kp, Dp, a_row_elems;
     const int *list; const int *n_list; int list0, pass_rows;
-    const unsigned *umask; int umask_words;
+    unsigned *umask; int umask_words;                        // read and cleared
+    int *need;                                               // the units' test-and-set words, released here
     int groups_per_array, n_frames;
     float *C; int c_planes; long long c_plane_stride;       // plane 0 takes the exact value, the others zeros (as k_repair_patch)
     float *hist_C; int hist_base;                            // lazy tails: units >= hist_base are rows of hist_C
 };
-constexpr int CAND_SLOTS = 4;
 
 // The repair contraction runs on however many rows the coarse pass listed (a device-side count): the K range is what
 // parallelises.  It is cut into a number of segments that depends on the SHAPE of the call only (api.hip, repair_ksplit_for:
