@@ -628,7 +628,7 @@ __device__ __forceinline__ bool wave_candidates(const float *En, int D, float ta
 // learns which chunk its second pick has to restart from.  need / chunk_from are cleaned by the kernels that consume them
 // (k_repair_patch, k_scan_repick); the list's length is reset by k_scan_carry.
 template <int PL, int MODE>
-__global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_scan_pick(ScanPickArgs p)   // (two workgroups per CU: <= 128 VGPRs; the plan's last round spills two)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sEn = reinterpret_cast<float *>(smem_raw);                   // [SCAN_SUB][Dl]
@@ -636,6 +636,13 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     __shared__ float s_val[SCAN_SUB * MCA_MAX_SOURCES];
     __shared__ unsigned s_flagmask;                                     // MODE 1: the flags of a batch of SCAN_SUB (<= 32) frames
     __shared__ unsigned s_cm[MODE == 1 ? 10 : 1][CAND_WORDS_MAX];       // MODE 1: the candidate columns of the flagged frame a wave is planning
+    // MODE 1, candidate columns without the gate: the plan of the whole batch is put together in LDS -- the 12 repair units a chunk's frames
+    // can need (its own 8 and the 4 before it), their column masks, the earliest row -- and goes to the device-side lists in ONE round
+    constexpr int PLAN_UNITS = (SCAN_CHUNK + REPAIR_WARM) / REPAIR_GROUP;
+    __shared__ unsigned s_um[MODE == 1 ? PLAN_UNITS : 1][CAND_WORDS_MAX];
+    __shared__ unsigned s_uneed, s_ncol, s_nall;
+    __shared__ int s_umin, s_ue[MODE == 1 ? PLAN_UNITS : 1];
+    static_assert(REPAIR_WARM % REPAIR_GROUP == 0 && SCAN_CHUNK % REPAIR_GROUP == 0, "the units of a chunk's plan are whole");
     static_assert(SCAN_SUB <= 32, "one 32-bit mask per batch");
     static_assert(SCAN_CHUNK <= 64, "one ballot per chunk");
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6, nwaves = blockDim.x >> 6;
@@ -686,6 +693,10 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
         if (d == 0) s_flagmask = 0u;
+        if (MODE == 1 && p.umask && !vc) {
+            if (d < PLAN_UNITS * CAND_WORDS_MAX) (&s_um[0][0])[d] = 0u;
+            if (d == 0) { s_uneed = 0u; s_ncol = 0u; s_nall = 0u; s_umin = 0x7fffffff; }
+        }
         // the batch's frames that passed the power gate (all without it), one bit each: every wave works the mask out for itself
         // from one byte per lane (a load of vc[t] inside the recursion made every step of it a round trip to memory)
         const unsigned vmask = (unsigned)__ballot(lane < 32 && ts + (lane & 31) < te && (!vc || vc[ts + (lane & 31)] != 0));
@@ -756,18 +767,63 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
             if (d < te - ts) p.flags[(long long)a * p.n_frames + ts + d] = (fm >> d) & 1u;
             // plan the repair of the flagged frames, one wave per frame
             int k = 0;
-            for (unsigned rest = fm; rest; rest &= rest - 1, ++k) {
-                if (k % nwaves != wave) continue;
-                const int t = ts + __ffs((int)rest) - 1;
-                if (p.umask) {
+            const bool plan_lds = p.umask != nullptr && !vc;            // (candidate-column calls are ungated: a frame needs its own row and the 16 before it)
+            if (plan_lds) {
+                const int r_first = t_start - REPAIR_WARM;                // first row of local unit 0
+                const int u_lo = p.hist_valid ? -HIST_FRAMES : 0;         // lazy tails: the rows before the call are the previous call's last ones
+                for (unsigned rest = fm; rest; rest &= rest - 1, ++k) {
+                    if (k % nwaves != wave) continue;
+                    const int t = ts + __ffs((int)rest) - 1;
                     const bool all = wave_candidates<PL>(sEn + (t - ts) * Dl, D, p.tau, t == t_force || ((um >> (t - ts)) & 0x7full) != 0, s_cm[wave], p.umask_words, lane);
+                    const int r_lo = max(t - REPAIR_WARM, u_lo);
+                    // a unit is needed if one of the frame's rows in it is not a frame of exact zeros (those are zero in both maps)
+                    const int r = r_lo + lane;
+                    if (r <= t && !(p.dead && r >= 0 && p.dead[(long long)a * p.n_frames + r] != 0)) atomicOr(&s_uneed, 1u << ((r - r_first) >> 2));
+                    if (lane < p.umask_words) {
+                        const unsigned m = s_cm[wave][lane];
+                        if (m)
+#pragma nounroll
+                            for (int lu = (r_lo - r_first) >> 2; lu <= (t - r_first) >> 2; ++lu) atomicOr(&s_um[lu][lane], m);
+                    }
                     if (lane == 0) {
                         int nc = 0;
+#pragma nounroll
                         for (int w = 0; w < p.umask_words; ++w) nc += __popc(s_cm[wave][w]);
-                        atomicAdd(&p.stats[2], (unsigned long long)nc);
-                        if (all) atomicAdd(&p.stats[3], 1ull);
+                        atomicAdd(&s_ncol, (unsigned)nc);
+                        if (all) atomicAdd(&s_nall, 1u);
+                        atomicMin(&s_umin, r_lo);
                     }
                 }
+                __syncthreads();
+                if (fm) {
+                    const unsigned needed = s_uneed;
+                    if (d < PLAN_UNITS && ((needed >> d) & 1u)) {
+                        const int r0 = r_first + REPAIR_GROUP * d;
+                        const int e = r0 >= 0 ? a * p.groups_per_array + r0 / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + r0) / REPAIR_GROUP;
+                        s_ue[d] = e;
+                        if (atomicExch(&p.need[e], 1) == 0) {
+                            p.list[atomicAdd(p.n_list, 1)] = e;
+                            atomicAdd(&p.stats[1], 1ull);
+                        }
+                    }
+                    if (d == 64) {                                        // (another wave than the units')
+                        const int ci = a * p.n_chunks + (int)blockIdx.x, u_min = s_umin;
+                        if (atomicMin(&p.chunk_from[ci], u_min < 0 ? -1 : u_min / p.chunk) >= p.n_chunks) p.clist[atomicAdd(p.n_clist, 1)] = ci;
+                        atomicAdd(&p.stats[0], (unsigned long long)__popc(fm));
+                        atomicAdd(&p.stats[2], (unsigned long long)s_ncol);
+                        if (s_nall) atomicAdd(&p.stats[3], (unsigned long long)s_nall);
+                    }
+                    __syncthreads();
+                    if (d < PLAN_UNITS * p.umask_words) {
+                        const int j = d / p.umask_words, w = d - j * p.umask_words;
+                        const unsigned m = s_um[j][w];
+                        if (((needed >> j) & 1u) && m) atomicOr(&p.umask[(long long)s_ue[j] * p.umask_words + w], m);
+                    }
+                }
+            }
+            for (unsigned rest = plan_lds ? 0u : fm; rest; rest &= rest - 1, ++k) {      // whole-row calls (and the gate): round 4's plan, a frame at a time
+                if (k % nwaves != wave) continue;
+                const int t = ts + __ffs((int)rest) - 1;
                 // the rows this frame's energy depends on: its own and those of the REPAIR_WARM frames before it that advanced
                 // the recursion (all of them without the gate, the voiced ones with it), 64 frames per step backwards
                 int remaining = REPAIR_WARM + 1, u_min = t;
@@ -778,9 +834,7 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                     const unsigned long long m = __ballot(on);
                     const int above = lane < 63 ? __popcll(m >> (lane + 1)) : 0;   // advancing frames after u in this window
                     const bool take = on && above < remaining;
-                    // (a frame of exact zeros: its row is zero in the coarse and in the exact map alike -- counted as a warm row, not listed)
-                    const bool listed = take && !(p.dead && u >= 0 && p.dead[(long long)a * p.n_frames + u] != 0);
-                    if (listed) {
+                    if (take) {
                         const int e = u >= 0 ? a * p.groups_per_array + u / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + u) / REPAIR_GROUP;
                         if (atomicExch(&p.need[e], 1) == 0) {
                             p.list[atomicAdd(p.n_list, 1)] = e;
@@ -788,15 +842,6 @@ __global__ __launch_bounds__(512) void k_scan_pick(ScanPickArgs p)
                         }
                     }
                     const unsigned long long mt = __ballot(take);
-                    const unsigned long long ml = __ballot(listed);
-                    if (p.umask && listed && !(((u + HIST_FRAMES) & (REPAIR_GROUP - 1)) != 0 && lane > 0 && ((ml >> (lane - 1)) & 1ull))) {
-                        // the frame's candidate columns onto the unit (once per unit: not from a lane whose left neighbour lists the same one)
-                        const int e = u >= 0 ? a * p.groups_per_array + u / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + u) / REPAIR_GROUP;
-                        for (int w = 0; w < p.umask_words; ++w) {
-                            const unsigned m = s_cm[wave][w];
-                            if (m) atomicOr(&p.umask[(long long)e * p.umask_words + w], m);
-                        }
-                    }
                     if (mt) u_min = hi - 63 + (__ffsll((long long)mt) - 1);
                     remaining -= __popcll(m);
                 }
