@@ -569,7 +569,7 @@ __device__ __forceinline__ bool wave_candidates(const float *En, int D, float ta
     float thr = 0.f;
     if (!full) {
         unsigned neg = 0u, unc = 0u;                                        // bit c: first difference j = clamp(b - 1 + c, 0, D - 2) (as wave_pick_pl)
-#pragma nounroll
+#pragma unroll 4
         for (int c = 0; c < PL + G + 3; ++c) {
             const int j = min(max(b - 1 + c, 0), max(D - 2, 0));
             const float df = En[min(j + 1, D - 1)] - En[j];
@@ -585,7 +585,7 @@ __device__ __forceinline__ bool wave_candidates(const float *En, int D, float ta
         for (int i = 0; i < PL; ++i) {
             float mn = INFINITY;
             bool open = ((up >> i) & 1u) != 0u;
-#pragma nounroll
+#pragma unroll
             for (int g = 1; g <= G; ++g) {
                 mn = fminf(mn, En[min(b + i + g, D - 1)]);                  // En[(b + i + g - 1) + 1]: the value of a step up at position b + i + g - 1
                 if (open && ((down >> (i + g)) & 1u) && b + i + g - 1 < D - 2) lv = fmaxf(lv, mn);
@@ -603,7 +603,7 @@ __device__ __forceinline__ bool wave_candidates(const float *En, int D, float ta
     }
     wave_lds_fence();
     if (!full) {
-#pragma nounroll
+#pragma unroll 3
         for (int i = 0; i < PL; ++i) {
             if (b + i < D - 2 && fabsf(En[min(b + i + 1, D - 1)]) >= thr) {
                 // position b + i reads En[b + i - 1 .. b + i + 3] (two first differences either side of its own two, :159-173)
