@@ -62,7 +62,7 @@ typedef enum {
                                 FP16X3's energies).  Picks that are TIES at that level -- two candidates, or a first difference
                                 against zero, closer than 1e-6 of the row's largest normalised energy: the bar of the parity tests
                                 -- may resolve differently from FP16X3 and between calls of different shapes.  Measured over 40
-                                random configurations / 696 320 frames: 42 picks on 30 frames differ from FP16X3, all 30 such ties
+                                random configurations / 696 320 frames: 41 picks on 29 frames differ from FP16X3, all 29 such ties
                                 (profiles/r05_adaptive_check.json; the warm-row count of 16 against 24: r04_adaptive_check_warm24.json).
                                 ROUND 5, device-pointer calls of 4 / 8-microphone contexts without the gate: (a) LAZY TAILS -- the
                                 call does not repeat its last frame for the state's sake; it keeps its last 16 frames of PCM, their

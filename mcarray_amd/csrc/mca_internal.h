@@ -35,7 +35,7 @@ constexpr int REPAIR_WARM = MCA_REPAIR_WARM;   // exact rows recomputed BEFORE a
                                   // when a call has many arrays and few frames -- 128 x 256: 13.9 % of the rows with 24, 10.7 % with 16.
                                   // Round 4, ADVICE r3: the flips against FP16X3 over 40 configurations / 696 320 frames are the SAME with
                                   // 16 and with 24 rows, every differing frame a tie at the parity bar's level (profiles/r04_adaptive_check.json /
-                                  // _warm24.json; the count of the shipped build is the one in include/mcarray_hip.h: 42 picks on 30 frames,
+                                  // _warm24.json; the count of the shipped build is the one in include/mcarray_hip.h: 41 picks on 29 frames,
                                   // profiles/r05_adaptive_check.json); 24 rows cost +12 % / +30 % repair time at 8 x 4096 / 128 x 256.)
 constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mode pass of a k_stft_phat workgroup
 // Lazy tails (round 5; ADAPTIVE, ungated, the wave-per-run analysis): a call does NOT recompute its last REPAIR_WARM + 1 rows exactly for the
