@@ -54,7 +54,7 @@ struct Knobs {
     bool gemm_ks2 = false;             // MCA_HIP_GEMM_KS2: two K halves for 16 384 ... 32 767 rows (round 4) instead of four quarters
     bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
          v1_nosplit = false, no_n512 = false, no_sub2 = false;
-    int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256;
+    int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256, list_grid = 512;
     bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
     int spw_waves = 4;                 // MCA_HIP_SPW_WAVES: 8 = the regular launches of k_stft_phat_wave as one workgroup of eight waves per CU
     int bfw_skew = -1;                 // MCA_HIP_BFW_SKEW: BeamformWaveArgs::skew (-1: the shipped rule, 0: off)
@@ -294,6 +294,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.repair_ksplit = (int)geti(measure_env("MCA_HIP_REPAIR_KSPLIT"), 0);
     k.v2_min_rows = (int)geti(measure_env("MCA_HIP_V2_MIN_ROWS"), 0);
     k.repick_grid = (int)geti(measure_env("MCA_HIP_REPICK_GRID"), 256);
+    k.list_grid = (int)geti(measure_env("MCA_HIP_LIST_GRID"), 512);
     k.dyn = measure_env("MCA_HIP_DYN") != nullptr;
     k.dyn_len0 = (int)geti(measure_env("MCA_HIP_DYN_LEN0"), 0);
     k.dyn_flat = measure_env("MCA_HIP_DYN_FLAT") != nullptr;
@@ -1588,7 +1589,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             if (hist_valid) { sa.hist_in = c->d_hist_pcm[c->hist_cur]; sa.hist_base = n_arrays * gpa; }
             const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
             // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
-            if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, 512), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
+            if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, std::max(1, c->kn.list_grid)), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
             if (pa.umask) {
                 // candidate columns: the exact values where the flagged frames need them, straight into the map (no partial maps, no patch)
                 CandArgs ca{};

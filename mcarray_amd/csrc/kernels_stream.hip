@@ -991,9 +991,12 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     }
     // the last workgroup to get here leaves both lists of the repair pass empty for the next call (every reader of n_list ran
     // before this kernel, every reader of n_clist is a workgroup of it that has counted itself in)
-    if (d == 0) {
+    // (only the workgroups that had a chunk to work on count themselves in -- min(grid, listed chunks) of them, a number every workgroup
+    // knows; with nothing listed workgroup 0 does the reset: 256 fences and atomics on one word cost the kernel 3 of its 15 us)
+    const int n_part = min((int)gridDim.x, n_listed);
+    if (d == 0 && ((int)blockIdx.x < n_part || (n_part == 0 && blockIdx.x == 0))) {
         __threadfence();
-        if (atomicAdd(p.n_clist + 1, 1) == (int)gridDim.x - 1) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
+        if (atomicAdd(p.n_clist + 1, 1) >= max(n_part, 1) - 1) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
     }
 }
 template __global__ void k_scan_repick<2>(ScanPickArgs);
