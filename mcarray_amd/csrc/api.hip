@@ -48,6 +48,7 @@ struct Knobs {
     bool scan_carry = false;           // MCA_HIP_SCAN_CARRY / cfg.scan_carry
     bool lazy_ks_shape = false;        // (measurement) MCA_HIP_LAZY_KS_SHAPE: the repair contraction's K segments by the call's shape also with lazy tails
     int cand = -1;                     // MCA_HIP_ADAPT_CAND: -1 / unset = by the back-off policy's reports (cand_call), 1 = wherever the call's shape allows, 0 = never (whole-row repair kernels)
+    bool cand_fuse = true;             // (measurement) MCA_HIP_CAND_FUSE=0: k_srp_cand as a launch of its own
     int cand_grid = 512;               // (measurement) MCA_HIP_CAND_GRID: workgroups of k_srp_cand
     bool lazy_tails = true;            // MCA_HIP_ADAPT_LAZY=0: every adaptive call repairs its own last rows for the state it hands over (round 4)
     // measurement only (-DMCA_MEASURE)
@@ -277,6 +278,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.repair_items = (int)geti(measure_env("MCA_HIP_REPAIR_ITEMS"), 768);
     if (const char *v = env_str("MCA_HIP_ADAPT_CAND")) k.cand = std::atoi(v) != 0 ? 1 : 0;
     k.cand_grid = (int)geti(measure_env("MCA_HIP_CAND_GRID"), 512);
+    k.cand_fuse = geti(measure_env("MCA_HIP_CAND_FUSE"), 1) != 0;
     k.stft_wg = measure_env("MCA_HIP_STFT_WG") != nullptr;
     k.bf_ola = measure_env("MCA_HIP_BF_OLA") != nullptr;
     k.bf_occ2 = measure_env("MCA_HIP_BF_OCC2") != nullptr;
@@ -864,7 +866,10 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
         } while (0)
 #define LAUNCH_W(MT, U)                                                                                              \
         do {                                                                                                         \
-            if constexpr (sizeof(OutT) == 2) { if (pl2) LAUNCH_W2(MT, U, true, false); else LAUNCH_W2(MT, U, false, false); } \
+            if constexpr (sizeof(OutT) == 2) {                                                                       \
+                if (pl2 && w.cand_on && a.list && !pw) LAUNCH_K((k_stft_phat_wave<MT, U, OutT, true, false, false, false, true>)); \
+                else if (pl2) LAUNCH_W2(MT, U, true, false); else LAUNCH_W2(MT, U, false, false);                    \
+            }                                                                                                        \
             else { if (a.no_phat) LAUNCH_W2(MT, U, false, true); else LAUNCH_W2(MT, U, false, false); }              \
         } while (0)
         if constexpr (sizeof(OutT) == 2) {
@@ -1587,17 +1592,22 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
             sa.list = c->ws().d_list; sa.n_list = c->ws().d_nlist; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = gpa;
             if (hist_valid) { sa.hist_in = c->d_hist_pcm[c->hist_cur]; sa.hist_base = n_arrays * gpa; }
-            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
-            // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
-            if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, std::max(1, c->kn.list_grid)), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
+            CandArgs ca{};
             if (pa.umask) {
-                // candidate columns: the exact values where the flagged frames need them, straight into the map (no partial maps, no patch)
-                CandArgs ca{};
+                // candidate columns: the exact values where the flagged frames need them, straight into the map (no partial maps, no patch) --
+                // by the workgroup that writes a unit's rows, inside the list-mode launch (4 / 8 microphones: k_stft_phat_wave)
                 ca.A = c->ws().d_Ax; ca.B = c->d_B; ca.Kp = c->Kp; ca.Dp = c->Dp; ca.a_row_elems = c->a_row_elems;
                 ca.list = c->ws().d_list; ca.n_list = c->ws().d_nlist; ca.list0 = (int)g0; ca.pass_rows = (int)pass_rows;
                 ca.umask = c->ws().d_umask; ca.umask_words = pa.umask_words; ca.need = c->ws().d_need; ca.groups_per_array = gpa; ca.n_frames = n_frames;
                 ca.C = c->ws().d_C; ca.c_planes = c->ws().c_planes; ca.c_plane_stride = c->ws().c_plane;
                 if (hist_valid) { ca.hist_C = c->d_hist_C[c->hist_cur]; ca.hist_base = n_arrays * gpa; }
+                if (c->kn.cand_fuse && (c->M == 8 || c->M == 4) && !c->kn.stft_wg) { sa.cand_on = 1; sa.cand = ca; }
+            }
+            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
+            // fixed, moderate grids: the kernels of the repair pass walk their device-side work lists
+            if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, std::max(1, c->kn.list_grid)), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
+            if (pa.umask && sa.cand_on) continue;
+            if (pa.umask) {
                 const long long max_items = pass_rows / REPAIR_GROUP;
                 hipLaunchKernelGGL(k_srp_cand, dim3((unsigned)std::min<long long>(max_items, std::max(1, c->kn.cand_grid))), dim3(1024), 0, st, ca);
                 continue;

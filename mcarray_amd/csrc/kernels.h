@@ -26,7 +26,7 @@ __global__ void k_bf_table(float2 *tab, const float *grid, const double *mic_x, 
 template <bool ODD, int VAR, int ABL> __global__ void k_beamform_wave(BeamformWaveArgs p);
 template <bool POWER> __global__ void k_stft_phat_wave16(StftPhatArgs p);   // 16-microphone ULA, one fp16 plane
 template <int NPT, bool ODD> __global__ void k_beamform_wave_ms(BeamformWaveArgs p);   // several sources, forward transforms shared (M <= 8)
-template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT, bool MERGE> __global__ void k_stft_phat_wave(StftPhatArgs p);
+template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT, bool MERGE, bool CAND = false> __global__ void k_stft_phat_wave(StftPhatArgs p);
 
 __global__ void k_srp_gemm_f32(GemmArgs p);
 template <bool SPLIT, int BN> __global__ void k_srp_gemm_f16(GemmArgs p);

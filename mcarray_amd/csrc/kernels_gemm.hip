@@ -10,6 +10,7 @@
 //   k_srp_gemm_f32   v_mfma_f32_32x32x2_f32: bit-exact fp32 fma chain, parity anchor
 //   k_srp_gemm_f16   v_mfma_f32_32x32x16_f16 with 1 (fp16) or 3 (fp16x3 hi/lo split) products
 #include "mca_internal.h"
+#include "cand_unit.h"
 
 namespace mca {
 
@@ -238,129 +239,15 @@ __global__ __launch_bounds__(256) void k_srp_gemm_repair(GemmArgs p)
 }
 
 // ---------------------------------------------------------------------------------------
-// k_srp_cand -- the repair contraction at the CANDIDATE COLUMNS only (CandArgs, mca_internal.h).
-// A workgroup takes one listed repair unit (4 rows) and the columns that unit asked for, eight at a time.  The shape is 4 x 8
-// with a depth of thousands, so the matrix instruction is the 16-block 4 x 4 x 4 one with the BLOCKS AS DEPTH SLICES: lane
-// 4 b + q holds row q of A / column q of B over the eight depth positions of slice b of a 128-deep step (one 16-byte load per
-// operand and plane; the sixteen lanes of a row read 256 contiguous bytes), two instructions per load.  The sixteen waves of
-// the workgroup interleave the steps; their 16 x 16 partial 4 x 4 tiles are summed in LDS in a fixed order and the exact
-// values go straight into the map (plane 0; zeros into the other planes): no partial maps, no patch kernel, and a value's
-// bits depend on nothing but the row and the column.  Three products (lo hi, hi lo, hi hi) as the whole-row kernel.
-// A fixed grid walks the units; a unit's column groups (<= 8 columns each; the usual flat-topped peak needs six: one group) are
-// taken one after the other -- a unit that asked for every column (46 groups) keeps its workgroup for ~70 us; by construction
-// that is a frame whose coarse map has no guaranteed peak, and rows of exact zeros are not listed at all.
+// k_srp_cand -- the repair contraction at the CANDIDATE COLUMNS only (CandArgs, mca_internal.h): one workgroup of sixteen waves per
+// listed unit, cand_unit.h.  A fixed grid walks the units.  (4 / 8-microphone contexts do this inside the list-mode analysis launch,
+// StftPhatArgs::cand_on; this launch serves the contexts whose list-mode analysis is another kernel.)
 // ---------------------------------------------------------------------------------------
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(1024) void k_srp_cand(CandArgs p)
 {
-    __shared__ float red[16][2][4][64];                               // [wave][column group][register = row][lane = 4 slice + column]
-    __shared__ float red2[32][8];
-    __shared__ unsigned s_mask[CAND_WORDS_MAX];
-    __shared__ int s_pre[CAND_WORDS_MAX + 1];
-    __shared__ unsigned short s_cols[CAND_WORDS_MAX * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[cand_unit_lds_bytes<16>()];
     const int n_here = min(*p.n_list - p.list0, p.pass_rows / REPAIR_GROUP);
-    if (n_here <= 0) return;
-    const int words = p.umask_words;
-    const _Float16 *A = reinterpret_cast<const _Float16 *>(p.A);
-    const _Float16 *B = reinterpret_cast<const _Float16 *>(p.B);
-    const int b = lane >> 2, q = lane & 3;
-    const int nst = (p.Kp + 127) / 128;
-    const long long bplane = (long long)p.Dp * p.Kp;
-    for (int g = blockIdx.x; g < n_here; g += gridDim.x) {
-        const int e = p.list[p.list0 + g];
-        // the unit is this workgroup's alone: its column mask is taken and cleared, its test-and-set word released (k_scan_pick of the next
-        // call finds both zero)
-        if (tid < words) { s_mask[tid] = p.umask[(long long)e * words + tid]; p.umask[(long long)e * words + tid] = 0u; }
-        if (tid == 0) p.need[e] = 0;
-        __syncthreads();
-        if (tid == 0) {
-            int n = 0;
-            for (int w = 0; w < words; ++w) { s_pre[w] = n; n += __popc(s_mask[w]); }
-            s_pre[words] = n;
-        }
-        __syncthreads();
-        const int ncols = s_pre[words];
-        if (tid < words * 32) {
-            const unsigned m = s_mask[tid >> 5];
-            if ((m >> (tid & 31)) & 1u) s_cols[s_pre[tid >> 5] + __popc(m & ((1u << (tid & 31)) - 1u))] = (unsigned short)tid;
-        }
-        __syncthreads();
-        // where the unit's rows live (as k_repair_patch): a unit of the previous call's last frames goes into the history's own map
-        const bool hist = p.hist_C != nullptr && e >= p.hist_base;
-        const int eu = hist ? e - p.hist_base : e, upa = hist ? HIST_UNITS : p.groups_per_array;
-        const int arr = eu / upa, f0 = (eu - arr * upa) * REPAIR_GROUP, f_lim = hist ? HIST_FRAMES : p.n_frames;
-        float *crow0 = hist ? p.hist_C + ((long long)arr * HIST_FRAMES + f0) * p.Dp : p.C + ((long long)arr * p.n_frames + f0) * p.Dp;
-        const _Float16 *pa = A + (long long)(g * REPAIR_GROUP + q) * p.a_row_elems + b * 8;
-        for (int c0 = 0; c0 < ncols; c0 += 8) {
-            const _Float16 *pb1 = B + (long long)s_cols[min(c0 + q, ncols - 1)] * p.Kp + b * 8;
-            const _Float16 *pb2 = B + (long long)s_cols[min(c0 + 4 + q, ncols - 1)] * p.Kp + b * 8;
-            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-            for (int st0 = wave; st0 < nst; st0 += 64) {
-                // four steps of this wave in flight: 24 sixteen-byte loads, then their 48 matrix instructions
-                f16x8 ah[4], al[4], b1h[4], b1l[4], b2h[4], b2l[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = (st0 + 16 * u) * 128;
-                    const bool on = k + b * 8 < p.Kp;                    // (the depth is a multiple of 32, a step takes 128; st0 + 16 u may be past the end)
-                    const int ks = on ? k : 0;
-                    ah[u] = *reinterpret_cast<const f16x8 *>(pa + ks); al[u] = *reinterpret_cast<const f16x8 *>(pa + p.Kp + ks);
-                    b1h[u] = *reinterpret_cast<const f16x8 *>(pb1 + ks); b1l[u] = *reinterpret_cast<const f16x8 *>(pb1 + bplane + ks);
-                    b2h[u] = *reinterpret_cast<const f16x8 *>(pb2 + ks); b2l[u] = *reinterpret_cast<const f16x8 *>(pb2 + bplane + ks);
-                    if (!on) {
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) { ah[u][x] = (_Float16)0.f; al[u][x] = (_Float16)0.f; }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const f16x4 xh = {ah[u][4 * hh], ah[u][4 * hh + 1], ah[u][4 * hh + 2], ah[u][4 * hh + 3]}, xl = {al[u][4 * hh], al[u][4 * hh + 1], al[u][4 * hh + 2], al[u][4 * hh + 3]};
-                        const f16x4 y1h = {b1h[u][4 * hh], b1h[u][4 * hh + 1], b1h[u][4 * hh + 2], b1h[u][4 * hh + 3]}, y1l = {b1l[u][4 * hh], b1l[u][4 * hh + 1], b1l[u][4 * hh + 2], b1l[u][4 * hh + 3]};
-                        const f16x4 y2h = {b2h[u][4 * hh], b2h[u][4 * hh + 1], b2h[u][4 * hh + 2], b2h[u][4 * hh + 3]}, y2l = {b2l[u][4 * hh], b2l[u][4 * hh + 1], b2l[u][4 * hh + 2], b2l[u][4 * hh + 3]};
-                        // small terms first so they are not absorbed by the large partial sum
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(xl, y1h, acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh, y1l, acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh, y1h, acc1, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_4x4x4f16(xl, y2h, acc2, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh, y2l, acc2, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh, y2h, acc2, 0, 0, 0);
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { red[wave][0][i][lane] = acc1[i]; red[wave][1][i][lane] = acc2[i]; }
-            __syncthreads();
-            // element el = (group, row i, column j) of the 4 x 8 result: 256 partial values (16 waves x 16 slices), summed in the order
-            // (wave, slice) -- eight threads take 32 each, one adds the eight
-            if (tid < 256) {
-                const int el = tid >> 3, part = tid & 7, grp = el >> 4, i = (el >> 2) & 3, j = el & 3;
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < 2; ++w)
-#pragma unroll
-                    for (int sl = 0; sl < 16; ++sl) v += red[2 * part + w][grp][i][4 * sl + j];
-                red2[el][part] = v;
-            }
-            __syncthreads();
-            if (tid < 32) {
-                const int grp = tid >> 4, i = (tid >> 2) & 3, j = tid & 3, ci = c0 + 4 * grp + j;
-                float v = red2[tid][0];
-#pragma unroll
-                for (int part = 1; part < 8; ++part) v += red2[tid][part];
-                if (ci < ncols && f0 + i < f_lim) {
-                    float *dst = crow0 + (long long)i * p.Dp + s_cols[ci];
-                    *dst = v;
-                    if (!hist)
-                        for (int pl = 1; pl < p.c_planes; ++pl) dst[pl * p.c_plane_stride] = 0.f;
-                }
-            }
-            __syncthreads();
-        }
-        __syncthreads();                                            // (s_mask / s_cols are rewritten by the next item)
-    }
+    for (int g = blockIdx.x; g < n_here; g += gridDim.x) cand_unit<16>(p, g, p.list[p.list0 + g], lds, (int)threadIdx.x);
 }
 
 template __global__ void k_srp_gemm_repair<192>(GemmArgs);

@@ -15,6 +15,7 @@
 
 #include "fft1024c.h"
 #include "mca_internal.h"
+#include "cand_unit.h"
 #include "phat_pairs.h"
 
 namespace mca {
@@ -420,7 +421,7 @@ __device__ __forceinline__ float wave_sum64(float v)
 // the lane's 8 x (M - 1) sums go into the wave's LDS region (the transform's scratch, free by then) with ds_add_f32 at
 // rank[m] -- every instruction hits 64 different words and the instructions of a wave execute in order, so the sums are
 // formed in a fixed order --, and the region is read back as the row: n_merged instead of (M - 1) * 513 complex values.
-template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT, bool MERGE>
+template <int MT, bool ULA, typename OutT, bool PL2, bool POWER, bool NOPHAT, bool MERGE, bool CAND = false>
 __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 4 or 8 waves (256 registers either way: two waves per SIMD)
 {
     static_assert(!MERGE || (ULA && !PL2 && !NOPHAT && sizeof(OutT) == 2), "the merged index serves the one-plane fp16 rows of a ULA");
@@ -495,8 +496,10 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
         }
         long long row_base = (long long)a * p.n_frames;     // A row of frame f = row_base + f
         bool hist_unit = false;                                // list mode, lazy tails: a unit of the PREVIOUS call's last frames (StftPhatArgs::hist_in)
+        int e_unit = 0;
         if (p.list) {
             const int e = li == p.list0 + (int)blockIdx.x ? e_first : p.list[li];
+            e_unit = e;
             hist_unit = p.hist_in != nullptr && e >= p.hist_base;
             const int eu = hist_unit ? e - p.hist_base : e, upa = hist_unit ? HIST_UNITS : p.groups_per_array;
             a = eu / upa;
@@ -504,10 +507,12 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
             row_base = (long long)(li - p.list0) * REPAIR_GROUP - g_begin;
             f_begin = g_begin + wave; f_end = min(f_begin + 1, hist_unit ? HIST_FRAMES : p.n_frames);
         }
-        if (f_begin >= f_end) {
+        const bool has_frame = f_begin < f_end;
+        if (!has_frame) {
             if (p.queue) break;                     // (cannot happen: every listed run holds a frame)
-            continue;
+            if (!CAND) continue;                    // (candidate-column list mode: the wave still helps to contract the unit's rows below)
         }
+        if (has_frame) {
         const float *base = hist_unit ? p.hist_in + (long long)a * MT * HIST_SAMPLES + lane : p.pcm + (long long)a * p.array_stride + lane;
         const long long mstride = hist_unit ? (long long)HIST_SAMPLES : p.mic_stride;
         const int fr0 = hist_unit ? 0 : p.frame0;
@@ -712,7 +717,17 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
 #pragma unroll
             for (int g = 0; g < NOUT; ++g) store_a_wave<PL2>(arow, 0u, g * KG + FFT_H, out[g], p.Kp);
         }
+        }
         wave_lds_fence();
+        if constexpr (CAND) {
+            static_assert(!CAND || PL2, "the candidate contraction reads the two-plane rows of the list mode");
+            {
+                // candidate columns: the unit's four rows are written -- by this workgroup, through this CU's L1 -- and are contracted at the
+                // unit's columns right here (cand_unit.h), in the transforms' scratch
+                __syncthreads();
+                cand_unit<4>(p.cand, li - p.list0, e_unit, reinterpret_cast<unsigned char *>(wbase), tid);
+            }
+        }
         if (p.queue) rq = __builtin_amdgcn_readfirstlane(rq_pending);
         ++runs_taken;
     }
@@ -928,5 +943,10 @@ template __global__ void k_stft_phat_wave<8, true, _Float16, false, false, false
 template __global__ void k_stft_phat_wave<8, true, _Float16, false, true, false, true>(StftPhatArgs);
 template __global__ void k_stft_phat_wave<4, true, _Float16, false, false, false, true>(StftPhatArgs);
 template __global__ void k_stft_phat_wave<4, true, _Float16, false, true, false, true>(StftPhatArgs);
+// list mode of a candidate-column call: two planes, no gate, with the candidate contraction of the unit behind its rows (CAND)
+template __global__ void k_stft_phat_wave<8, true, _Float16, true, false, false, false, true>(StftPhatArgs);
+template __global__ void k_stft_phat_wave<8, false, _Float16, true, false, false, false, true>(StftPhatArgs);
+template __global__ void k_stft_phat_wave<4, true, _Float16, true, false, false, false, true>(StftPhatArgs);
+template __global__ void k_stft_phat_wave<4, false, _Float16, true, false, false, false, true>(StftPhatArgs);
 
 }  // namespace mca

@@ -46,6 +46,25 @@ constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mo
 constexpr int HIST_FRAMES = REPAIR_WARM, HIST_UNITS = HIST_FRAMES / REPAIR_GROUP, HIST_SAMPLES = (HIST_FRAMES + 1) * 512;
 static_assert(HIST_FRAMES % REPAIR_GROUP == 0, "history = whole repair units");
 
+// k_srp_cand: the exact values of the listed rows AT THEIR CANDIDATE COLUMNS, written straight into the map.
+// Which columns: a flagged frame's S picks are, on the exact map, among the positions whose coarse |En| reaches v - tau, v the S-th
+// largest coarse peak whose four first differences are all pinned (|d| > tau) -- such a peak exists on the exact map with a value
+// >= v - tau / 2, and a position below v - tau cannot reach that -- plus the two columns either side that feed the sign / median
+// chain (:159-173) of such a position.  The second pick then runs on a row that is exact wherever it matters and coarse elsewhere.
+// Frames flagged for the state's sake (eager tails) or because the coarse analysis could not vouch for a row (unsure) take every column.
+constexpr int CAND_WORDS_MAX = 20;          // Dp <= 640 (the peak pick handles D <= 514)
+struct CandArgs {
+    const void *A;           // exact analysis rows of the listed units, fp16 hi + lo planes: [rows][a_row_elems], row = 4 x list position + frame
+    const void *B;           // steering table, fp16 hi + lo planes: [2][Dp][Kp]
+    int Kp, Dp, a_row_elems;
+    const int *list; const int *n_list; int list0, pass_rows;
+    unsigned *umask; int umask_words;                        // read and cleared
+    int *need;                                               // the units' test-and-set words, released here
+    int groups_per_array, n_frames;
+    float *C; int c_planes; long long c_plane_stride;       // plane 0 takes the exact value, the others zeros (as k_repair_patch)
+    float *hist_C; int hist_base;                            // lazy tails: units >= hist_base are rows of hist_C
+};
+
 struct StftPhatArgs {
     const float *pcm;
     long long array_stride, mic_stride;
@@ -90,6 +109,9 @@ struct StftPhatArgs {
                              // frame is at the rounding level of the transform.  PHAT keeps only the SIGN of such a bin, and the exact rows of 16
                              // microphones come from another kernel (k_stft_phat<16>) that need not round it the same way: k_scan_pick repairs the
                              // frame and the six after it whatever the map says ("A limit of PHAT itself")
+    // list mode of a candidate-column call: the workgroup that wrote a unit's four rows contracts them at the unit's columns (cand_unit.h) --
+    // k_srp_cand's work without its launch
+    int cand_on; CandArgs cand;
 };
 
 // The run schedule of the dynamic mode, the same arithmetic on the host (the number of runs) and in the kernel (run r -> array, frames):
@@ -202,25 +224,6 @@ struct ScanPickArgs {
     // per unit (k_scan_pick ORs a flagged frame's candidate columns into every unit it lists; k_srp_cand -- one workgroup per unit -- takes
     // and clears them and releases the unit's test-and-set word).  NULL: whole rows (k_srp_gemm_repair + k_repair_patch).
     unsigned *umask; int umask_words;
-};
-
-// k_srp_cand: the exact values of the listed rows AT THEIR CANDIDATE COLUMNS, written straight into the map.
-// Which columns: a flagged frame's S picks are, on the exact map, among the positions whose coarse |En| reaches v - tau, v the S-th
-// largest coarse peak whose four first differences are all pinned (|d| > tau) -- such a peak exists on the exact map with a value
-// >= v - tau / 2, and a position below v - tau cannot reach that -- plus the two columns either side that feed the sign / median
-// chain (:159-173) of such a position.  The second pick then runs on a row that is exact wherever it matters and coarse elsewhere.
-// Frames flagged for the state's sake (eager tails) or because the coarse analysis could not vouch for a row (unsure) take every column.
-constexpr int CAND_WORDS_MAX = 20;          // Dp <= 640 (the peak pick handles D <= 514)
-struct CandArgs {
-    const void *A;           // exact analysis rows of the listed units, fp16 hi + lo planes: [rows][a_row_elems], row = 4 x list position + frame
-    const void *B;           // steering table, fp16 hi + lo planes: [2][Dp][Kp]
-    int Kp, Dp, a_row_elems;
-    const int *list; const int *n_list; int list0, pass_rows;
-    unsigned *umask; int umask_words;                        // read and cleared
-    int *need;                                               // the units' test-and-set words, released here
-    int groups_per_array, n_frames;
-    float *C; int c_planes; long long c_plane_stride;       // plane 0 takes the exact value, the others zeros (as k_repair_patch)
-    float *hist_C; int hist_base;                            // lazy tails: units >= hist_base are rows of hist_C
 };
 
 // The repair contraction runs on however many rows the coarse pass listed (a device-side count): the K range is what
