@@ -46,12 +46,14 @@ constexpr int REPAIR_GROUP = 4;   // frames per repair unit = frames per list-mo
 constexpr int HIST_FRAMES = REPAIR_WARM, HIST_UNITS = HIST_FRAMES / REPAIR_GROUP, HIST_SAMPLES = (HIST_FRAMES + 1) * 512;
 static_assert(HIST_FRAMES % REPAIR_GROUP == 0, "history = whole repair units");
 
-// k_srp_cand: the exact values of the listed rows AT THEIR CANDIDATE COLUMNS, written straight into the map.
-// Which columns: a flagged frame's S picks are, on the exact map, among the positions whose coarse |En| reaches v - tau, v the S-th
-// largest coarse peak whose four first differences are all pinned (|d| > tau) -- such a peak exists on the exact map with a value
-// >= v - tau / 2, and a position below v - tau cannot reach that -- plus the two columns either side that feed the sign / median
-// chain (:159-173) of such a position.  The second pick then runs on a row that is exact wherever it matters and coarse elsewhere.
-// Frames flagged for the state's sake (eager tails) or because the coarse analysis could not vouch for a row (unsure) take every column.
+// cand_unit.h / k_srp_cand: the exact values of the listed rows AT THEIR CANDIDATE COLUMNS, written straight into the map.
+// Which columns (wave_candidates, kernels_stream.hip): a flagged frame's pick is, on the exact map, among the positions whose coarse |En|
+// reaches v - tau, v the best GUARANTEED peak of the coarse row -- a window in which the median-filtered sign chain, with every first
+// difference within tau taken as of either sign, is pinned to "rising" at one end and to "falling" at the other: the exact map has a
+// peak in there worth at least the window's smallest coarse energy - tau / 2, and a position below v - tau cannot reach that -- plus the
+// two columns either side that feed the sign / median chain (:159-173) of such a position.  The second pick then runs on a row that is
+// exact wherever it matters and coarse elsewhere.  A frame without such a window (a flat map) takes every column; the contexts that flag
+// whole rows by construction (eager tails, unsure rows, several sources) keep the whole-row kernels (api.hip, cand_call).
 constexpr int CAND_WORDS_MAX = 20;          // Dp <= 640 (the peak pick handles D <= 514)
 struct CandArgs {
     const void *A;           // exact analysis rows of the listed units, fp16 hi + lo planes: [rows][a_row_elems], row = 4 x list position + frame
