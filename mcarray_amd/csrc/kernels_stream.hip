@@ -808,16 +808,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                     }
                     if (d == 64) {                                        // (another wave than the units')
                         const int ci = a * p.n_chunks + (int)blockIdx.x, u_min = s_umin;
-                        if (atomicMin(&p.chunk_from[ci], u_min < 0 ? -1 : u_min / p.chunk) >= p.n_chunks) p.clist[atomicAdd(p.n_clist, 1)] = ci;
+                        if (atomicMin(&p.chunk_from[ci], u_min < 0 ? -1 : u_min / SCAN_CHUNK) >= p.n_chunks) p.clist[atomicAdd(p.n_clist, 1)] = ci;   // (p.chunk == SCAN_CHUNK)
                         atomicAdd(&p.stats[0], (unsigned long long)__popc(fm));
                         atomicAdd(&p.stats[2], (unsigned long long)s_ncol);
                         if (s_nall) atomicAdd(&p.stats[3], (unsigned long long)s_nall);
                     }
                     __syncthreads();
-                    if (d < PLAN_UNITS * p.umask_words) {
-                        const int j = d / p.umask_words, w = d - j * p.umask_words;
-                        const unsigned m = s_um[j][w];
-                        if (((needed >> j) & 1u) && m) atomicOr(&p.umask[(long long)s_ue[j] * p.umask_words + w], m);
+                    if (d < PLAN_UNITS * 32) {                            // (thread = (unit, word): 32 words per unit are more than any grid has)
+                        const int j = d >> 5, w = d & 31;
+                        static_assert(CAND_WORDS_MAX <= 32, "a word per thread");
+                        if (w < p.umask_words && ((needed >> j) & 1u)) {
+                            const unsigned m = s_um[j][w];
+                            if (m) atomicOr(&p.umask[s_ue[j] * p.umask_words + w], m);
+                        }
                     }
                 }
             }
