@@ -518,8 +518,7 @@ __device__ __forceinline__ bool wave_pick_pl(const float *En, int D, int S, floa
     }
     bool sens = false;
     float prev_bv = 0.f, v_last = 0.f;
-    const int n_pick = SENS ? S + 1 : S;                          // SENS: one more, the runner-up of the last pick
-    for (int s = 0; s < n_pick; ++s) {                             // :185-194
+    for (int s = 0; s < S; ++s) {                                  // :185-194
         float lv = sdv[0]; int li = 0;                            // this lane's first maximum
 #pragma unroll
         for (int i = 1; i < PL; ++i)
@@ -535,18 +534,22 @@ __device__ __forceinline__ bool wave_pick_pl(const float *En, int D, int S, floa
             if (bi == b + i) sdv[i] = 0.f;                         // _secondDerivative[maxIdx] = 0
         if (SENS && s > 0 && prev_bv > 0.f && prev_bv - bv <= tau) sens = true;
         prev_bv = bv;
-        if (s < S) {
-            v_last = bv;
-            if (lane == 0) { obin[s] = bi + 1; oval[s] = bv; }     // doaIdx2angle(maxIdx+1) and the outputs: by the caller
-        }
+        v_last = bv;
+        if (lane == 0) { obin[s] = bi + 1; oval[s] = bv; }         // doaIdx2angle(maxIdx+1) and the outputs: by the caller
     }
     if (SENS) {
-        umax = wave_max64(umax);
-        zmin = wave_min64(zmin);
-        if (v_last > 0.f ? umax >= v_last - tau : umax > -INFINITY) sens = true;
+        // The three wave-wide questions are "does ANY position reach a bound", so they are ballots of per-lane answers, not reductions
+        // (round 5: the runner-up's pick round and two DPP reductions per frame were 9 of this kernel's 48 us):
+        // the runner-up of the last pick within tau of it <=> a remaining second-derivative value >= that pick - tau,
+        float lv = sdv[0];
+#pragma unroll
+        for (int i = 1; i < PL; ++i) lv = fmaxf(lv, sdv[i]);
+        if (prev_bv > 0.f && __ballot(prev_bv - lv <= tau) != 0ull) sens = true;
+        // an uncertain position whose energy reaches the last pick,
+        if (__ballot(v_last > 0.f ? umax >= v_last - tau : umax > -INFINITY) != 0ull) sens = true;
         // the last pick is (within tau of) one of the zero entries: a candidate whose normalised energy is within tau of zero
         // could be a positive peak -- picked before every zero -- or a negative one
-        if (v_last <= tau && zmin <= tau) sens = true;
+        if (v_last <= tau && __ballot(zmin <= tau) != 0ull) sens = true;
     }
     return sens;
 }
