@@ -62,6 +62,7 @@ struct Knobs {
     int spw_skew = -1;                 // MCA_HIP_SPW_SKEW: StftPhatArgs::skew (-1: the shipped rule, 0: off)
     int spw_lds_pad = 0;               // MCA_HIP_SPW_LDS_PAD: KiB of unused LDS added to every k_stft_phat_wave launch (fewer workgroups per CU: occupancy A/B, tools/third_wave.sh)
     bool spw_xcd = false;              // MCA_HIP_SPW_XCD: StftPhatArgs::xcd_map
+    bool no_balance = false;           // MCA_HIP_NO_BALANCE: StftPhatArgs::no_balance (the cost / the effect of pair_balance.h)
     bool dyn_flat = false;             // MCA_HIP_DYN_FLAT: every run of the queue has the first runs' length
     const char *wave_clock = nullptr;  // MCA_HIP_WAVE_CLOCK=<file>: entry / exit clocks of every wave of the last k_stft_phat_wave launch, written at destruction
     int dyn_len0 = 0;                  // MCA_HIP_DYN_LEN0: length of the first (longest) runs of the queue (0: half a wave's share, at most 16)
@@ -301,6 +302,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.dyn_len0 = (int)geti(measure_env("MCA_HIP_DYN_LEN0"), 0);
     k.dyn_flat = measure_env("MCA_HIP_DYN_FLAT") != nullptr;
     k.spw_xcd = measure_env("MCA_HIP_SPW_XCD") != nullptr;
+    k.no_balance = measure_env("MCA_HIP_NO_BALANCE") != nullptr;
     k.spw_lds_pad = (int)geti(measure_env("MCA_HIP_SPW_LDS_PAD"), 0);
     k.lazy_ks_shape = measure_env("MCA_HIP_LAZY_KS_SHAPE") != nullptr;
     k.spw_skew = (int)geti(measure_env("MCA_HIP_SPW_SKEW"), -1);
@@ -772,6 +774,7 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
     if constexpr (sizeof(OutT) == 2) {
         if (wave16_applies(c) && a.a_planes == 1 && !a.list) {
             StftPhatArgs w = a;
+            w.no_balance = c->kn.no_balance ? 1 : 0;
             w.fpb = 16;
             while (w.fpb > 1 && (long long)grid.y * ((a.n_frames + w.fpb - 1) / w.fpb) < 2048) w.fpb >>= 1;
             dim3 gw(((a.n_frames + w.fpb - 1) / w.fpb + 3) / 4, grid.y);
@@ -796,6 +799,7 @@ int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, h
     // 4 or 8 microphones: one wave per run of frames on the 1024-point transform of channel pairs (k_stft_phat_wave)
     if ((M == 8 || M == 4) && (a.no_phat || !c->kn.stft_wg)) {
         StftPhatArgs w = a;
+        w.no_balance = c->kn.no_balance ? 1 : 0;
         dim3 gw;
         if (a.list) { w.fpb = 1; gw = dim3(grid.x, 1); }      // a listed group of REPAIR_GROUP = 4 frames per workgroup, a frame per wave
         else {

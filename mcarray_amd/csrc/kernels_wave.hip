@@ -17,6 +17,7 @@
 #include "mca_internal.h"
 #include "cand_unit.h"
 #include "phat_pairs.h"
+#include "pair_balance.h"
 
 namespace mca {
 
@@ -361,13 +362,15 @@ template __global__ void k_beamform_wave_ms<4, false>(BeamformWaveArgs); templat
 // zeros must give X = 0 like the reference's own transform; riding on its partner's transform it would come out as the
 // partner's rounding noise, which the whitening would blow up to unit modulus).
 // NOPHAT (gcc_weighting NONE): X itself, z / 2.
+// thr, unit (wave-uniform; pair_balance.h): a channel that went through the transform multiplied by s has thr = 4e-30 s^2 and
+// unit = 0.5 / s; a channel without a non-zero windowed sample thr = inf and unit = 0.
 template <bool NOPHAT = false>
-__device__ __forceinline__ float2 whiten4(float2 z, float &pw, bool alive = true)
+__device__ __forceinline__ float2 whiten4(float2 z, float &pw, float thr = 4e-30f, float unit = 0.5f)
 {
     v2f zv = to_v2f(z), sq, r;
     asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(zv));
     pw = sq.x + sq.y;
-    const float s = NOPHAT ? (alive ? 0.5f : 0.f) : ((pw > 4e-30f && alive) ? rsqrtf(pw) : 0.f);
+    const float s = NOPHAT ? unit : (pw > thr ? rsqrtf(pw) : 0.f);
     v2f sv = {s, s};
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(zv), "v"(sv));
     return from_v2f(r);
@@ -540,13 +543,6 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
                 float2 z[16];
-                // a channel of exact zeros? (any set bit below the sign)
-                unsigned oa = __float_as_uint(xa[0]), ob = __float_as_uint(xb[0]);
-#pragma unroll
-                for (int i = 1; i < 15; i += 2) { oa = or3(oa, __float_as_uint(xa[i]), __float_as_uint(xa[i + 1])); ob = or3(ob, __float_as_uint(xb[i]), __float_as_uint(xb[i + 1])); }
-                oa |= __float_as_uint(xa[15]); ob |= __float_as_uint(xb[15]);
-                const bool alive_a = __any((oa << 1) != 0), alive_b = __any((ob << 1) != 0);
-                any_alive = any_alive || alive_a || alive_b;
                 if (p.hist_out) {
                     // lazy tails: the call's last HIST_FRAMES frames of PCM stay behind for the next call's repair pass (frame j of the
                     // history = samples [512 j, 512 j + 1024) of a channel's HIST_SAMPLES)
@@ -567,6 +563,20 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const v2f zv = to_v2f(z[i]); asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(ptime) : "v"(zv)); }
                 }
+                // the lane's largest |windowed sample| of either channel: a channel of exact zeros?  two channels whose levels are far
+                // apart?  (pair_balance.h: the weaker one goes through the transform scaled up by a power of two)
+                float ma = max3abs(z[0].x, z[1].x, z[2].x), mb = max3abs(z[0].y, z[1].y, z[2].y);
+#pragma unroll
+                for (int i = 3; i < 15; i += 2) { ma = max3abs(ma, z[i].x, z[i + 1].x); mb = max3abs(mb, z[i].y, z[i + 1].y); }
+                ma = max2abs(ma, z[15].x); mb = max2abs(mb, z[15].y);
+                const PairBalance pb = pair_balance(ma, mb, !p.no_balance);
+                const bool alive_a = pb.alive_a, alive_b = pb.alive_b;
+                any_alive = any_alive || alive_a || alive_b;
+                if (pb.scaled()) {
+                    const float sa = pb.sa(), sb = pb.sb();
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) z[i] = make_float2(z[i].x * sa, z[i].y * sb);
+                }
                 // the next pair's samples (the run's last step reloads its own) are requested in the middle of the transform
                 fft1024c<false, 3>(z, buf, lane, tab, lc, [&]() {
                     const bool lastp = pr == NP - 1, last = lastp && fi + 1 >= nfr;
@@ -577,10 +587,11 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
                 // Two v_permlane32_swap per register pair (j, j + 4), j = 8..11, leave the partner's register j in slot j + 4 and
                 // the partner's j + 4 in slot j: the mirror of bin s is read from slot mate(15 - s).  Lanes 0 and 32 are their own
                 // mirrors -- lane 32: register 15 - s, lane 0: register (16 - s) & 15 -- and put those into the same slots.
-                if (MERGE) zn[pr] = make_float2(alive_a ? z[dr16(8)].x : 0.f, alive_b ? z[dr16(8)].y : 0.f);     // (lane 0's is the Nyquist bin)
+                const float un_a = pb.un_a(), un_b = pb.un_b();                                  // back to the channel's own scale (0: exact zeros)
+                if (MERGE) zn[pr] = make_float2(z[dr16(8)].x * un_a, z[dr16(8)].y * un_b);     // (lane 0's is the Nyquist bin)
                 if (lane == 0) {
                     const float2 n = z[dr16(8)];
-                    if (!MERGE) nyq[(f - f_begin) * NP + pr] = make_float2(alive_a ? n.x : 0.f, alive_b ? n.y : 0.f);
+                    if (!MERGE) nyq[(f - f_begin) * NP + pr] = make_float2(n.x * un_a, n.y * un_b);
                     float2 t[16];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) t[j] = z[dr16(j)];
@@ -597,14 +608,17 @@ __global__ __launch_bounds__(512) void k_stft_phat_wave(StftPhatArgs p)      // 
                         swap_rows32(u.y, w.y); swap_rows32(w.y, u.y);
                     }
                 }
+                // z = 2 s X (s: the channel's power of two): |X|^2 > 1e-30 <=> |z|^2 > 4e-30 s^2;  NOPHAT: X = z / (2 s)
+                const float thr_a = PairBalance::thr(4e-30f, pb.na, alive_a), thr_b = PairBalance::thr(4e-30f, pb.nb, alive_b);
+                const float half_a = PairBalance::down(0.5f, pb.na, alive_a), half_b = PairBalance::down(0.5f, pb.nb, alive_b);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const float2 zk = z[dr16(s)], zm = z[dr16(15 - s < 12 ? 15 - s + 4 : 15 - s - 4)];      // Z[k], Z[1024 - k] (slot mate(15 - s))
                     const float2 a2 = make_float2(zk.x + zm.x, zk.y - zm.y);                               // 2 X_a
                     const float2 b2 = make_float2(zk.y + zm.y, zm.x - zk.x);                               // 2 X_b
                     float pwa, pwb;
-                    Xh[2 * pr][s] = whiten4<NOPHAT>(a2, pwa, alive_a);
-                    Xh[2 * pr + 1][s] = whiten4<NOPHAT>(b2, pwb, alive_b);
+                    Xh[2 * pr][s] = whiten4<NOPHAT>(a2, pwa, thr_a, half_a);
+                    Xh[2 * pr + 1][s] = whiten4<NOPHAT>(b2, pwb, thr_b, half_b);
                 }
             }
             if (p.dead && lane == 0) p.dead[(long long)a * p.total_frames + p.frame0 + f] = any_alive ? 0 : 1;
@@ -817,11 +831,6 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             float2 z[16];
-            unsigned oa = __float_as_uint(xa[0]), ob = __float_as_uint(xb[0]);
-#pragma unroll
-            for (int i = 1; i < 15; i += 2) { oa = or3(oa, __float_as_uint(xa[i]), __float_as_uint(xa[i + 1])); ob = or3(ob, __float_as_uint(xb[i]), __float_as_uint(xb[i + 1])); }
-            oa |= __float_as_uint(xa[15]); ob |= __float_as_uint(xb[15]);
-            const bool alive_a = __any((oa << 1) != 0), alive_b = __any((ob << 1) != 0);
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 const float4 w4 = wq[i4];
@@ -837,6 +846,20 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
                 if (POWER) { ptime.x += pz.x; ptime.y += pz.y; }
                 if (p.unsure) { ref_a = 4.f * wave_sum64(pz.x); ref_b = 4.f * wave_sum64(pz.y); }
             }
+            // exact zeros?  levels far apart?  (as k_stft_phat_wave; pair_balance.h)
+            float ma = max3abs(z[0].x, z[1].x, z[2].x), mb = max3abs(z[0].y, z[1].y, z[2].y);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) { ma = max3abs(ma, z[i].x, z[i + 1].x); mb = max3abs(mb, z[i].y, z[i + 1].y); }
+            ma = max2abs(ma, z[15].x); mb = max2abs(mb, z[15].y);
+            const PairBalance pb = pair_balance(ma, mb, !p.no_balance);
+            const bool alive_a = pb.alive_a, alive_b = pb.alive_b;
+            float dc_a = ref_a, dc_b = ref_b;
+            if (pb.scaled()) {
+                const float sa = pb.sa(), sb = pb.sb();
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = make_float2(z[i].x * sa, z[i].y * sb);
+                dc_a *= sa * sa; dc_b *= sb * sb;                                     // (the DC bin below is the scaled channel's; the Nyquist bin is parked unscaled)
+            }
             fft1024c<false, 3>(z, buf, lane, tab, lc, [&]() {
                 const bool lastp = pr == NP - 1, last = lastp && fi + 1 >= nfr;
                 load_pair(last ? f : (lastp ? frame_of(fi + 1) : f), last ? pr : (lastp ? 0 : pr + 1));
@@ -844,7 +867,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
             // the mirror exchange and the separation of the two channels: as k_stft_phat_wave
             if (lane == 0) {
                 const float2 n = z[dr16(8)];
-                nyq[(f - f_begin) * NP + pr] = make_float2(alive_a ? n.x : 0.f, alive_b ? n.y : 0.f);
+                nyq[(f - f_begin) * NP + pr] = make_float2(n.x * pb.un_a(), n.y * pb.un_b());
                 float2 t[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) t[j] = z[dr16(j)];
@@ -862,20 +885,21 @@ __global__ __launch_bounds__(256, 2) void k_stft_phat_wave16(StftPhatArgs p)
                 }
             }
             float pw0a = 0.f, pw0b = 0.f;
+            const float thr_a = PairBalance::thr(4e-30f, pb.na, alive_a), thr_b = PairBalance::thr(4e-30f, pb.nb, alive_b);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const float2 zk = z[dr16(s)], zm = z[dr16(15 - s < 12 ? 15 - s + 4 : 15 - s - 4)];
                 const float2 a2 = make_float2(zk.x + zm.x, zk.y - zm.y);                               // 2 X_a
                 const float2 b2 = make_float2(zk.y + zm.y, zm.x - zk.x);                               // 2 X_b
                 float pwa, pwb;
-                const float2 wa = whiten4<false>(a2, pwa, alive_a), wb = whiten4<false>(b2, pwb, alive_b);
+                const float2 wa = whiten4<false>(a2, pwa, thr_a), wb = whiten4<false>(b2, pwb, thr_b);
                 const float2_t va = {wa.x, wa.y}, vb = {wb.x, wb.y};
                 Xh[2 * pr][s] = __builtin_convertvector(va, h2);
                 Xh[2 * pr + 1][s] = __builtin_convertvector(vb, h2);
                 if (s == 0) { pw0a = pwa; pw0b = pwb; }
                 if (s == 0 && p.unsure && lane == 0) {                             // lane 0 holds bin 0: against the channel's mean bin power
                     nref[(f - f_begin) * NP + pr] = make_float2(ref_a, ref_b);
-                    dc_unsure = dc_unsure || (pw0a < UNSURE * ref_a) || (pw0b < UNSURE * ref_b);
+                    dc_unsure = dc_unsure || (pw0a < UNSURE * dc_a) || (pw0b < UNSURE * dc_b);
                 }
             }
         }

@@ -90,6 +90,7 @@ struct StftPhatArgs {
     const unsigned short *mrank; int n_merged;   // k_stft_phat_wave, merged index (ULA, one fp16 plane): rank of the product m = k (j - i)
                              // among the n_merged distinct ones, [(M - 1) * 512 + 1]; NULL: per-group index g * 513 + k
     int no_phat;             // 1: gcc_weighting NONE -- the pair products of the spectra themselves (k_stft_phat_wave, fp32 rows only)
+    int no_balance;          // (measurement, make MEASURE=1 + MCA_HIP_NO_BALANCE) 1: the two channels of a pair transform are never level-balanced (pair_balance.h): round 5's analysis
     // k_stft_phat_wave, dynamic runs (round 5): queue != NULL -- the grid is one resident wave set and every wave takes runs of frames off
     // a device-side counter until none is left: queue[0] next run, queue[1] waves that have left (the last one zeroes both: the words
     // are clean for the next launch, recorded graphs included).  The runs get shorter towards the end (dyn_run below: 8, 4, 2, 1 frames
