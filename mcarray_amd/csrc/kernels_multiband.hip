@@ -9,6 +9,7 @@
 //   k_mb_summary   the power gate (:125-143, :214-225) and _currentDOA / _prob (:237-255), in frame order
 #include "fft_block.h"
 #include "mca_internal.h"
+#include "pair_balance.h"
 
 namespace mca {
 
@@ -191,7 +192,9 @@ __global__ __launch_bounds__(512) void k_mb_analyse_512(MbAnalyseArgs p, int fpb
         if (wave < nb) {
             float2 v[8];
             load_pair_512(v, base, p.ch_stride, 0, 2, (long long)(f + wave) * N512_H, wreg, lane);
+            const PairBalance pb = pair_balance_512(v);        // (the PHAT cross-spectrum below keeps the phase only: pair_balance.h)
             rfft512_pair(v, scr + wave * FFT_SCRATCH, spec + (2 * wave) * N512_ROW, spec + (2 * wave + 1) * N512_ROW, lane, tw);
+            pair_restore_512(pb, spec + (2 * wave) * N512_ROW, spec + (2 * wave + 1) * N512_ROW, lane);
         }
         __syncthreads();
         // per-bin power and PHAT cross-spectrum: wave j -> frame j

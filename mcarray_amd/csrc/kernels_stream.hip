@@ -11,6 +11,7 @@
 #include "fft512.h"
 #include "mca_internal.h"
 #include "phat_pairs.h"
+#include "pair_balance.h"
 
 namespace mca {
 
@@ -1355,7 +1356,9 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
         if (slot < nfr && c0 < M) {
             float2 v[8];
             load_pair_512(v, base, p.mic_stride, c0, M, (long long)(p.frame0 + f + slot) * N512_H, wreg, lane);
+            const PairBalance pb = pair_balance_512(v);        // (PHAT keeps the phase only: a channel far below its transform partner, pair_balance.h)
             rfft512_pair(v, scr + wave * FFT_SCRATCH, spec + (slot * 8 + c0) * N512_ROW, spec + (slot * 8 + c0 + 1) * N512_ROW, lane, tw);
+            pair_restore_512(pb, spec + (slot * 8 + c0) * N512_ROW, spec + (slot * 8 + c0 + 1) * N512_ROW, lane);
         }
         __syncthreads();
         const int fi = tid >> 8, k = tid & 255;

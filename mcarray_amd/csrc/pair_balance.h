@@ -92,4 +92,42 @@ __device__ __forceinline__ PairBalance pair_balance(float ma, float mb, bool ena
     return r;
 }
 
+// ---- 512-sample frames: two channels per 512-point complex transform (fft512.h: load_pair_512 / rfft512_pair) -----------------
+// v[r] = (a[m], b[m]) w[m] / 2: balanced in place before the transform ...
+__device__ __forceinline__ PairBalance pair_balance_512(float2 (&v)[8])
+{
+    float ma = max3abs(v[0].x, v[1].x, v[2].x), mb = max3abs(v[0].y, v[1].y, v[2].y);
+    ma = max3abs(ma, v[3].x, v[4].x); mb = max3abs(mb, v[3].y, v[4].y);
+    ma = max3abs(ma, v[5].x, v[6].x); mb = max3abs(mb, v[5].y, v[6].y);
+    ma = max2abs(ma, v[7].x); mb = max2abs(mb, v[7].y);
+    const PairBalance pb = pair_balance(ma, mb);
+    if (pb.scaled()) {
+        const float sa = pb.sa(), sb = pb.sb();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_float2(v[r].x * sa, v[r].y * sb);
+    }
+    return pb;
+}
+// ... and the two spectra rfft512_pair left in LDS (k = 0..256; a lane touches the words it wrote) back at the channels' own scales;
+// a channel of exact zeros gets zeros, not its partner's rounding noise
+__device__ __forceinline__ void pair_restore_512(const PairBalance &pb, float2 *specA, float2 *specB, int lane)
+{
+    if (pb.scaled() || !pb.alive_a || !pb.alive_b) {
+        const float ua = pb.un_a(), ub = pb.un_b();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            const float2 xa = specA[k], xb = specB[k];
+            specA[k] = make_float2(xa.x * ua, xa.y * ua);
+            specB[k] = make_float2(xb.x * ub, xb.y * ub);
+        }
+        if (lane == 0) {
+            const float2 xa = specA[256], xb = specB[256];
+            specA[256] = make_float2(xa.x * ua, xa.y * ua);
+            specB[256] = make_float2(xb.x * ub, xb.y * ub);
+        }
+        wave_lds_fence();
+    }
+}
+
 }  // namespace mca

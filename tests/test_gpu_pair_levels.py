@@ -141,3 +141,36 @@ def test_a_channel_with_one_sample_under_the_windows_zero_is_a_channel_of_zeros(
         r = ctx.process_frames_host(pcm, want_energy=True)
         check_against_oracle(r, pcm, fs, N, xs, 1, 0.5, prec, ctx.P)
         ctx.close()
+
+
+@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3])
+def test_uneven_levels_at_512_sample_frames(prec):
+    """16 kHz / 512-sample frames (k_stft_phat_512: two channels per 512-point complex transform, fft512.h rfft512_pair): the same
+    balance -- and a muted channel gives X = 0 there too, not its partner's rounding noise whitened to unit modulus"""
+    fs, N, F, cut = 16000, 512, 150, 71
+    xs = synth.ULA8
+    pcm = uneven_streams(xs, fs, (F + 1) * 256, 7600, mute=(21 * 256 + 77, 58 * 256 + 201))
+    ctx = api.Context(fs, xs, N, 1.0, 1, srp_precision=prec, max_arrays=4)
+    ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * 256], want_energy=True)
+    rb = ctx.process_frames_host(pcm[:, :, cut * 256:], want_energy=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out")}
+    check_against_oracle(r, pcm, fs, N, xs, 1, 1.0, prec, ctx.P)
+    ctx.close()
+
+
+def test_multiband_localiser_with_one_ear_far_below_the_other():
+    """MultibandBinarualLocalisation at 16 kHz (k_mb_analyse_512: the two channels of a frame are ONE 512-point transform;
+    MultibandBinarualLocalisation.cpp:164-196 whitens the cross-spectrum): right channel 80 dB down, left channel muted for a while"""
+    from test_gpu_multiband import _compare
+    fs, N, nbins, F, A = 16000, 512, 15, 70, 2
+    xs = synth.BINAURAL
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-40.0 + 70.0 * a), fs, (F + 1) * N // 2, 60 + a) for a in range(A)]).astype(np.float32)
+    pcm[0, 1] *= np.float32(1e-4)
+    pcm[1, 0, 20 * 256 + 31:41 * 256 + 200] = 0.0
+    loc = api.MultibandBinarualLocalisation(fs, xs, nbins, False, max_arrays=A)
+    r = loc.process(pcm, want_bands=True)
+    flagged = 0
+    for a in range(A):
+        flagged += _compare(loc, po.Multiband(fs, xs, N + 2, nbins, False), pcm[a], N, r, a)
+    assert flagged <= 0.4 * A * F, flagged                     # (a muted ear: flat band correlations, ties by construction)
+    loc.close()
