@@ -123,11 +123,14 @@ typedef struct {
                                   field is accepted and means PHAT.) */
     /* Appended in round 4 (a struct_size that ends before them is accepted; zero = the default of each): */
     int adaptive_fallback;     /* mca_hip_adaptive_fallback.  MCA_HIP_SRP_ADAPTIVE only.  0 = AUTO: the context backs off to
-                                  FP16X3 by itself while most rows need the repair (noise only, silence) and probes again later;
-                                  WHICH call switches depends on when the GPU's report reaches the host, so two runs of the
-                                  same input may differ in the last bits of the energies around a switch.  1 = OFF: the mode is
-                                  pinned -- every eligible call runs coarse + repair, and two runs of the same calls return
-                                  the same bits in every output. */
+                                  FP16X3 by itself while most rows need the repair (noise only, silence) and probes again later.
+                                  Round 6: a call's report is consumed by the eligible call TWO calls after it, which waits for it
+                                  if it has not arrived (the call in between is still queued behind it: the device does not idle),
+                                  so which call switches depends on the sequence of calls and their content only -- two runs of the
+                                  same calls return the same bits in every output under AUTO as well (tests/test_gpu_adaptive.py).
+                                  A report that stays away for 4 s (a stream held up by something only the calling thread would
+                                  release) ends the policy until mca_hip_reset.  HIP-graph recordings never switch.
+                                  1 = OFF: the mode is pinned -- every eligible call runs coarse + repair. */
     int adaptive_min_rows;     /* ADAPTIVE: calls of fewer rows (arrays x frames) run as FP16X3; 0 = 4096 */
     int adaptive_max_sources;  /* ADAPTIVE: contexts with more sources run as FP16X3; 0 = 1 */
     int scan_carry;            /* 1: the chunk start values of the energy recursion always come from the serial carry pass

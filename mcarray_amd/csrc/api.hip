@@ -9,11 +9,13 @@
 #include "knobs.h"
 #include "stage.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mca;
@@ -36,6 +38,11 @@ struct mca_hip_graph;
 // tools that reach a context only through a wrapper.  The A/B switches that exist so that a measured claim of DESIGN.md can be
 // repeated -- one of them (MCA_HIP_BFW_ABL) returns deliberately wrong audio -- are compiled in only with -DMCA_MEASURE
 // (make MEASURE=1, tools/*.py say when they need it); in the default build they are the constants below.
+// The back-off policy reads the report of an adaptive call at a FIXED lag: the eligible call FB_LAG calls after the one that enqueued
+// it (and blocks on the page-locked word if it has not arrived: at a lag of two the work of the call in between is still queued
+// behind it, so the device does not idle).  What a call does therefore depends on the sequence of calls and their content only, not
+// on when a report happens to land: two runs of one stream return the same bits.
+constexpr int FB_LAG = 2, FB_RING = 64, FB_WAIT_MS = 4000;
 struct Knobs {
     // product
     bool fb_enabled = true;            // MCA_HIP_ADAPT_FALLBACK=0 / cfg.adaptive_fallback = OFF
@@ -173,9 +180,12 @@ struct mca_hip_ctx {
     int fb_left = 0, fb_backoff = 8, fb_state = 0;      // (adapt_policy_begin)
     bool cand_heavy = false;                            // the last report had more than a fifth of the rows recomputed: whole-row repair kernels (adapt_policy_begin)
     unsigned long long fb_probe_seq = 0;
-    unsigned long long *h_probe = nullptr;              // [3] flagged frames, listed repair units, sequence number of the call
+    unsigned long long *h_probe = nullptr;              // [FB_RING][4] one slot per adaptive call (seq - 1) % FB_RING: flagged frames, listed repair units, sequence number of the call
     unsigned long long fb_calls = 0, fb_seq_seen = 0, fb_groups_prev = 0, fb_frames_prev = 0, fb_flagged_prev = 0;
-    unsigned long long fb_frames_ring[64] = {};         // adapt_frames_total after adaptive call number i + 1
+    unsigned long long fb_frames_ring[FB_RING] = {};    // adapt_frames_total after adaptive call number i + 1
+    unsigned long long fb_m = 0;                        // eligible stream calls seen by adapt_policy_begin
+    unsigned long long fb_launch_m[FB_RING] = {};       // ... and the one during which adaptive call number i + 1 was enqueued
+    bool fb_lost = false;                               // a report did not arrive within FB_WAIT_MS: the policy stops consuming reports (until mca_hip_reset)
     int a_row_elems = 0, a_planes = 1, a_elem = 4;
     // frame API (double)
     double *d_fr = nullptr; size_t fr_elems = 0;
@@ -607,23 +617,34 @@ static bool cand_call(const mca_hip_ctx *c, bool lazy)
     return c->kn.fb_enabled && c->h_probe && c->fb_state == 0 && !c->cand_heavy;
 }
 
-// Called once at the top of an eager stream call (not per piece of a call, not while a graph is recorded): reads what the
-// adaptive calls that have finished by now reported and decides whether this call runs coarse + repair or plain FP16X3.
+// Called once at the top of an eager stream call (not per piece of a call, not while a graph is recorded): consumes the reports of
+// the adaptive calls that were enqueued FB_LAG eligible calls ago (or earlier) and decides whether this call runs coarse + repair or
+// plain FP16X3.
 //   NORMAL     adaptive; a report of more than 30 % of the rows recomputed (or of the frames flagged) since the last one suspends the mode for fb_backoff
 //              eligible calls (8, doubling up to 256 while the probes keep reporting that)
 //   SUSPENDED  plain FP16X3, counting down; then ONE adaptive call probes
-//   WAITING    plain FP16X3 until the probe's report is in (a caller that queues many calls ahead gets it late): heavy again ->
-//              SUSPENDED, else NORMAL
-// Which call a report reaches depends on timing, so the switch can move by a call from run to run; both modes return the exact
-// path's bins (MCA_HIP_ADAPT_FALLBACK=0 pins the mode).
+//   WAITING    plain FP16X3 until the probe's report is consumed (FB_LAG calls after the probe): heavy again -> SUSPENDED, else NORMAL
+// Round 6: every adaptive call has its own report slot and a report is consumed by the call FB_LAG calls after its
+// own, which WAITS for it if need be -- before, a call took "whatever has arrived by now" and the switch (and with it the choice between
+// candidate columns and whole rows, cand_call) could move by a call from run to run.  A report that does not arrive within FB_WAIT_MS (a
+// stream held up by something only this thread would release) ends the policy for the stream: the mode stays what it is.
 void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
 {
     if (!c->kn.fb_enabled || c->capturing || !c->h_probe || !adaptive_shape(c, n_arrays, n_frames)) return;
     bool fresh = false, heavy = false;
-    const unsigned long long seq = __atomic_load_n(&c->h_probe[2], __ATOMIC_ACQUIRE);
-    if (seq > c->fb_seq_seen && seq <= c->fb_calls && c->fb_calls - seq < 64) {
-        const unsigned long long groups = __atomic_load_n(&c->h_probe[1], __ATOMIC_RELAXED), frames = c->fb_frames_ring[(seq - 1) % 64];
-        const unsigned long long flagged = __atomic_load_n(&c->h_probe[0], __ATOMIC_RELAXED);
+    const unsigned long long m = c->fb_m++;
+    unsigned long long seq = c->fb_seq_seen;                                   // the last report due at this call
+    while (seq < c->fb_calls && c->fb_launch_m[seq % FB_RING] + FB_LAG <= m) ++seq;      // (call number seq + 1 lives at index seq % FB_RING)
+    if (seq > c->fb_seq_seen && !c->fb_lost && c->fb_calls - seq < FB_RING - 8) {
+        const unsigned long long *slot = c->h_probe + 4 * ((seq - 1) % FB_RING);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(&slot[2], __ATOMIC_ACQUIRE) != seq) {
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > FB_WAIT_MS) { c->fb_lost = true; break; }
+            std::this_thread::yield();
+        }
+        if (!c->fb_lost) {
+        const unsigned long long groups = __atomic_load_n(&slot[1], __ATOMIC_RELAXED), frames = c->fb_frames_ring[(seq - 1) % FB_RING];
+        const unsigned long long flagged = __atomic_load_n(&slot[0], __ATOMIC_RELAXED);
         const bool fwd = groups >= c->fb_groups_prev && frames > c->fb_frames_prev && flagged >= c->fb_flagged_prev;      // (the totals restart with mca_hip_reset_timing)
         const unsigned long long dg = fwd ? groups - c->fb_groups_prev : 0, df = fwd ? frames - c->fb_frames_prev : 0, dfl = fwd ? flagged - c->fb_flagged_prev : 0;
         c->fb_seq_seen = seq; c->fb_groups_prev = groups; c->fb_frames_prev = frames; c->fb_flagged_prev = flagged;
@@ -632,6 +653,9 @@ void adapt_policy_begin(mca_hip_ctx *c, int n_arrays, int n_frames)
         heavy = fresh && (dg * REPAIR_GROUP * 100 > df * 30 || dfl * 100 > df * 30);
         // candidate columns pay while the list is short (one workgroup per unit); a call that recomputes most rows is a dense contraction again
         if (fresh) c->cand_heavy = dg * REPAIR_GROUP * 100 > df * 20;
+        }
+    } else if (seq > c->fb_seq_seen) {
+        c->fb_seq_seen = seq;                                                  // (more calls in flight than slots, or the policy has ended: dropped)
     }
     auto suspend = [&]() {
         c->fb_state = 1; c->adapt_suspended = true;
@@ -1107,7 +1131,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
                 (rc = zalloc((void **)&c->d_ehist[i], na * c->D * 4))) { g_create_error = c->err; free_ctx(c); return rc; }
     }
     if (c->prec == MCA_HIP_SRP_ADAPTIVE && c->kn.fb_enabled) {
-        if (hipHostMalloc((void **)&c->h_probe, 32, hipHostMallocDefault) == hipSuccess) std::memset(c->h_probe, 0, 32);
+        if (hipHostMalloc((void **)&c->h_probe, FB_RING * 32, hipHostMallocDefault) == hipSuccess) std::memset(c->h_probe, 0, FB_RING * 32);
         else { c->h_probe = nullptr; (void)hipGetLastError(); }                    // (no page-locked memory: the mode never backs off)
     }
     if (c->stream_ok && ((rc = build_steering_table(c)) || (rc = build_merged_tables(c)))) { g_create_error = c->err; free_ctx(c); return rc; }
@@ -1163,6 +1187,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     }
     HIP_TRY(c, hipMemsetAsync(c->d_silence, 0, na * 4, st));
     c->adapt_suspended = false; c->fb_state = 0; c->fb_left = 0; c->fb_backoff = 8; c->cand_heavy = false;     // new streams: the adaptive mode starts afresh
+    c->fb_lost = false; c->fb_seq_seen = c->fb_calls;                                                          // (reports still in flight belong to the old streams)
     c->hist_pending = false;                                                              // ... and no call owes the next one its last rows
     // the self-cleaning words of the adaptive path (a call that failed half way may have left some set)
     for (Workspace &w : c->lanes) {
@@ -1546,8 +1571,9 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         if (cand_call(c, lazy)) { pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32; pa.dead = c->ws().d_unsure; }   // (dead: the unsure bytes, unused by these contexts)
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
-            c->fb_frames_ring[c->fb_calls % 64] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
-            pa.probe = c->h_probe; pa.probe_seq = ++c->fb_calls;
+            c->fb_frames_ring[c->fb_calls % FB_RING] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
+            c->fb_launch_m[c->fb_calls % FB_RING] = c->fb_m > 0 ? c->fb_m - 1 : 0;       // (the eligible call this piece belongs to)
+            pa.probe = c->h_probe + 4 * (c->fb_calls % FB_RING); pa.probe_seq = ++c->fb_calls;
         }
     }
     const int nthr = round_up(c->D, 64);

@@ -58,13 +58,14 @@ def test_adaptive_matches_oracle(force_small, xs, step, S, thetas):
 
 def test_adaptive_backs_off_to_fp16x3_while_most_rows_need_the_repair(force_small, monkeypatch):
     """Noise only: every pick is a near tie, every frame is flagged, and coarse + repair of everything costs twice the direct
-    exact pass.  The last kernel of an adaptive call reports its totals through page-locked memory; the calls after it run as
-    plain FP16X3 (no adaptive frames counted) for 8 calls, then one call probes again.  The bins stay the exact path's."""
+    exact pass.  The last kernel of an adaptive call reports its totals through page-locked memory; the call TWO calls later consumes
+    the report (a fixed lag: round 6), the calls from there on run as plain FP16X3 (no adaptive frames counted) for 8 calls, then one
+    call probes again.  The bins stay the exact path's."""
     monkeypatch.setenv("MCA_HIP_ADAPT_FALLBACK", "1")
     fs, N, F, A = 48000, 1024, 256, 1
     xs = synth.ULA8
     rng = np.random.default_rng(5)
-    n_calls = 11
+    n_calls = 13
     pcm = (0.1 * rng.standard_normal((A, len(xs), (n_calls * F + 1) * 512))).astype(np.float32)
     ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
     ref = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16X3, max_arrays=A)
@@ -72,12 +73,13 @@ def test_adaptive_backs_off_to_fp16x3_while_most_rows_need_the_repair(force_smal
     counted, bins, rbins = [], [], []
     for i in range(n_calls):
         chunk = pcm[:, :, i * F * 512:((i + 1) * F + 1) * 512]
-        bins.append(ctx.process_frames_host(chunk)["bin"])      # (synchronous: the report of call i is there before call i + 1)
+        bins.append(ctx.process_frames_host(chunk)["bin"])
         rbins.append(ref.process_frames_host(chunk)["bin"])
         counted.append(ctx.repair_stats()["frames"])
-    # call 0 adaptive, calls 1..8 suspended, call 9 probes (adaptive again), call 10 suspended (for 16 calls)
-    assert counted[0] == A * F and counted[8] == counted[0], counted
-    assert counted[9] == 2 * A * F and counted[10] == counted[9], counted
+    # calls 0 and 1 adaptive (call 0's report is consumed by call 2), calls 2..9 suspended, call 10 probes (adaptive again), call 11 waits
+    # for the probe's report, call 12 consumes it: suspended (for 16 calls)
+    assert counted[0] == A * F and counted[1] == 2 * A * F and counted[9] == counted[1], counted
+    assert counted[10] == 3 * A * F and counted[12] == counted[10], counted
     st = ctx.repair_stats()
     assert st["recomputed"] > 0.3 * st["frames"], st
     got, want = np.concatenate(bins, axis=1), np.concatenate(rbins, axis=1)
@@ -87,6 +89,60 @@ def test_adaptive_backs_off_to_fp16x3_while_most_rows_need_the_repair(force_smal
     o = po.ssl_stream(fs, N, xs, pcm[0].astype(np.float64), 1, 0.5, want_map=True)
     _assert_bins(got[0], o["bin"], o["energy"], ctx.P, max_ties=int(0.02 * n_calls * F))
     ctx.close(); ref.close()
+
+
+def test_the_back_off_policy_is_reproducible_run_to_run(force_small, monkeypatch):
+    """north_star: "bit-exact for DOA peak indices"; SteeringBeamforming.cpp:146-195 is deterministic.  Under adaptive_fallback = AUTO the
+    switch to FP16X3 (and the choice between candidate columns and whole-row repair kernels) hangs on reports the GPU sends to the
+    host.  Round 6: every report is consumed by the call two calls after its own, which waits for it -- so one stream of six
+    device-pointer calls (source, source, NOISE ONLY, source, source, source: calls 0..3 adaptive, call 4 consumes the report of call 2
+    and runs FP16X3 with call 5) returns the same bits whether the calls are fired back to back without a single synchronisation or
+    one at a time with the device drained and the host asleep in between (before: the second form saw every report a call earlier)."""
+    import time
+    monkeypatch.setenv("MCA_HIP_ADAPT_FALLBACK", "1")
+    monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "128")
+    fs, N, hop, A, F, n_calls = 48000, 1024, 512, 2, 128, 6
+    xs = synth.ULA8
+    total = F * n_calls
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-33.0 + 70 * a), fs, (total + 1) * hop, 8100 + a, snr_db=10.0).astype(np.float32) for a in range(A)])
+    rng = np.random.default_rng(81)
+    pcm[:, :, 2 * F * hop + hop:3 * F * hop] = (0.1 * rng.standard_normal((A, len(xs), F * hop - hop))).astype(np.float32)    # call 2: independent noise on every channel
+    dev = torch.device("cuda:0")
+    x_all = torch.from_numpy(pcm).to(dev)
+
+    def run(drain):
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)      # adaptive_fallback AUTO (the default)
+        ctx.reset_timing()
+        outs = []
+        for i in range(n_calls):
+            x = x_all[:, :, i * F * hop:((i + 1) * F + 1) * hop].contiguous()
+            b = torch.empty(A, F, 1, dtype=torch.int32, device=dev)
+            r = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+            q = torch.empty(A, F, 1, dtype=torch.float32, device=dev)
+            e = torch.empty(A, F, ctx.D, dtype=torch.float32, device=dev)
+            o = torch.empty(A, 1, F * hop, dtype=torch.float32, device=dev)
+            ctx.process_frames_dev(x, F, b, r, q, e, o)
+            outs.append((x, b, r, q, e, o))
+            if drain:
+                torch.cuda.synchronize()
+                time.sleep(0.05)
+        torch.cuda.synchronize()
+        frames = ctx.repair_stats()["frames"]
+        res = [np.concatenate([t[j].cpu().numpy() for t in outs], axis=-1 if j == 5 else 1) for j in range(1, 6)]
+        ctx.close()
+        return frames, res
+    fa, ra = run(False)
+    fb, rb = run(True)
+    assert fa == fb == 4 * A * F, (fa, fb)                  # calls 0..3 adaptive, 4 and 5 FP16X3 -- in both runs
+    for name, u, v in zip(("bin", "doa", "prob", "energy", "audio"), ra, rb):
+        assert np.array_equal(u, v), name
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, 0.5, want_map=True)
+        _assert_bins(ra[0][a], o["bin"], o["energy"], ctx_P(xs), max_ties=int(0.03 * total))
+
+
+def ctx_P(xs):
+    return len(xs) * (len(xs) - 1) // 2
 
 
 def test_adaptive_context_runs_small_and_gated_calls_as_fp16x3():
@@ -453,6 +509,7 @@ def test_candidate_columns_and_frames_of_exact_zeros(force_small, monkeypatch):
         ctx.reset_timing()
         b, audio = _dev_calls(ctx, pcm, F, n_calls, hop)
         res[cand] = (b, audio, ctx.repair_stats(), ctx.repair_columns())
+        assert ctx.D == 361
         ctx.close()
         for a in range(A):
             ties, bad = classify_bins(b[a], o[a]["bin"][:, 0], o[a]["energy"], 28)
@@ -460,7 +517,6 @@ def test_candidate_columns_and_frames_of_exact_zeros(force_small, monkeypatch):
             assert_audio_where_bins_agree(audio[a][None], o[a]["out"], b[a], o[a]["bin"][:, 0], hop)
     st, cols = res["1"][2], res["1"][3]
     assert st["flagged"] > 30, st
-    assert ctx.D == 361
     assert cols["whole_row_frames"] <= 2 * A * 80, cols          # (only frames of the silent stretch -- flat maps -- can lack a lower bound; their rows are zero: not listed)
     narrow = st["flagged"] - cols["whole_row_frames"]
     assert narrow > 0 and 0 < cols["candidate_columns"] - 361 * cols["whole_row_frames"] <= 40 * narrow, (st, cols)
