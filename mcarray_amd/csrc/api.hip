@@ -1467,6 +1467,30 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
     return MCA_HIP_OK;
 }
 
+// _energyMemoryFactor and its float complement (SteeringBeamforming.h:70, .cpp:134,139: float arithmetic) -- one place for every launch
+constexpr float ENERGY_MU = 0.8f, ENERGY_ONE_MINUS_MU = 1 - 0.8f;
+
+// One pass of the whole-row repair behind the list-mode analysis: the exact rows of the listed units [list0, list0 + pass_rows /
+// REPAIR_GROUP) in w.d_Ax -> three-product contraction in K segments (w.d_Cx) -> summed into the map by k_repair_patch (pp: where the
+// rows go; list0, pass_rows, col_tiles, ksplit and items are filled in here).  Shared by localise_impl and settle_history.
+static void launch_repair_contraction(mca_hip_ctx *c, Workspace &w, long long list0, long long pass_rows, int ksplit_arrays, RepairPatchArgs pp, hipStream_t st)
+{
+    GemmArgs ga{};
+    ga.A = w.d_Ax; ga.B = c->d_B; ga.C = w.d_Cx; ga.Bt = c->d_Bt;
+    ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
+    ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
+    ga.n_list = w.d_nlist; ga.list0 = (int)list0;
+    ga.repair_ksplit = repair_ksplit_for(c, ksplit_arrays); ga.repair_items = c->kn.repair_items;
+    const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
+    const long long max_work = (pass_rows + 127) / 128 * col_tiles * ga.repair_ksplit;
+    dim3 gg((unsigned)std::min<long long>(max_work, 768));
+    if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
+    pp.Cx = w.d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit; pp.items = ga.repair_items;
+    pp.list = w.d_list; pp.n_list = w.d_nlist; pp.list0 = (int)list0; pp.need = w.d_need; pp.Dp = c->Dp;
+    hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);
+}
+
 // Lazy tails (mca_internal.h, HIST_FRAMES): the repair of a call's last rows is left to the call that needs them.  Settling the debt --
 // for every consumer of the state that is not the next lazy call itself (an FP16X3 call of the same context, another array count,
 // state_save, a recorded graph): the previous call's last HIST_FRAMES rows of EVERY array are recomputed exactly from the kept PCM (the
@@ -1474,46 +1498,46 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
 static int settle_history(mca_hip_ctx *c, hipStream_t st)
 {
     if (!c->hist_pending) return MCA_HIP_OK;
-    c->hist_pending = false;
     const int n = c->hist_n, units = n * HIST_UNITS, rows = units * REPAIR_GROUP, cur = c->hist_cur;
     Workspace &w = c->lanes[0];
     if (!w.d_list || !w.d_need || !w.d_nlist || !w.d_Ax || !w.d_Cx) return fail(c, MCA_HIP_ERR_HIP, "lazy tails: the adaptive workspace is gone");
+    // The workspace was sized by the lazy call that left the debt (ensure_adapt_workspace: repair_pass_rows of its shape, capped by the
+    // budget, MCA_HIP_WS_MAX_MB); the history's rows go through it in passes of at most that many rows, as localise_impl's do (ADVICE r5:
+    // one pass of all of them wrote past d_Ax / d_Cx when the budget was small and the arrays many).
+    const int ksplit = repair_ksplit_for(c, n);
+    long long pass_rows = std::min<long long>((rows + 127) / 128 * 128, repair_pass_rows(c, n, HIST_FRAMES));
+    const long long fit_a = (long long)(w.ax_bytes / ((size_t)2 * c->Kp * 2)) / 128 * 128, fit_c = (long long)(w.cx_bytes / ((size_t)ksplit * c->Dp * 4)) / 128 * 128;
+    pass_rows = std::min(pass_rows, std::min(fit_a, fit_c));
+    if (pass_rows < 128) return fail(c, MCA_HIP_ERR_HIP, "lazy tails: the adaptive workspace is smaller than one repair pass");
+    const int pass_groups = (int)(pass_rows / REPAIR_GROUP);
     const int planes_before = c->a_planes;
     set_call_planes(c, 2);
     hipLaunchKernelGGL(k_hist_list, dim3((units + 255) / 256), dim3(256), 0, st, w.d_list, w.d_nlist, w.d_need, units);
-    StftPhatArgs sa{};
-    sa.pcm = c->d_hist_pcm[cur]; sa.array_stride = (long long)c->M * HIST_SAMPLES; sa.mic_stride = HIST_SAMPLES;
-    sa.M = c->M; sa.n_frames = HIST_FRAMES; sa.frame0 = 0; sa.fpb = REPAIR_GROUP; sa.total_frames = HIST_FRAMES;
-    sa.window = c->d_window; sa.A = w.d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
-    sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
-    sa.list = w.d_list; sa.n_list = w.d_nlist; sa.list0 = 0; sa.list_cap = units; sa.groups_per_array = HIST_UNITS;
-    sa.hist_in = c->d_hist_pcm[cur]; sa.hist_base = 0;
-    const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
-    int rc = launch_stft<_Float16>(c, sa, dim3(std::min(units, 512), 1), smem1, st);
-    if (!rc) {
-        const int cap = (rows + 127) / 128 * 128;
-        GemmArgs ga{};
-        ga.A = w.d_Ax; ga.B = c->d_B; ga.C = w.d_Cx; ga.Bt = c->d_Bt;
-        ga.rows = cap; ga.chunk_frames = cap; ga.total_frames = cap; ga.frame0 = 0;
-        ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = (long long)cap * c->Dp;
-        ga.n_list = w.d_nlist; ga.list0 = 0;
-        ga.repair_ksplit = repair_ksplit_for(c, n); ga.repair_items = c->kn.repair_items;
-        const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
-        const long long max_work = (long long)(cap / 128) * col_tiles * ga.repair_ksplit;
-        dim3 gg((unsigned)std::min<long long>(max_work, 768));
-        if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
-        else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
+    int rc = MCA_HIP_OK;
+    for (long long g0 = 0; g0 < units && !rc; g0 += pass_groups) {
+        StftPhatArgs sa{};
+        sa.pcm = c->d_hist_pcm[cur]; sa.array_stride = (long long)c->M * HIST_SAMPLES; sa.mic_stride = HIST_SAMPLES;
+        sa.M = c->M; sa.n_frames = HIST_FRAMES; sa.frame0 = 0; sa.fpb = REPAIR_GROUP; sa.total_frames = HIST_FRAMES;
+        sa.window = c->d_window; sa.A = w.d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
+        sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
+        sa.list = w.d_list; sa.n_list = w.d_nlist; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = HIST_UNITS;
+        sa.hist_in = c->d_hist_pcm[cur]; sa.hist_base = 0;
+        const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
+        rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, 512), 1), smem1, st);
+        if (rc) break;
         RepairPatchArgs pp{};
-        pp.Cx = w.d_Cx; pp.pass_rows = cap; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit; pp.items = ga.repair_items;
-        pp.list = w.d_list; pp.n_list = w.d_nlist; pp.list0 = 0; pp.groups_per_array = HIST_UNITS; pp.need = w.d_need;
-        pp.C = w.d_C; pp.c_planes = 1; pp.c_plane_stride = 0; pp.n_frames = HIST_FRAMES; pp.Dp = c->Dp;
+        pp.groups_per_array = HIST_UNITS;
+        pp.C = w.d_C; pp.c_planes = 1; pp.c_plane_stride = 0; pp.n_frames = HIST_FRAMES;
         pp.hist_C = c->d_hist_C[cur]; pp.hist_base = 0;
-        hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min(rows, 2048)), dim3(128), 0, st, pp);
+        launch_repair_contraction(c, w, g0, pass_rows, n, pp, st);
+    }
+    if (!rc) {
         hipLaunchKernelGGL(k_hist_settle, dim3(n), dim3(std::max(round_up(c->D, 64), 64)), 0, st, c->d_ehist[cur], c->d_hist_C[cur], c->d_E[c->e_cur], w.d_nlist, c->D, c->Dp,
-                           0.8f, 1 - 0.8f);
+                           ENERGY_MU, ENERGY_ONE_MINUS_MU);
         if (hipGetLastError() != hipSuccess) rc = fail(c, MCA_HIP_ERR_HIP, "lazy tails: a launch of the settling pass failed");
     }
     set_call_planes(c, planes_before);
+    if (!rc) c->hist_pending = false;           // (only now: a settling pass that failed leaves the debt standing and is tried again by the next consumer -- ADVICE r5)
     return rc;
 }
 
@@ -1554,7 +1578,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     ScanPickArgs pa{};
     pa.C = c->ws().d_C; pa.c_planes = c->ws().c_planes; pa.c_plane_stride = c->ws().c_plane; pa.n_frames = n_frames; pa.Dp = c->Dp; pa.D = c->D; pa.P = c->P; pa.S = c->S;
     pa.chunk = SCAN_CHUNK; pa.n_chunks = n_chunks;
-    pa.mu = 0.8f; pa.one_minus_mu = 1 - 0.8f;                                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
+    pa.mu = ENERGY_MU; pa.one_minus_mu = ENERGY_ONE_MINUS_MU;                 // SteeringBeamforming.h:70, .cpp:134,139 (float arithmetic)
     pa.inv_norm = exact_reciprocal(30.f * (float)c->P);
     pa.state_in = c->d_E[c->e_cur] + a0 * c->D; pa.state_out = c->d_E[c->e_cur ^ 1] + a0 * c->D;
     pa.part_planes = c->ws().partial_done ? c->ws().part_planes : 1; pa.part_plane_stride = (long long)n_arrays * n_chunks * c->D;
@@ -1642,23 +1666,11 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
                 hipLaunchKernelGGL(k_srp_cand, dim3((unsigned)std::min<long long>(max_items, std::max(1, c->kn.cand_grid))), dim3(1024), 0, st, ca);
                 continue;
             }
-            GemmArgs ga{};
-            ga.A = c->ws().d_Ax; ga.B = c->d_B; ga.C = c->ws().d_Cx; ga.Bt = c->d_Bt;
-            ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
-            ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
-            ga.n_list = c->ws().d_nlist; ga.list0 = (int)g0;
-            ga.repair_ksplit = repair_ksplit_for(c, n_arrays); ga.repair_items = c->kn.repair_items;
-            const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
-            const long long max_work = (pass_rows + 127) / 128 * col_tiles * ga.repair_ksplit;
-            dim3 gg((unsigned)std::min<long long>(max_work, 768));
-            if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
-            else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
             RepairPatchArgs pp{};
-            pp.Cx = c->ws().d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit; pp.items = ga.repair_items;
-            pp.list = c->ws().d_list; pp.n_list = c->ws().d_nlist; pp.list0 = (int)g0; pp.groups_per_array = gpa; pp.need = c->ws().d_need;
-            pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames; pp.Dp = c->Dp;
+            pp.groups_per_array = gpa;
+            pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames;
             if (hist_valid) { pp.hist_C = c->d_hist_C[c->hist_cur]; pp.hist_base = n_arrays * gpa; }
-            hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);
+            launch_repair_contraction(c, c->ws(), g0, pass_rows, n_arrays, pp, st);
         }
         set_call_planes(c, 1);
         const size_t smem4 = (size_t)32 * (c->Dp + 8) * sizeof(float);

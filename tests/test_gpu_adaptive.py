@@ -484,6 +484,42 @@ def test_lazy_tails_match_the_eager_form_and_the_oracle(force_small, monkeypatch
     assert counts[True]["recomputed"] + 12 * A * n_calls <= counts[False]["recomputed"], counts
 
 
+def test_settling_the_history_in_passes_when_the_workspace_budget_is_small(force_small, monkeypatch):
+    """settle_history ran ONE pass over the history rows of every array whatever the workspace held.  With a 4 MB budget
+    (MCA_HIP_WS_MAX_MB: 128 two-plane rows per repair pass) and 16 arrays the history is 256 rows: two passes.  A lazy call, a call too
+    small for the mode (settles the debt), a lazy call, a state blob (settles again), the stream continued from the blob: bins
+    against the oracle throughout."""
+    monkeypatch.setenv("MCA_HIP_WS_MAX_MB", "4")
+    monkeypatch.setenv("MCA_HIP_ADAPT_TAU_SCALE", "20")
+    fs, N, hop, A = 48000, 1024, 512, 16
+    xs = synth.ULA8
+    sizes = [64, 16, 64, 64]
+    total = sum(sizes)
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-70.0 + 9 * a), fs, (total + 1) * hop, 9100 + a, snr_db=8.0).astype(np.float32) for a in range(A)])
+    ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A, adaptive_fallback=False)
+    ctx.reset_timing()
+    b1, a1 = _dev_calls(ctx, pcm, 0, 3, hop, sizes[:3])
+    blob = ctx.state_save()
+    st = ctx.repair_stats()
+    ctx.close()
+    assert st["frames"] == 2 * A * 64, st                       # (the 16-frame call ran as FP16X3)
+    ctx2 = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A, adaptive_fallback=False)
+    ctx2.state_load(blob)
+    t0 = sum(sizes[:3])
+    b2, a2 = _dev_calls(ctx2, pcm[:, :, t0 * hop:], 0, 1, hop, sizes[3:])
+    ctx2.close()
+    bins, audio = np.concatenate([b1, b2], axis=1), np.concatenate([a1, a2], axis=1)
+    from parity_helpers import classify_bins, assert_audio_where_bins_agree
+    n_ties = 0
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, 0.5, want_map=True)
+        ties, bad = classify_bins(bins[a], o["bin"][:, 0], o["energy"], 28)
+        assert not bad, (a, bad[:5])
+        n_ties += len(ties)
+        assert_audio_where_bins_agree(audio[a][None], o["out"], bins[a], o["bin"][:, 0], hop)
+    assert n_ties <= 0.02 * A * total, n_ties
+
+
 def test_candidate_columns_and_frames_of_exact_zeros(force_small, monkeypatch):
     """Candidate columns (round 5; CandArgs in mca_internal.h): lazy calls recompute a flagged frame's rows at the delays its pick can be
     among.  A low-SNR stream with a stretch of digital silence in the middle (every channel exact zeros: those rows are zero in the coarse
