@@ -4,7 +4,8 @@ On the MI355X boxes of this pool that operand path returns a wrong value now and
 mixes MFMA with LDS reads (tools/probes/coresidency_standalone.hip reproduces it without this library, rocFFT
 shows it too).  The hand-written helpers keep to the rule (fft512.h, RULE); this script catches what the compiler's vectoriser
 invents.  It disassembles every gfx950 code object inside mcarray_amd/libmcarray_hip.so and lists the offending instructions per
-kernel.  usage: python tools/check_isa.py [path/to/lib.so]     (exit code 1 when anything is found; tests/test_cabi_loads.py runs it)"""
+kernel.  usage: python tools/check_isa.py [path/to/lib.so]     (exit code 3 when the form is found -- any other non-zero code is a
+failure of the tooling itself, an exception or a missing disassembler; tests/test_cabi_loads.py runs it)"""
 import os
 import re
 import shutil
@@ -47,4 +48,4 @@ if __name__ == "__main__":
     for k in sorted(bad, key=lambda k: -len(bad[k])):
         print("%5d  %s   e.g. %s" % (len(bad[k]), k, bad[k][0]))
     print("%s: %d kernels hold %d packed-fp32 instructions with the high half of src1 in the low result" % (lib, len(bad), sum(len(v) for v in bad.values())))
-    sys.exit(1 if bad else 0)
+    sys.exit(3 if bad else 0)
