@@ -326,8 +326,9 @@ def test_graph_of_a_new_shape_while_the_mode_is_suspended(monkeypatch):
     ctx.reset_timing()
     noise = (0.1 * rng.standard_normal((A, len(xs), (F + 1) * 512))).astype(np.float32)
     ctx.process_frames_host(noise)                     # adaptive: everything flagged, the report says so
-    ctx.process_frames_host(noise)                     # reads the report: suspended from here on
-    assert ctx.repair_stats()["frames"] == A * F
+    ctx.process_frames_host(noise)                     # adaptive as well: a report is consumed two calls after its own
+    ctx.process_frames_host(noise)                     # consumes the first report: suspended from here on
+    assert ctx.repair_stats()["frames"] == 2 * A * F
     F2, A2 = 320, 2                                    # a shape this context has not run in adaptive mode
     pcm = torch.from_numpy(np.stack([synth.noise_source_stream(xs, np.deg2rad(20.0 + 30 * a), fs, (F2 + 1) * 512, 5 + a) for a in range(A2)])).to(dev)
     b = torch.empty(A2, F2, 1, dtype=torch.int32, device=dev); r = torch.empty(A2, F2, 1, dtype=torch.float32, device=dev)
