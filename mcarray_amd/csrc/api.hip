@@ -61,7 +61,7 @@ struct Knobs {
     // measurement only (-DMCA_MEASURE)
     bool gemm_ks2 = false;             // MCA_HIP_GEMM_KS2: two K halves for 16 384 ... 32 767 rows (round 4) instead of four quarters
     bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
-         v1_nosplit = false, no_n512 = false, no_sub2 = false;
+         v1_nosplit = false, no_n512 = false, no_sub2 = false, no_n2048 = false;   // (no_n2048: MCA_HIP_NO_N2048, the any-length kernels at 2048-sample frames: A/B and parity of both)
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256, list_grid = 512;
     bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
     int spw_waves = 4;                 // MCA_HIP_SPW_WAVES: 8 = the regular launches of k_stft_phat_wave as one workgroup of eight waves per CU
@@ -111,6 +111,7 @@ struct mca_hip_ctx {
     int M = 0, P = 0, G = 0, D = 0, Dp = 0, K = 0, N = 0, H = 0, logH = 0, Kp = 0, S = 1, prec = 0;
     bool ula = false, stream_ok = false, generic = false;
     bool n512 = false;             // 512-sample frames with <= 8 microphones: k_stft_phat_512 / k_beamform_512 instead of the any-length kernels
+    bool n2048 = false;            // 2048-sample frames on the wave-level 1024-point transform (kernels_2048.hip): the beamformer for any M, the analysis for M <= 8 and > 2
     std::string stream_why;       // why the stream API is unavailable for this configuration
     int v2_min_rows = 16384;       // one operand plane; twice that with two (plan_gemm)
     float step = 0.f;
@@ -299,6 +300,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.gemm_ks2 = measure_env("MCA_HIP_GEMM_KS2") != nullptr;
     k.v1_nosplit = measure_env("MCA_HIP_V1_NOSPLIT") != nullptr;
     k.no_n512 = measure_env("MCA_HIP_NO_N512") != nullptr;
+    k.no_n2048 = env_str("MCA_HIP_NO_N2048") != nullptr;
     k.no_sub2 = measure_env("MCA_HIP_NO_SUB2") != nullptr;
     k.spw_fpw = (int)geti(measure_env("MCA_HIP_SPW_FPW"), 0);
     k.bfw_ft = (int)geti(measure_env("MCA_HIP_BFW_FT"), 0);
@@ -1043,6 +1045,7 @@ int mca_hip_create(const mca_hip_config *cfg, mca_hip_ctx **out)
         c->stream_why = "gcc_weighting NONE: the stream API serves it at fft_size 1024 with 4 or 8 microphones (the frame API takes any shape)";
     }
     c->n512 = c->N == 512 && c->M <= 8 && c->stream_ok && !c->kn.no_n512;
+    c->n2048 = c->N == 2048 && c->stream_ok && !c->kn.no_n2048;
     if (c->kn.v2_min_rows > 0) c->v2_min_rows = c->kn.v2_min_rows;
 
     // generateLookupTable (SteeringBeamforming.cpp:58-94): pairs i<j lexicographic, float delays
@@ -1392,6 +1395,28 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             else { if (c->prec == MCA_HIP_SRP_FP32) LSUB(4, float); else LSUB(4, _Float16); }
 #undef LSUB
             rc = MCA_HIP_OK;
+        } else if (c->n2048 && c->M > 2 && c->M <= 8) {
+            // 2048-sample frames: a wave per channel on the 1024-point complex transform + split, spectra in LDS, thread = two bins
+            const int fp = c->M == 4 ? 2 : 1, mr = c->M == 4 ? 4 : 8;
+            sa.fpb = 16;
+            while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
+            const size_t smem6 = ((size_t)fp * mr * 1026 + F1K_TWORDS + 8 * F1K_SCRATCH + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
+            dim3 g6((nf + sa.fpb - 1) / sa.fpb, n_arrays);
+#define L2048(MT, U, T)                                                                                                   \
+            do {                                                                                                          \
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_2048<MT, U, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem6)); \
+                hipLaunchKernelGGL((k_stft_phat_2048<MT, U, T>), g6, dim3(512), smem6, st, sa);                           \
+            } while (0)
+#define L2048T(T)                                                                                                         \
+            do {                                                                                                          \
+                if (c->M == 8 && c->ula) L2048(8, true, T); else if (c->M == 8) L2048(8, false, T);                       \
+                else if (c->M == 4 && c->ula) L2048(4, true, T); else if (c->M == 4) L2048(4, false, T);                  \
+                else if (c->ula) L2048(0, true, T); else L2048(0, false, T);                                              \
+            } while (0)
+            if (c->prec == MCA_HIP_SRP_FP32) L2048T(float); else L2048T(_Float16);
+#undef L2048T
+#undef L2048
+            rc = MCA_HIP_OK;
         } else if (c->generic) {
             const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2) + 16;
 #define GEN_LAUNCH(K)                                                                                                     \
@@ -1732,6 +1757,16 @@ static bool wave_beamformer_applies(const mca_hip_ctx *c)
 // steering rows of every grid angle (+ the initial DOA): allocated and built once, outside any capture
 static int ensure_bf_table(mca_hip_ctx *c)
 {
+    if (!c->d_bftab && c->n2048) {
+        // 2048-sample frames: a row per (angle, CHANNEL), [D + 1][M][1032] (k_beamform_wave_2048)
+        HIP_TRY(c, hipMalloc((void **)&c->d_bftab, (size_t)(c->D + 1) * c->M * 1032 * sizeof(float2)));
+        c->bf_pairs = c->M;
+        const double unit = (double)c->cfg.sample_rate / (double)c->N / 346.1;     // Beamformer.cpp:59 without 2 pi
+        hipLaunchKernelGGL(k_bf_table_2048, dim3(c->D + 1, c->M), dim3(256), 0, nullptr, c->d_bftab, c->d_grid, c->d_micx, c->M, unit);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipDeviceSynchronize());
+        return MCA_HIP_OK;
+    }
     if (c->d_bftab || !wave_beamformer_applies(c)) return MCA_HIP_OK;
     const int np = (c->M + 1) / 2;
     HIP_TRY(c, hipMalloc((void **)&c->d_bftab, (size_t)(c->D + 1) * np * 1024 * sizeof(float2)));
@@ -1747,6 +1782,23 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
                          int n_arrays, int n_frames, const float *doa_rad, float *out_pcm, hipStream_t st, const int *doa_bin = nullptr)
 {
     const size_t a0 = (size_t)c->a0;
+    if (doa_bin && c->d_bftab && c->n2048 && (reinterpret_cast<uintptr_t>(out_pcm) & 7) == 0) {
+        // 2048-sample frames, the localiser's own picks: one wave per run of frames, a transform per channel (k_beamform_wave_2048)
+        BeamformWaveArgs wa{};
+        wa.pcm = pcm; wa.array_stride = array_stride; wa.mic_stride = mic_stride;
+        wa.M = c->M; wa.n_pairs = c->M; wa.n_frames = n_frames; wa.S = c->S;
+        wa.ft = 16;
+        while (wa.ft > 2 && (long long)n_arrays * c->S * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
+        wa.window = c->d_window; wa.doa_bin = doa_bin; wa.table = c->d_bftab; wa.out = out_pcm;
+        wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->S * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->S * c->H;
+        const int runs = (n_frames + wa.ft - 1) / wa.ft;
+        const size_t smem_w = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2);
+        time_begin(c, MCA_HIP_K_BEAMFORM, st);
+        hipLaunchKernelGGL(k_beamform_wave_2048, dim3((runs + 3) / 4, n_arrays, c->S), dim3(256), smem_w, st, wa);
+        time_end(c, st);
+        HIP_TRY(c, hipGetLastError());
+        return MCA_HIP_OK;
+    }
     if (doa_bin && c->d_bftab && wave_beamformer_applies(c)) {
         BeamformWaveArgs wa{};
         wa.pcm = pcm; wa.array_stride = array_stride; wa.mic_stride = mic_stride;

@@ -59,6 +59,8 @@ CASES = [
     ("ULA16", synth.ULA16, 1024, (70, 58)),
     ("ULA4", ULA4, 1024, (33, 95)),
     ("REEMC_2048", synth.REEM_C, 2048, (20, 21)),          # the dead beamformer test's array and frame length (test_mcarray.cpp:640-656)
+    ("ULA16_2048", synth.ULA16, 2048, (17, 30)),
+    ("ULA8_2048", synth.ULA8, 2048, (33, 9)),
 ]
 
 
@@ -91,10 +93,11 @@ def test_das_stream_angle_changing_per_frame_matches_oracle(name, xs, N, splits)
     ctx.close()
 
 
-@pytest.mark.parametrize("name,xs,N,splits", CASES[:3], ids=[c[0] for c in CASES[:3]])
+@pytest.mark.parametrize("name,xs,N,splits", CASES, ids=[c[0] for c in CASES])
 def test_das_stream_grid_angles_match_oracle(name, xs, N, splits):
     """bins_are_grid: the caller passes grid bins and their angles (the localiser's picks, or any grid index) --
-    mca_hip_separate_frames_bins_dev, k_beamform_wave with the per-angle rows T[bin]."""
+    mca_hip_separate_frames_bins_dev, k_beamform_wave with the per-angle rows T[bin] (2048-sample frames: k_beamform_wave_2048,
+    a row per angle and channel)."""
     fs, F = 48000, sum(splits)
     pcm = synth.noise_source_stream(xs, np.deg2rad(40.0), fs, (F + 1) * (N // 2), 2300 + len(xs))
     ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=1)

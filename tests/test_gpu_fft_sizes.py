@@ -81,6 +81,67 @@ def test_other_frame_length_power_gate():
     ctx.close()
 
 
+IRR5 = [0.0, 0.028, 0.071, 0.102, 0.155]
+
+
+@pytest.mark.parametrize("prec", [api.SRP_FP32, api.SRP_FP16X3, api.SRP_FP16])
+@pytest.mark.parametrize("name,xs,S,step", [("ULA8", synth.ULA8, 1, 0.5), ("REEMC", synth.REEM_C, 2, 5.0), ("IRR5", IRR5, 1, 1.0), ("ULA3", [0.0, 0.05, 0.1], 1, 3.0),
+                                             ("ULA16", synth.ULA16, 1, 1.0)])
+def test_2048_sample_frames_on_the_wave_level_transform(name, xs, S, step, prec):
+    """Round 6 (kernels_2048.hip): a 2048-sample frame is ONE 1024-point complex transform of (even, odd) samples per channel plus a split
+    step -- k_stft_phat_2048 (3 ... 8 microphones: compile-time 8 / 4, run-time others; 16 keep the any-length analysis) and
+    k_beamform_wave_2048 (any M).  The reference's own beamformer test runs this frame length (test/test_mcarray.cpp:660-662, fftOrder 11).
+    Against the oracle in two calls (the overlap-add carries and the energy state), and against the any-length kernels
+    (MCA_HIP_NO_N2048) on the same input."""
+    fs, N, hop, F, cut, A = 96000, 2048, 1024, 45, 19, 2
+    pcm = np.stack([sum(synth.noise_source_stream(xs, np.deg2rad(th + 31.0 * a), fs, (F + 1) * hop, 90 + 7 * a + i) for i, th in enumerate((-48.0, 22.0)[:S]))
+                    for a in range(A)]).astype(np.float32)
+    ctx = api.Context(fs, xs, N, step, S, srp_precision=prec, max_arrays=A)
+    ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * hop], want_energy=True)
+    rb = ctx.process_frames_host(pcm[:, :, cut * hop:], want_energy=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out")}
+    tol_e = {api.SRP_FP32: 2e-5, api.SRP_FP16X3: 2e-5, api.SRP_FP16: 2e-4}[prec]
+    from parity_helpers import assert_audio_where_bins_agree
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), S, step, want_map=True)
+        _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=3)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= tol_e * np.abs(o["energy"]).max()
+        assert_audio_where_bins_agree(r["out"][a][:o["out"].shape[0]], o["out"], r["bin"][a], o["bin"], hop)
+    ctx.close()
+    os.environ["MCA_HIP_NO_N2048"] = "1"
+    try:
+        ctx = api.Context(fs, xs, N, step, S, srp_precision=prec, max_arrays=A)
+    finally:
+        del os.environ["MCA_HIP_NO_N2048"]
+    g = ctx.process_frames_host(pcm, want_energy=True)
+    ctx.close()
+    assert np.mean(g["bin"] != r["bin"]) <= 0.02
+    assert np.abs(g["energy"] - r["energy"]).max() <= (4e-6 if prec != api.SRP_FP16 else 2e-4) * np.abs(r["energy"]).max()
+
+
+def test_2048_sample_frames_power_gate():
+    """the gate on the 2048-sample analysis (FFTPower from the spectra in LDS; 3 s at 96 kHz = 141 frames of 2048 samples)"""
+    fs, N, F = 96000, 2048, 230
+    xs, hop = synth.ULA8, N // 2
+    rng = np.random.default_rng(4)
+    L = (F + 1) * hop
+    src = synth.noise_source_stream(xs, np.deg2rad(-33.0), fs, L, 23).astype(np.float64)
+    env = np.zeros(L)
+    for a, b in ((150, 170), (176, 181), (195, F - 1)):
+        env[a * hop:b * hop] = 1.0
+    pcm = (rng.standard_normal((len(xs), L)) * 0.001 + src * env).astype(np.float32)
+    o = po.ssl_stream_gated(fs, N, xs, pcm.astype(np.float64), 1, 5.0, True)
+    assert 0 < o["fired"].sum() < F and o["fired"][:141].sum() == 0
+    ctx = api.Context(fs, xs, N, 5.0, 1, use_power_floor=True)
+    r = ctx.process_frames_host(pcm[None], want_energy=True)
+    assert np.array_equal(r["voiced"][0], o["fired"])
+    np.testing.assert_allclose(r["power"][0][141:], o["power"][141:], rtol=0, atol=2e-3)          # dB
+    assert np.array_equal(r["bin"][0], o["bin"])
+    assert np.abs(r["energy"][0] - o["energy"]).max() <= 2e-5 * np.abs(o["energy"]).max()
+    assert np.abs(r["out"][0] - o["out"]).max() <= 2e-5 * np.abs(o["out"]).max() + 1e-7
+    ctx.close()
+
+
 def test_any_length_kernels_agree_with_tuned_kernels_at_1024():
     # MCA_HIP_FORCE_GENERIC routes N = 1024 through kernels_generic.hip: same A layout, same contraction
     fs, N, F, A = 48000, 1024, 40, 2

@@ -70,6 +70,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "two":
         run_two_channel()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n2048":       # 2048-sample frames (kernels_2048.hip; MCA_HIP_NO_N2048=1: the any-length kernels)
+        run(8, 96000, 2048, 0.5, 8, 2048, steps=30)
+        run(8, 96000, 2048, 0.5, 8, 2048, prec=api.SRP_FP16, steps=30)
+        run(4, 96000, 2048, 0.5, 8, 2048, steps=30)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gate":          # the reference's default usePowerFloor, in the bench's precision
         for gate in (False, True):
             run(8, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, gate=gate, steps=30)
