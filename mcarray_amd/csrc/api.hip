@@ -481,7 +481,10 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
     if (c->plan_rows > 0) rows = c->plan_rows;
     // 256 x 384 tiles from 16 384 rows with one operand plane (128 workgroups of k_srp_gemm_f16_v3 beat the 128 x 192 kernel
     // there: 134 vs 156 us, and leave the scan's chunk results), from 32 768 rows with the hi + lo planes (343 vs 299 us at 16 384)
-    g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows >= (long long)c->v2_min_rows * (c->a_planes == 2 ? 2 : 1) && !c->kn.gemm_v1;
+    // (round 6: a contraction twice as deep -- 2048-sample frames, 16 microphones: 14 350 / 15 390 elements per plane -- gives a 256 x 384
+    // workgroup of a K QUARTER the work a K half has at 7 182: two planes take the big tiles from 16 384 rows there, profiles/r06_n2048.log)
+    const long long deep = cur_kp(c) >= 12288 ? 2 : 1;
+    g.v2 = c->prec != MCA_HIP_SRP_FP32 && c->Dp == 384 && rows * (c->a_planes == 2 ? deep : 1) >= (long long)c->v2_min_rows * (c->a_planes == 2 ? 2 : 1) && !c->kn.gemm_v1;
     if (g.v2) {
         // 256 x 384 tiles need >= ~256 workgroups to fill the chip: one K range from 65 536 rows, two halves from 32 768, and below that four
         // quarters where the contraction is deep (round 5: 16 microphones, 15 392 terms per row -- 16 384 rows were 128 workgroups on half
@@ -1787,14 +1790,17 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         BeamformWaveArgs wa{};
         wa.pcm = pcm; wa.array_stride = array_stride; wa.mic_stride = mic_stride;
         wa.M = c->M; wa.n_pairs = c->M; wa.n_frames = n_frames; wa.S = c->S;
+        // frames per wave: a workgroup covers 4 ft - 1 frames (one analysed twice); the smallest ft whose workgroups fit ONE resident round of
+        // two per CU (255 registers: two waves per SIMD), 16 when no such ft exists (many rounds anyway)
         wa.ft = 16;
-        while (wa.ft > 2 && (long long)n_arrays * c->S * ((n_frames + wa.ft - 1) / wa.ft) < 2048) wa.ft >>= 1;
+        for (int ft = 2; ft <= 64; ++ft)
+            if ((long long)n_arrays * c->S * ((n_frames + 4 * ft - 2) / (4 * ft - 1)) <= 2LL * c->n_cu) { wa.ft = ft; break; }
         wa.window = c->d_window; wa.doa_bin = doa_bin; wa.table = c->d_bftab; wa.out = out_pcm;
         wa.tail_in = c->d_tail[c->tail_cur] + a0 * c->S * c->H; wa.tail_out = c->d_tail[c->tail_cur ^ 1] + a0 * c->S * c->H;
-        const int runs = (n_frames + wa.ft - 1) / wa.ft;
-        const size_t smem_w = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2);
+        const int wgs = (n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1);
+        const size_t smem_w = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH + 4 * 512) * sizeof(float2);
         time_begin(c, MCA_HIP_K_BEAMFORM, st);
-        hipLaunchKernelGGL(k_beamform_wave_2048, dim3((runs + 3) / 4, n_arrays, c->S), dim3(256), smem_w, st, wa);
+        hipLaunchKernelGGL(k_beamform_wave_2048, dim3(wgs, n_arrays, c->S), dim3(256), smem_w, st, wa);
         time_end(c, st);
         HIP_TRY(c, hipGetLastError());
         return MCA_HIP_OK;

@@ -218,9 +218,13 @@ __global__ __launch_bounds__(256) void k_bf_table_2048(float2 *tab, const float 
 }
 
 // --------------------------------------------------------------------------------------
-// k_beamform_wave_2048: grid (ceil(runs / 4), arrays, sources) x 256 threads = 4 waves, one wave per run of ft frames (a run re-analyses the
-// frame before it for its overlap-add carry; that frame's output is dropped).  Per frame and channel: windowed samples -> transform ->
-// mirrors -> split -> Y += 2 X_c T_c[doa bin] at the lane's 17 bins; then the inverse split
+// k_beamform_wave_2048: grid (workgroups per array, arrays, sources) x 256 threads = 4 waves, one wave per run of frames.  Overlap-add carries
+// as in k_beamform_wave: a workgroup covers 4 ft - 1 consecutive frames; wave 0 takes the frame BEFORE them too (only its second half
+// counts: the carry into the workgroup's first hop) and ft - 1 frames, waves 1..3 take ft frames each.  A wave does not wait for its
+// predecessor: it stores its first hop without a carry, the waves leave their final carries in LDS, and after one barrier at the very end
+// each wave adds its predecessor's carry to that hop.  One frame in 4 ft is analysed twice.
+// Per frame and channel: windowed samples -> transform -> mirrors -> split -> Y += 2 X_c T_c[doa bin] at the lane's 17 bins; then the
+// inverse split
 //     2 E'[k] = Y[k] + conj Y[1024 - k],   2 O'[k] = (Y[k] - conj Y[1024 - k]) conj(W^k),   Z'[k] = E' + j O',   Z'[1024 - k] = conj E' + j conj O'
 // through the wave's scratch into the transform's input order, the inverse transform (y[2n] + j y[2n+1] at n = lane + 64 i), overlap-add.
 // --------------------------------------------------------------------------------------
@@ -230,16 +234,19 @@ __global__ __launch_bounds__(256, 2) void k_beamform_wave_2048(BeamformWaveArgs 
     float2 *tab = reinterpret_cast<float2 *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *buf = tab + F1K_TWORDS + wave * F1K_SCRATCH;
+    float2 *xcarry = tab + F1K_TWORDS + 4 * F1K_SCRATCH;                  // [4 waves][512] final carries
     f1k_table_init(tab, tid, 256);
     F1kLane lc;
     lc.init(lane);
     __syncthreads();
     const int a = blockIdx.y, S = p.S, M = p.M;
     const long long as = (long long)a * S + blockIdx.z;
-    const int t0 = ((int)blockIdx.x * 4 + wave) * p.ft, t1 = min(t0 + p.ft, p.n_frames);
-    if (t0 >= t1) return;                                                 // (no barrier below)
-    const int tfirst = t0 > 0 ? t0 - 1 : 0;
+    const int w0 = (int)blockIdx.x * (4 * p.ft - 1);                      // the workgroup's first frame
+    const int t0 = wave == 0 ? w0 : w0 + wave * p.ft - 1, t1 = min(w0 + (wave + 1) * p.ft - 1, p.n_frames);
+    const bool active = t0 < t1;
+    const int tfirst = (wave == 0 && t0 > 0) ? t0 - 1 : t0;               // wave 0 analyses the frame before its run for the carry
     const int lam = lane <= 32 ? lane : 96 - lane;
+    if (active) {
     float2 wk[8], win[16];
     split_twiddles(wk, lam);
 #pragma unroll
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_beamform_wave_2048(BeamformWaveArgs 
             buf[k] = make_float2(e2.x - o2.y, e2.y + o2.x);                   // E' + j O'
             if (k != 0) buf[H2K - k] = make_float2(e2.x + o2.y, o2.x - e2.y); // conj E' + j conj O'
         }
-        if (lane == 0) buf[512] = make_float2(Y512.x, -Y512.y);               // Z'[512] = conj Y[512]  (2 E' = 2 Re Y, 2 O' = -2 Im Y)
+        if (lane == 0) buf[512] = make_float2(2.f * Y512.x, -2.f * Y512.y);   // 2 Z'[512] = 2 conj Y[512]  (2 E' = 2 Re Y, 2 O' = -2 Im Y; every word holds 2 E' + j 2 O')
         wave_lds_fence();
         float2 y[16];
 #pragma unroll
@@ -318,6 +325,18 @@ __global__ __launch_bounds__(256, 2) void k_beamform_wave_2048(BeamformWaveArgs 
     if (t1 == p.n_frames) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) reinterpret_cast<float2 *>(p.tail_out + as * H2K)[lane + 64 * i] = carry[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xcarry[wave * 512 + lane + 64 * i] = carry[i];
+    }
+    __syncthreads();
+    if (active && wave > 0) {                                             // (the hop was stored without a carry: the wave's own store, read back)
+        float2 *o = reinterpret_cast<float2 *>(p.out + as * p.n_frames * H2K + (long long)t0 * H2K) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 c = xcarry[(wave - 1) * 512 + lane + 64 * i], v = o[64 * i];
+            o[64 * i] = make_float2(v.x + c.x, v.y + c.y);
+        }
     }
 }
 
