@@ -120,6 +120,18 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False):
                 ch_ = int(rng.integers(0, M))
                 pcm[:, ch_, lo_:hi_] = 0.0
                 silence = ("channel %d" % ch_, lo_ / (N // 2), hi_ / (N // 2))
+        # round 6 (csrc/pair_balance.h): channels whose levels are far apart -- one channel 20 ... 110 dB down (any mode), or, outside the lazy mode
+        # too, one channel digitally muted over a stretch whose edges fall inside frames
+        uneven = None
+        if M > 1 and rng.integers(0, 4) == 0:
+            ch_, db_ = int(rng.integers(0, M)), float(rng.uniform(20.0, 110.0))
+            pcm[:, ch_, :] *= np.float32(10.0 ** (-db_ / 20.0))
+            uneven = "channel %d %.0f dB down" % (ch_, db_)
+        if M > 1 and not lazy and rng.integers(0, 6) == 0:
+            lo_ = int(rng.integers(0, max(pcm.shape[2] // 2, 2))); hi_ = lo_ + int(rng.integers(1, max(pcm.shape[2] // 2, 2)))
+            ch_ = int(rng.integers(0, M))
+            pcm[:, ch_, lo_:hi_] = 0.0
+            uneven = (uneven + ", " if uneven else "") + "channel %d muted over samples %d..%d" % (ch_, lo_, hi_)
         if os.environ.get("MCA_FUZZ_PREC"):
             prec = {"fp32": api.SRP_FP32, "fp16x3": api.SRP_FP16X3, "fp16": api.SRP_FP16, "adaptive": api.SRP_ADAPTIVE}[os.environ["MCA_FUZZ_PREC"]]
         tag = "case %d: M=%d %s fs=%d N=%d step=%.1f S=%d A=%d F=%d prec=%d gate=%d" % (case, M, "ula" if ula else "irr", fs, N, step, S, A, F, prec, gate)
@@ -181,11 +193,11 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False):
             if st and st["frames"]:
                 n_adaptive += 1
             n_ties += ties
-            print("ok  ", tag, "ties", ties, "cut", sizes if sizes else cut, "repair", st)
+            print("ok  ", tag, "ties", ties, "cut", sizes if sizes else cut, "repair", st, ("uneven: " + uneven) if uneven else "")
             ctx.close()
         except Exception as e:  # noqa: BLE001
             bad += 1
-            print("FAIL", tag, "--", e, "| cut", sizes if sizes else locals().get("cut"), "repair", ctx.repair_stats() if prec == api.SRP_ADAPTIVE else None)
+            print("FAIL", tag, "--", e, "| cut", sizes if sizes else locals().get("cut"), "repair", ctx.repair_stats() if prec == api.SRP_ADAPTIVE else None, ("uneven: " + uneven) if uneven else "")
     print("%d cases, %d failures (unclassified bin differences, energy / audio errors, refused shapes), %d cases went through the adaptive path, "
           "%d classified differences (oracle-fragile frames) in total, %d of them under the absolute bar of round 3 and %d only with eps scaled by "
           "the values compared (tests/parity_helpers.py)" % (cases, bad, n_adaptive, n_ties, n_abs, n_ties - n_abs))
