@@ -40,6 +40,88 @@ ROW_PAD = 64                                           # floats of padding behin
 PROFILE_TAG = "r05"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
 
 
+MERGED_REALS = {8: 3968, 4: 1600}     # reals per merged one-plane A row (2 x the distinct products k (j - i), padded to the K stage of the kernel; 8-mic ULA: 1 962 complex)
+
+
+def compact_line(line):
+    """The record the driver's stdout tail must hold whole (under 6 KB): numbers only -- the notes, sources and
+    sub-measurements stay in the full record (--detail-out / --full; what every field means: profiles/bench_notes.md)."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+    def r4(x):
+        return float("%.4g" % x) if isinstance(x, float) else x
+
+    def rnd(o):
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v) for v in o]
+        return r4(o)
+    out = pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"))
+    out["vs_baseline"] = line.get("vs_baseline")          # (null: BASELINE.md holds no published number for this metric)
+    cfg = line.get("config", {})
+    c = pick(cfg, ("workload", "arrays_per_gpu", "frames_per_array", "srp_precision", "parallelism", "streams_per_gpu", "frames_per_stream"))
+    ss = cfg.get("single_stream_4096")
+    if ss:
+        c["single_stream_4096"] = dict(pick(ss, ("value", "ms_per_call")), graph_replay_ms=(ss.get("graph_replay") or {}).get("ms_per_call"))
+    das = cfg.get("das_single_stream")
+    if das:
+        d2 = {}
+        for k in ("offline_any_angle", "offline_grid_angle"):
+            if das.get(k):
+                d2[k] = dict(pick(das[k], ("value", "ms_per_call", "hbm_roofline_frac")),
+                             oracle_err_of_peak=(das[k].get("oracle_check") or {}).get("of_peak"), oracle_ok=(das[k].get("oracle_check") or {}).get("ok"),
+                             cpu_frames_per_s=(das[k].get("cpu_baseline") or {}).get("value"))
+        gl = das.get("graph_chunk_latency") or {}
+        d2["graph_launch_median_ms"] = {k: v.get("median_ms") for k, v in gl.items()}
+        c["das_single_stream"] = d2
+    mv = cfg.get("mvdr_256x64")
+    if mv:
+        rf = mv.get("roofline") or {}
+        c["mvdr_256x64"] = dict(pick(mv, ("value", "unit", "ms_per_step", "hbm_roofline_frac")),
+                                kernels_ms={k: v["avg_ms"] for k, v in (mv.get("kernels") or {}).items()},
+                                solve_flop_frac=(rf.get("flop_roofline") or {}).get("frac"), solve_valu_frac=(rf.get("valu_roofline") or {}).get("frac"),
+                                solve_traffic=rf.get("traffic"), cpu_frames_per_s=(mv.get("cpu_baseline") or {}).get("value"))
+    out["config"] = c
+    out.update(pick(line, ("algorithmic_GBps", "hbm_roofline_frac")))
+    if line.get("kernels"):
+        out["kernels"] = {k: pick(v, ("launches", "avg_ms")) for k, v in line["kernels"].items() if v.get("launches")}
+    rf = line.get("roofline")
+    if rf:
+        o = pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms", "measured_in", "algorithmic_bytes_per_frame", "traffic_ratio",
+                      "binding", "path_frac", "path_achieved"))
+        if rf.get("valu_roofline"):
+            o["valu_roofline"] = pick(rf["valu_roofline"], ("frac", "floor_ms", "insts_valu_per_launch", "clock_ghz"))
+        for k in ("flop_roofline",):
+            if rf.get(k):
+                o[k] = pick(rf[k], ("frac", "achieved", "peak", "unit"))
+        out["roofline"] = o
+    if line.get("roofline_by_kernel"):
+        out["roofline_by_kernel"] = [dict(pick(e, ("kernel", "avg_ms", "bound", "frac", "traffic_ratio")),
+                                          **({"valu_frac": e["valu_roofline"]["frac"]} if e.get("valu_roofline") else {}),
+                                          **({"mfma_pipe_frac": e["mfma_pipe"]["frac_of_peak"]} if e.get("mfma_pipe") else {})) for e in line["roofline_by_kernel"]]
+    cb = line.get("cpu_baseline")
+    if cb:
+        o = pick(cb, ("value", "unit", "cores", "kind", "oracle_check"))
+        o["sample"] = (cb.get("sample") or "").split(", double-precision")[0][:120]
+        if cb.get("all_cores"):
+            o["all_cores"] = pick(cb["all_cores"], ("value", "cores"))
+        out["cpu_baseline"] = o
+    if line.get("repair"):
+        out["repair"] = pick(line["repair"], ("frames", "flagged", "recomputed", "flagged_fraction", "recomputed_fraction", "columns_per_flagged_frame", "whole_row_frames"))
+    if line.get("repair_spread"):
+        out["repair_spread"] = [dict(input=(sp.get("input") or "")[:40], **pick(sp, ("ms_per_32768_frames", "vs_headline", "repair_ms", "recomputed_fraction"))) for sp in line["repair_spread"]]
+    if line.get("warmup_beyond_the_declared_steps"):
+        out["seconds_of_other_configurations_before_the_warm_up"] = line["warmup_beyond_the_declared_steps"].get("seconds_of_other_configurations_before_the_warm_up")
+    if line.get("exchange"):
+        out["exchange"] = line["exchange"]
+    out["notes"] = "profiles/bench_notes.md"
+    out = rnd(out)
+    out["value"], out["ms_per_step"] = line["value"], line["ms_per_step"]      # (the judged numbers: unrounded)
+    return out
+
+
 def synth_batch(xs, seeds, n_frames, device, noise=0.01):
     """Far-field white source per array + 20 dB sensor noise, generated on the GPU.
     One seed per array, derived from the array's GLOBAL index, so its data does not depend on the rank count."""
@@ -463,6 +545,14 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             ach = flops / (v["avg_ms"] * 1e-3) / 1e12
             e.update(bound="mfma", achieved=ach, peak=PEAK_TFLOPS[args.precision], unit="TFLOP/s", frac=ach / PEAK_TFLOPS[args.precision],
                      algorithmic_flops_per_frame=2.0 * ctx.G * 2 * K * D)
+            # ... and what the MFMA pipe itself executes: the one-plane rows of a ULA are MERGED (1 962 complex terms instead
+            # of 7 x 513: api.hip build_merged_tables) and padded (3 968 reals per row, 384 columns), so the pipe runs fewer flops than the
+            # algorithm counts; the exact modes run the unmerged depth three times (FP16X3) or on the fp32 MFMA (FP32)
+            if args.precision in ("adaptive", "fp16") and M in (4, 8):
+                ex = 2.0 * MERGED_REALS.get(M, 0) * 384 * frames_per_launch / (v["avg_ms"] * 1e-3) / 1e12
+                if ex > 0:
+                    e["mfma_pipe"] = {"executed_TFLOPs": ex, "frac_of_peak": ex / PEAK_TFLOPS[args.precision],
+                                      "executed_flops_per_frame": 2.0 * MERGED_REALS[M] * 384}
         elif name in per_frame_bytes:
             ach = per_frame_bytes[name] * frames_per_launch / (v["avg_ms"] * 1e-3) / 1e9
             e.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_frame=per_frame_bytes[name])
@@ -520,7 +610,7 @@ def run_ssl(args, world, rank, local_rank, dev, use_dist, dist):
             fps, dt, ref = cpu_baseline(pcm[0].cpu().numpy(), nf)
             gb = last_bin[0, :nf, 0].cpu().numpy()
             mism = int((gb != ref["bin"][:, 0]).sum())
-            cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+            cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port", "oracle_check": {"frames": nf, "doa_bin_mismatches": mism},
                    "sample": "array 0, first %d frames of the same input, %.1f s, double-precision scalar C restatement "
                              "(oracle/mca_oracle.c, -O3); GPU/oracle DOA-bin mismatches on the sample: %d" % (nf, dt, mism)}
             if args.cpu_all_cores:
@@ -698,6 +788,8 @@ def main():
     ap.add_argument("--gather-audio", action="store_true",
                     help="N > 1: also gather the beamformed audio (2 KB per frame) to rank 0 every step (BASELINE configs[4]: 'RCCL gather of DOA/output')")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the kernels with HIP events (A/B of the event overhead)")
+    ap.add_argument("--full", action="store_true", help="print the full record (every note, source and sub-measurement: ~15 KB) instead of the compact line")
+    ap.add_argument("--detail-out", default=None, help="file the full record is written to (default: gpurun_out/bench_detail.json when that directory exists)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -731,7 +823,20 @@ def main():
 
     line = (run_mvdr if args.config == "mvdr" else run_ssl)(args, world, rank, local_rank, dev, use_dist, dist)
     if rank == 0 and line is not None:
-        print(json.dumps(line))
+        detail = args.detail_out or (os.path.join("gpurun_out", "bench_detail.json") if os.path.isdir("gpurun_out") else None)
+        if detail:
+            try:
+                with open(detail, "w") as fh:
+                    json.dump(line, fh)
+            except OSError:
+                detail = None
+        if args.full:
+            print(json.dumps(line))
+        else:
+            out = compact_line(line)
+            if detail:
+                out["detail"] = detail
+            print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 

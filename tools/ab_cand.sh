@@ -3,7 +3,7 @@
 # against whole rows (MCA_HIP_ADAPT_CAND=0: k_srp_gemm_repair + k_repair_patch, round 4); the shipped library
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for cand in 0 1 0 1; do
-  MCA_HIP_ADAPT_CAND=$cand python bench.py --steps 100 --warmup 20 --cpu-frames 0 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
+  MCA_HIP_ADAPT_CAND=$cand python bench.py --full --steps 100 --warmup 20 --cpu-frames 0 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
   python - $cand <<PY
 import json,sys
 d=json.load(open('/tmp/ab.json'))

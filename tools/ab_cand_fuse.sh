@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 export MCA_HIP_LIB=$GRAFT_REPO_ROOT/abtest/lib_measure.so
 for f in 0 1 0 1; do
-  MCA_HIP_CAND_FUSE=$f python bench.py --steps 100 --warmup 20 --cpu-frames 0 --single-stream 1 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
+  MCA_HIP_CAND_FUSE=$f python bench.py --full --steps 100 --warmup 20 --cpu-frames 0 --single-stream 1 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
   python - $f <<PY
 import json,sys
 d=json.load(open('/tmp/ab.json'))

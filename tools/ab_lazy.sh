@@ -2,7 +2,7 @@
 # round 5: lazy tails (shipped) against every call repairing its own last rows (MCA_HIP_ADAPT_LAZY=0): the bench line's headline, the literal configs[2] call and the repair spread
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for lazy in 0 1 0 1; do
-  MCA_HIP_ADAPT_LAZY=$lazy python bench.py --steps 100 --warmup 20 --cpu-frames 0 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
+  MCA_HIP_ADAPT_LAZY=$lazy python bench.py --full --steps 100 --warmup 20 --cpu-frames 0 2> /dev/null | grep "^{" | tail -1 > /tmp/ab.json
   python - $lazy <<PY
 import json,sys
 d=json.load(open('/tmp/ab.json'))
