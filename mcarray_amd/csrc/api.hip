@@ -1846,7 +1846,9 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             return MCA_HIP_OK;
         }
         const int abl = c->kn.bfw_abl & 3;     // (-DMCA_MEASURE only: ablations with wrong results)
-        const int var = abl ? 14 : (c->kn.bfw_var & 15);
+        int var = abl ? 14 : (c->kn.bfw_var & 31);
+        // (MEASURE builds, MCA_HIP_BFW_VAR=31) the staged variant needs 16-byte aligned rows: otherwise the shipped one
+        if ((var & 16) && (var != 31 || (mic_stride & 3) || (array_stride & 3) || (reinterpret_cast<uintptr_t>(pcm) & 15))) var = 15;
         // workgroups per array: 4 runs of ft frames each, or (hand-off of the overlap-add carries inside the workgroup, VAR bit 1)
         // 4 ft - 1 frames.  With the hand-off ft is the smallest run length whose workgroups are all resident at once (two per
         // CU: 512) -- one workgroup more than that costs a whole extra round.
@@ -1855,7 +1857,7 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             while (wa.ft < 256 && (long long)n_arrays * c->S * ((n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1)) > 512) ++wa.ft;
         }
         const int wgs = (var & 2) ? (n_frames + 4 * wa.ft - 2) / (4 * wa.ft - 1) : ((n_frames + wa.ft - 1) / wa.ft + 3) / 4;
-        const size_t smem = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2) + ((var & 2) ? 4 * FFT_H * sizeof(float) : 0);
+        const size_t smem = (size_t)(F1K_TWORDS + 4 * F1K_SCRATCH) * sizeof(float2) + ((var & 2) ? 4 * FFT_H * sizeof(float) : 0) + ((var & 16) ? 3 * 8192 : 0);
         // one resident round of (nearly) two workgroups per CU: the older workgroup of every CU takes longer runs (BeamformWaveArgs::skew)
         dim3 gb(wgs, n_arrays, c->S);
         if ((var & 2) && !abl && c->kn.bfw_skew != 0 && c->S == 1 && (wgs & 1) == 0 && wa.ft >= 8 &&
@@ -1875,6 +1877,12 @@ static int separate_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         switch (var) {
             BFW_CASE(0) BFW_CASE(1) BFW_CASE(2) BFW_CASE(3) BFW_CASE(4) BFW_CASE(5) BFW_CASE(6) BFW_CASE(7)
             BFW_CASE(8) BFW_CASE(9) BFW_CASE(10) BFW_CASE(11) BFW_CASE(12) BFW_CASE(13) BFW_CASE(14) BFW_CASE(15)
+            case 31:
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_wave<false, 31, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_beamform_wave<true, 31, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                if (c->M & 1) hipLaunchKernelGGL((k_beamform_wave<true, 31, 0>), gb, dim3(256), smem, st, wa);
+                else hipLaunchKernelGGL((k_beamform_wave<false, 31, 0>), gb, dim3(256), smem, st, wa);
+                break;
         }
 #else
         switch (var) { BFW_CASE(15) }

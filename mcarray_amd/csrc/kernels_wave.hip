@@ -81,6 +81,12 @@ template <bool ODD, int VAR, int ABL>
 __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs p)
 {
     constexpr bool T1REG = VAR & 1, HANDOFF = VAR & 2, TMID = VAR & 4;
+    // (round 6 A/B; MEASURE builds) STAGE: the next step's samples go to LDS with eight global_load_lds_dwordx4 (16 bytes
+    // per lane whatever the transform's register layout wants) and are read from there with ds_read_b32, instead of 32 four-byte loads into
+    // registers that stay live through the transform.  The staging buffer of a wave is 8 KiB; wave 0 takes the twiddle table's place (dead
+    // once the stage-A twiddles are in registers), so that two workgroups still share a CU.
+    constexpr bool STAGE = (VAR & 16) != 0;
+    static_assert(!STAGE || (T1REG && TMID), "the staged variant reuses the twiddle table's LDS and requests its steering rows in the middle of the transform");
     constexpr int FOPT = 1 | ((VAR >> 3) & 1) << 1 | (T1REG ? 4 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *tab = reinterpret_cast<float2 *>(smem_raw);
@@ -92,6 +98,12 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
     lc.init(lane);
     __syncthreads();
     if (T1REG) lc.load_t1(tab, lane);
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    float *stage = nullptr;
+    if (STAGE) {
+        __syncthreads();                                                   // (every wave has its twiddles: the table's place is free)
+        stage = wave == 0 ? reinterpret_cast<float *>(tab) : reinterpret_cast<float *>(tab + F1K_TWORDS + 4 * F1K_SCRATCH) + 4 * FFT_H + (wave - 1) * 2048;
+    }
 
     const int a = p.skew ? blockIdx.x : blockIdx.y;
     const long long as = (long long)a * p.S + blockIdx.z;                // (array, source): output channel, overlap-add carry
@@ -137,8 +149,24 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
         auto load_pair = [&](int t, int pr) {
             const float *pa = base + (long long)(2 * pr) * p.mic_stride + (long long)t * FFT_H;
             const float *pb = (ODD && pr == NP - 1) ? pa : pa + p.mic_stride;
+            if (STAGE) {
+                // lane l, instruction q: samples 4 (64 q + l) .. + 3 -> the same words of the buffer (a linear copy of the frame)
+                const float *ga = pa - lane + 4 * lane, *gb = pb - lane + 4 * lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(ga + 256 * q), (lds_void_t *)(stage + 256 * q), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gb + 256 * q), (lds_void_t *)(stage + 1024 + 256 * q), 16, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { xa[i] = pa[64 * i]; xb[i] = pb[64 * i]; }
+            }
+        };
+        auto take_pair = [&]() {                                           // STAGE: the staged step into registers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xa[i] = stage[lane + 64 * i]; xb[i] = stage[1024 + lane + 64 * i]; }
+            wave_lds_fence();
         };
         load_pair(tfirst, 0);
 
@@ -149,6 +177,7 @@ __global__ __launch_bounds__(256, BFW_OCC) void k_beamform_wave(BeamformWaveArgs
         const float2 *trow = p.table + ((long long)(bins[(long long)t * p.S] + 1) * NP) * 1024 + lane;
         for (;;) {
             float2 z[16], T[16];
+            if (STAGE) take_pair();
 #pragma unroll
             for (int i = 0; i < 8; ++i) { z[2 * i] = win_lo(xa[2 * i], xb[2 * i], win[i]); z[2 * i + 1] = win_hi(xa[2 * i + 1], xb[2 * i + 1], win[i]); }
             if (ODD && pr == NP - 1) {
@@ -222,6 +251,7 @@ template __global__ void k_beamform_wave<false, 14, 1>(BeamformWaveArgs); templa
 template __global__ void k_beamform_wave<false, 14, 3>(BeamformWaveArgs);
 INST_BFW(0) INST_BFW(1) INST_BFW(2) INST_BFW(3) INST_BFW(4) INST_BFW(5) INST_BFW(6) INST_BFW(7)
 INST_BFW(8) INST_BFW(9) INST_BFW(10) INST_BFW(11) INST_BFW(12) INST_BFW(13) INST_BFW(14)
+INST_BFW(31)              // the shipped variant with its samples staged through LDS (round 6 A/B: profiles/r06_bfw_lds_stage_negative.log)
 #endif
 
 // --------------------------------------------------------------------------------------
