@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8.0
 PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0, "adaptive": 2500.0}   # dense MFMA peaks, same guide
 PREC = {"fp32": 0, "fp16x3": 1, "fp16": 2, "adaptive": 3}
 ROW_PAD = 64                                           # floats of padding behind every channel row of the synthetic input (synth_batch)
-PROFILE_TAG = "r05"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
+PROFILE_TAG = "r06"                                    # profiles/<tag>_pmc_traffic_<precision>.json of the committed PMC passes
 
 
 MERGED_REALS = {8: 3968, 4: 1600}     # reals per merged one-plane A row (2 x the distinct products k (j - i), padded to the K stage of the kernel; 8-mic ULA: 1 962 complex)
@@ -204,7 +204,7 @@ def traffic_table(precision, shape_matches):
     a --pmc pass serialises the kernels and cannot share a process with the timed loop.  Newest committed round first."""
     if not shape_matches:
         return {}, None
-    for tag in (PROFILE_TAG, "r04", "r03"):
+    for tag in (PROFILE_TAG, "r05", "r04"):
         tj = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (tag, precision))
         if not os.path.exists(tj):
             continue
@@ -238,7 +238,7 @@ def valu_roofline(kernel_substrings, avg_ms, which="adaptive", exclude=(), launc
     that issues I wave-instructions cannot finish before I x 4 / (1024 SIMDs x clock).  I (SQ_INSTS_VALU) and the clock (SQ_BUSY_CYCLES of
     the 32 shader engines / 32 / the kernel's duration in the same pass) come from the committed rocprofv3 SQ pass of the same command
     (tools/pmc_sq.sh) -- counters cannot share a process with the timed loop.  frac = that floor / this run's average launch."""
-    for tag in (PROFILE_TAG, "r04"):
+    for tag in (PROFILE_TAG, "r05", "r04"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_sq_%s.json" % (tag, which))
         if not os.path.exists(path):
             continue
@@ -707,10 +707,12 @@ def run_mvdr(args, world, rank, local_rank, dev, use_dist, dist):
     ach = per_frame * S_ * F / (kt[dom]["avg_ms"] * 1e-3) / 1e9
     tr, tr_src = None, None
     tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_mvdr.json" % PROFILE_TAG)
+    if not os.path.exists(tpath):                      # (the MVDR kernels did not change in round 6: round 5's passes stand)
+        tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic_mvdr.json")
     if os.path.exists(tpath) and S_ == 256 and F == 64:
         tk = json.load(open(tpath))["kernels"].get(dom)
         if tk:
-            tr, tr_src = tk["hbm_bytes_per_step"], "profiles/%s_pmc_traffic_mvdr.json (committed PMC passes of `bench.py --config mvdr`; not this run)" % PROFILE_TAG
+            tr, tr_src = tk["hbm_bytes_per_step"], "%s (committed PMC passes of `bench.py --config mvdr`; not this run)" % os.path.relpath(tpath, ROOT)
     roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": tr,
             "algorithmic_bytes_per_frame": per_frame}
     if tr is not None:

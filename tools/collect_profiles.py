@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -75,7 +75,7 @@ if os.path.exists(log):
     if lines:
         open(os.path.join(P, "%s_bench_mvdr.json" % tag), "w").write(lines[-1])
 for name in ("adaptive_check.json", "precision_report.json", "host_path.log", "bench_128x256.json", "bench_single_stream.json", "shapes.log", "gputest.log", "fallback.log",
-             "bench_driver_cmd.json", "bench_warmup0.json", "bench_warmup1.json", "kernel_stats_driver_cmd.csv", "stream_latency.log",
+             "bench_driver_cmd.json", "bench_driver_cmd_detail.json", "bench_warmup0.json", "bench_warmup1.json", "kernel_stats_driver_cmd.csv", "stream_latency.log",
              "repair_breakdown.log", "timeline.log"):
     src = os.path.join(G, "final", name)
     if os.path.exists(src) and os.path.getsize(src) > 0:

@@ -1,12 +1,13 @@
 # Round profiles: the driver's bench command, bench lines per precision, rocprofv3 kernel stats, PMC traffic / SQ counters, shapes.
-# usage (GPU box, from the repo root): bash tools/final_profiles.sh [a|b|c] (parts that each fit one 20-minute gpurun call; default a and b) ; then python tools/collect_profiles.py r05 here
+# usage (GPU box, from the repo root): bash tools/final_profiles.sh [a|b|c] (parts that each fit one 20-minute gpurun call; default a and b) ; then python tools/collect_profiles.py r06 here
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 PART=${1:-ab}
 if [[ $PART == *a* ]]; then
 # the driver's exact command, and the two short warm-ups VERDICT r3 asked about
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/final/bench_driver_cmd.log 2>&1
-grep "^{" gpurun_out/final/bench_driver_cmd.log | tail -1 > gpurun_out/final/bench_driver_cmd.json
+grep "^{" gpurun_out/final/bench_driver_cmd.log | tail -1 > gpurun_out/final/bench_driver_cmd.json      # (the compact line, as the driver sees it)
+cp gpurun_out/bench_detail.json gpurun_out/final/bench_driver_cmd_detail.json                                # (... and the full record of the same run)
 for w in 0 1; do
   timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup $w --cpu-frames 0 --single-stream 0 --extras 0 2> /dev/null | grep "^{" | tail -1 > gpurun_out/final/bench_warmup$w.json
 done
@@ -17,15 +18,15 @@ for p in adaptive fp16x3; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_$p -- python3 bench.py --steps 100 --warmup 20 --cpu-frames 0 --single-stream 0 --extras 0 --precision $p > gpurun_out/final/rocprof_$p.log 2>&1
   python3 tools/summarize_rocprof.py gpurun_out/final/rocprof_$p gpurun_out/final/kernel_stats_$p.csv > /dev/null; rm -rf gpurun_out/final/rocprof_$p
 done
-timeout 900 python bench.py > gpurun_out/final/bench_adaptive.log 2>&1
-timeout 300 python bench.py --arrays 128 --frames 256 --cpu-frames 0 --single-stream 0 --extras 0 > gpurun_out/final/bench_128x256.log 2>&1
+timeout 900 python bench.py --full > gpurun_out/final/bench_adaptive.log 2>&1
+timeout 300 python bench.py --full --arrays 128 --frames 256 --cpu-frames 0 --single-stream 0 --extras 0 > gpurun_out/final/bench_128x256.log 2>&1
 grep "^{" gpurun_out/final/bench_128x256.log | tail -1 > gpurun_out/final/bench_128x256.json
-timeout 900 python bench.py --precision fp16x3 --cpu-frames 0 --extras 0 > gpurun_out/final/bench_fp16x3.log 2>&1
-timeout 900 python bench.py --precision fp16 --cpu-frames 0 --extras 0 > gpurun_out/final/bench_fp16.log 2>&1
-timeout 900 python bench.py --precision fp32 --cpu-frames 0 --extras 0 --steps 30 --warmup 5 > gpurun_out/final/bench_fp32.log 2>&1
+timeout 900 python bench.py --full --precision fp16x3 --cpu-frames 0 --extras 0 > gpurun_out/final/bench_fp16x3.log 2>&1
+timeout 900 python bench.py --full --precision fp16 --cpu-frames 0 --extras 0 > gpurun_out/final/bench_fp16.log 2>&1
+timeout 900 python bench.py --full --precision fp32 --cpu-frames 0 --extras 0 --steps 30 --warmup 5 > gpurun_out/final/bench_fp32.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/rocprof_mvdr -- python3 bench.py --config mvdr --steps 20 --warmup 5 --cpu-frames 0 > gpurun_out/final/rocprof_mvdr.log 2>&1
 python3 tools/summarize_rocprof.py gpurun_out/final/rocprof_mvdr gpurun_out/final/kernel_stats_mvdr.csv > /dev/null; rm -rf gpurun_out/final/rocprof_mvdr
-timeout 300 python bench.py --config mvdr > gpurun_out/final/bench_mvdr.log 2>&1
+timeout 300 python bench.py --full --config mvdr > gpurun_out/final/bench_mvdr.log 2>&1
 fi
 if [[ $PART == *b* ]]; then
 bash tools/pmc_traffic.sh adaptive gpurun_out/pmc_traffic_adaptive > gpurun_out/final/pmc_traffic.log 2>&1
@@ -33,7 +34,7 @@ bash tools/pmc_sq.sh adaptive gpurun_out/pmc_sq > gpurun_out/final/pmc_sq.log 2>
 timeout 600 python tools/precision_report.py > gpurun_out/final/precision_report.json 2> gpurun_out/final/precision_report.log
 timeout 300 python tools/host_path_rate.py > gpurun_out/final/host_path.log 2>&1
 python tools/bench_fallback.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/fallback.log
-(python tools/bench_shapes.py; python tools/bench_shapes.py m16; python tools/bench_shapes.py sources; python tools/bench_shapes.py gate) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/shapes.log
+(python tools/bench_shapes.py; python tools/bench_shapes.py m16; python tools/bench_shapes.py sources; python tools/bench_shapes.py gate; python tools/bench_shapes.py n2048; echo "--- the any-length kernels at 2048-sample frames (MCA_HIP_NO_N2048=1):"; MCA_HIP_NO_N2048=1 python tools/bench_shapes.py n2048) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/shapes.log
 timeout 300 python tools/stream_latency.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/stream_latency.log
 fi
 if [[ $PART == *c* ]]; then
