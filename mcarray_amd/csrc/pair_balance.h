@@ -9,8 +9,8 @@
 // channel's windowed samples are multiplied by a power of two (exact) that brings it to its partner's level BEFORE the transform,
 // and the thresholds behind the transform are scaled with it: its rounding is then its own, as in a transform of its own.
 //
-// Cost on balanced input: the per-lane largest |windowed sample| of either channel (v_max3_f32, in place of the OR chain of the
-// exact-zeros test, which it also answers) and a screen of two ballots.  The screen is NECESSARY for an imbalance: the lane that
+// Cost on balanced input (2.1 % of k_stft_phat_wave, profiles/r06_ab_r05_r06.log): the per-lane largest |windowed sample| of either channel
+// (v_max3_f32, in place of the OR chain of the exact-zeros test, which it also answers) and a screen of two ballots.  The screen is NECESSARY for an imbalance: the lane that
 // holds the wave maximum of the stronger channel sees it above PB_SCREEN x its own value of the other channel.  Only then are the
 // two wave maxima formed (DPP) and compared by exponent; channels less than PB_MIN_SHIFT exponents apart stay untouched (the same
 // bits as before this header existed), so do frames of microphones that see the same field.
