@@ -53,7 +53,7 @@ def test_product_package_does_not_import_oracle():
 
 def test_measurement_switches_are_not_in_the_shipped_library():
     """the A/B switches behind DESIGN.md's measurements (one of them, MCA_HIP_BFW_ABL, returns wrong audio on
-    purpose) are compiled in only with `make MEASURE=1`; the shipped library knows the nine product switches, reads them once in
+    purpose) are compiled in only with `make MEASURE=1`; the shipped library knows the ten product switches, reads them once in
     mca_hip_create (csrc/knobs.h is the only place that touches the environment) and nothing else."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,7 +61,7 @@ def test_measurement_switches_are_not_in_the_shipped_library():
     names = set(m.decode() for m in re.findall(rb"MCA_HIP_[A-Z0-9_]{3,}", blob))
     switches = {n for n in names if not re.match(r"MCA_HIP_(OK|ERR_|SRP_|GCC_|K_|ADAPT_FALLBACK_(AUTO|OFF))", n)}
     assert switches == {"MCA_HIP_ADAPT_CAND", "MCA_HIP_ADAPT_FALLBACK", "MCA_HIP_ADAPT_LAZY", "MCA_HIP_ADAPT_MAX_SOURCES", "MCA_HIP_ADAPT_MIN_ROWS", "MCA_HIP_ADAPT_TAU_SCALE",
-                        "MCA_HIP_FORCE_GENERIC", "MCA_HIP_SCAN_CARRY", "MCA_HIP_WS_MAX_MB"}, switches
+                        "MCA_HIP_FORCE_GENERIC", "MCA_HIP_NO_N2048", "MCA_HIP_SCAN_CARRY", "MCA_HIP_WS_MAX_MB"}, switches
     src = os.path.join(root, "mcarray_amd", "csrc")
     for f in os.listdir(src):
         if f.endswith((".hip", ".h")) and f != "knobs.h":
