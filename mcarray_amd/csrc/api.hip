@@ -92,6 +92,7 @@ struct Workspace {
     float *d_part = nullptr, *d_estart = nullptr; int *d_nv = nullptr; size_t scan_ws_chunks = 0;
     float *d_power = nullptr; unsigned char *d_voiced = nullptr; float *d_power_out = nullptr; size_t gate_frames = 0;
     // ADAPTIVE: flags, repair list
+    int *d_list_full = nullptr, *d_need_full = nullptr;   // two work lists (ScanPickArgs::list_full): the units of the frames that take whole rows
     unsigned char *d_flags = nullptr; int *d_chunk_from = nullptr, *d_list = nullptr, *d_need = nullptr; unsigned *d_umask = nullptr; size_t adapt_frames = 0, adapt_chunks = 0, adapt_groups = 0;
     unsigned char *d_unsure = nullptr;                // 16 microphones: frames whose DC / Nyquist bin the coarse analysis could not vouch for (StftPhatArgs::unsure)
     int *d_nlist = nullptr, *d_last_vchunk = nullptr; size_t lastv_arrays = 0;
@@ -100,7 +101,7 @@ struct Workspace {
     {
         auto F = [](void *q) { if (q) (void)hipFree(q); };
         F(d_A); F(d_Ax); F(d_C); F(d_Cx); F(d_part); F(d_estart); F(d_nv); F(d_power); F(d_voiced); F(d_power_out);
-        F(d_flags); F(d_chunk_from); F(d_list); F(d_need); F(d_umask); F(d_nlist); F(d_last_vchunk); F(d_unsure);
+        F(d_flags); F(d_chunk_from); F(d_list); F(d_need); F(d_umask); F(d_nlist); F(d_last_vchunk); F(d_unsure); F(d_list_full); F(d_need_full);
         *this = Workspace();
     }
 };
@@ -622,6 +623,18 @@ static bool cand_call(const mca_hip_ctx *c, bool lazy)
     return c->kn.fb_enabled && c->h_probe && c->fb_state == 0 && !c->cand_heavy;
 }
 
+// Two work lists (round 6; k_scan_pick<PL, 2>): contexts whose flagged frames include whole rows BY CONSTRUCTION -- the 16-microphone ULA: eager
+// tails (its coarse kernel keeps no PCM) and unsure rows -- send those frames' units to the whole-row kernels and everything else to the
+// candidate kernel (k_srp_cand as a launch of its own: the exact rows of such an array come from k_stft_phat<16>).  Ungated calls only (the plan
+// in LDS assumes every frame advances the recursion).  MEASURED NEGATIVE (profiles/r06_m16_two_lists_negative.log: repair 0.186 -> 0.193 ms at
+// 8 x 2 048 frames -- the exact analysis, 69 us of k_stft_phat<16> at one workgroup per CU, runs once per list and the second chain's launches
+// cost what the narrower contraction saves): only with MCA_HIP_ADAPT_CAND=1 ("candidate columns wherever the call's shape allows"), never by
+// the policy; the parity test of the mode runs it that way.
+static bool cand_mixed(const mca_hip_ctx *c, bool lazy, bool gate)
+{
+    return c->kn.cand == 1 && !lazy && !gate && wave16_applies(c) && c->S == 1 && c->Dp / 32 <= CAND_WORDS_MAX;
+}
+
 // Called once at the top of an eager stream call (not per piece of a call, not while a graph is recorded): consumes the reports of
 // the adaptive calls that were enqueued FB_LAG eligible calls ago (or earlier) and decides whether this call runs coarse + repair or
 // plain FP16X3.
@@ -738,6 +751,12 @@ int ensure_adapt_workspace(mca_hip_ctx *c, int n_arrays, int n_frames, int n_chu
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_list, ng * 4));
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_need, ng * 4));
         HIP_TRY(c, hipMemset(c->ws().d_need, 0, ng * 4));                 // test-and-set words; released by k_repair_patch / k_scan_repick
+        if (c->ws().d_list_full) (void)hipFree(c->ws().d_list_full);
+        if (c->ws().d_need_full) (void)hipFree(c->ws().d_need_full);
+        c->ws().d_list_full = c->ws().d_need_full = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_list_full, ng * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->ws().d_need_full, ng * 4));
+        HIP_TRY(c, hipMemset(c->ws().d_need_full, 0, ng * 4));
         if (c->ws().d_umask) (void)hipFree(c->ws().d_umask);
         c->ws().d_umask = nullptr;
         HIP_TRY(c, hipMalloc((void **)&c->ws().d_umask, ng * (c->Dp / 32) * 4));
@@ -1198,6 +1217,7 @@ int mca_hip_reset(mca_hip_ctx *c, void *stream)
     // the self-cleaning words of the adaptive path (a call that failed half way may have left some set)
     for (Workspace &w : c->lanes) {
         if (w.d_need) HIP_TRY(c, hipMemsetAsync(w.d_need, 0, w.adapt_groups * 4, st));
+        if (w.d_need_full) HIP_TRY(c, hipMemsetAsync(w.d_need_full, 0, w.adapt_groups * 4, st));
         if (w.d_umask) HIP_TRY(c, hipMemsetAsync(w.d_umask, 0, w.adapt_groups * (c->Dp / 32) * 4, st));
         if (w.d_chunk_from) HIP_TRY(c, hipMemsetAsync(w.d_chunk_from, 0x7f, w.adapt_chunks * 4, st));
         if (w.d_nlist) HIP_TRY(c, hipMemsetAsync(w.d_nlist, 0, 16, st));
@@ -1501,13 +1521,15 @@ constexpr float ENERGY_MU = 0.8f, ENERGY_ONE_MINUS_MU = 1 - 0.8f;
 // One pass of the whole-row repair behind the list-mode analysis: the exact rows of the listed units [list0, list0 + pass_rows /
 // REPAIR_GROUP) in w.d_Ax -> three-product contraction in K segments (w.d_Cx) -> summed into the map by k_repair_patch (pp: where the
 // rows go; list0, pass_rows, col_tiles, ksplit and items are filled in here).  Shared by localise_impl and settle_history.
-static void launch_repair_contraction(mca_hip_ctx *c, Workspace &w, long long list0, long long pass_rows, int ksplit_arrays, RepairPatchArgs pp, hipStream_t st)
+static void launch_repair_contraction(mca_hip_ctx *c, Workspace &w, long long list0, long long pass_rows, int ksplit_arrays, RepairPatchArgs pp, hipStream_t st,
+                                      const int *list = nullptr, const int *n_list = nullptr, int *need = nullptr)
 {
+    if (!list) { list = w.d_list; n_list = w.d_nlist; need = w.d_need; }
     GemmArgs ga{};
     ga.A = w.d_Ax; ga.B = c->d_B; ga.C = w.d_Cx; ga.Bt = c->d_Bt;
     ga.rows = (int)pass_rows; ga.chunk_frames = (int)pass_rows; ga.total_frames = (int)pass_rows; ga.frame0 = 0;
     ga.Kp = c->Kp; ga.Dp = c->Dp; ga.a_row_elems = c->a_row_elems; ga.c_plane_elems = pass_rows * c->Dp;
-    ga.n_list = w.d_nlist; ga.list0 = (int)list0;
+    ga.n_list = n_list; ga.list0 = (int)list0;
     ga.repair_ksplit = repair_ksplit_for(c, ksplit_arrays); ga.repair_items = c->kn.repair_items;
     const int col_tiles = c->Dp == 64 ? 1 : c->Dp / 192;
     const long long max_work = (pass_rows + 127) / 128 * col_tiles * ga.repair_ksplit;
@@ -1515,7 +1537,7 @@ static void launch_repair_contraction(mca_hip_ctx *c, Workspace &w, long long li
     if (c->Dp == 64) hipLaunchKernelGGL((k_srp_gemm_repair<64>), gg, dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((k_srp_gemm_repair<192>), gg, dim3(256), 0, st, ga);
     pp.Cx = w.d_Cx; pp.pass_rows = (int)pass_rows; pp.col_tiles = col_tiles; pp.ksplit = ga.repair_ksplit; pp.items = ga.repair_items;
-    pp.list = w.d_list; pp.n_list = w.d_nlist; pp.list0 = (int)list0; pp.need = w.d_need; pp.Dp = c->Dp;
+    pp.list = list; pp.n_list = n_list; pp.list0 = (int)list0; pp.need = need; pp.Dp = c->Dp;
     hipLaunchKernelGGL(k_repair_patch, dim3((unsigned)std::min<long long>(pass_rows, 2048)), dim3(128), 0, st, pp);
 }
 
@@ -1613,6 +1635,7 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
     pa.part = c->ws().d_part; pa.nvoiced = c->ws().d_nv; pa.e_start = c->ws().d_estart; pa.voiced = gate ? c->ws().d_voiced : nullptr;
     pa.grid = c->d_grid; pa.doa_bin = doa_bin; pa.doa_rad = doa_rad; pa.prob = prob; pa.energy = energy;
     const int gpa = (n_frames + REPAIR_GROUP - 1) / REPAIR_GROUP;
+    const bool mixed = adaptive && cand_mixed(c, lazy, gate);
     if (adaptive) {
         pa.mode = 1; pa.tau = c->tau_en; pa.flags = c->ws().d_flags; pa.groups_per_array = gpa;
         pa.need = c->ws().d_need; pa.list = c->ws().d_list; pa.n_list = c->ws().d_nlist; pa.chunk_from = c->ws().d_chunk_from; pa.last_vchunk = c->ws().d_last_vchunk; pa.stats = c->d_rstats;
@@ -1621,6 +1644,10 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
         if (lazy) { pa.lazy = 1; pa.hist_C_out = c->d_hist_C[c->hist_cur ^ 1]; pa.e_hist_out = c->d_ehist[c->hist_cur ^ 1]; }
         if (hist_valid) { pa.hist_valid = 1; pa.hist_C_in = c->d_hist_C[c->hist_cur]; pa.e_hist_in = c->d_ehist[c->hist_cur]; }
         if (cand_call(c, lazy)) { pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32; pa.dead = c->ws().d_unsure; }   // (dead: the unsure bytes, unused by these contexts)
+        else if (mixed) {
+            pa.umask = c->ws().d_umask; pa.umask_words = c->Dp / 32;
+            pa.need_full = c->ws().d_need_full; pa.list_full = c->ws().d_list_full; pa.n_list_full = c->ws().d_nlist + 3;
+        }
         pa.clist = c->ws().d_chunk_from + c->ws().adapt_chunks; pa.n_clist = c->ws().d_nlist + 1;   // (+ 2: see ScanPickArgs)
         if (c->h_probe && !c->capturing) {
             c->fb_frames_ring[c->fb_calls % FB_RING] = c->adapt_frames_total + (unsigned long long)n_arrays * n_frames;
@@ -1647,7 +1674,8 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pick<PL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3)); \
         hipLaunchKernelGGL((k_scan_pick<PL, MODE>), g3, dim3(std::max(nthr, 512)), smem3, st, pa);   /* 8 waves: the per-frame pick is one wave per frame */ \
     } while (0)
-    if (adaptive) { if (ppl == 2) LAUNCH_PICK(2, 1); else if (ppl == 6) LAUNCH_PICK(6, 1); else LAUNCH_PICK(8, 1); }
+    if (mixed) { if (ppl == 2) LAUNCH_PICK(2, 2); else if (ppl == 6) LAUNCH_PICK(6, 2); else LAUNCH_PICK(8, 2); }
+    else if (adaptive) { if (ppl == 2) LAUNCH_PICK(2, 1); else if (ppl == 6) LAUNCH_PICK(6, 1); else LAUNCH_PICK(8, 1); }
     else { if (ppl == 2) LAUNCH_PICK(2, 0); else if (ppl == 6) LAUNCH_PICK(6, 0); else LAUNCH_PICK(8, 0); }
 #undef LAUNCH_PICK
     DoaFillArgs fa{};
@@ -1699,6 +1727,21 @@ static int localise_impl(mca_hip_ctx *c, const float *pcm, long long array_strid
             pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames;
             if (hist_valid) { pp.hist_C = c->d_hist_C[c->hist_cur]; pp.hist_base = n_arrays * gpa; }
             launch_repair_contraction(c, c->ws(), g0, pass_rows, n_arrays, pp, st);
+        }
+        // two work lists: the units of the frames that take whole rows (tails, unsure rows) through the whole-row kernels
+        for (long long g0 = 0; mixed && g0 < all_groups; g0 += pass_groups) {
+            StftPhatArgs sa{};
+            sa.pcm = pcm; sa.array_stride = array_stride; sa.mic_stride = mic_stride;
+            sa.M = c->M; sa.n_frames = n_frames; sa.frame0 = 0; sa.fpb = REPAIR_GROUP; sa.total_frames = n_frames;
+            sa.window = c->d_window; sa.A = c->ws().d_Ax; sa.Kp = c->Kp; sa.a_row_elems = c->a_row_elems; sa.a_planes = 2;
+            sa.N = c->N; sa.logH = c->logH; sa.kg = c->K; sa.ula = c->ula ? 1 : 0; sa.tw = c->d_tw;
+            sa.list = pa.list_full; sa.n_list = pa.n_list_full; sa.list0 = (int)g0; sa.list_cap = pass_groups; sa.groups_per_array = gpa;
+            const size_t smem1 = ((size_t)c->M * FFT_SCRATCH + TW_WORDS + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
+            if ((rc = launch_stft<_Float16>(c, sa, dim3(std::min(pass_groups, std::max(1, c->kn.list_grid)), 1), smem1, st))) { set_call_planes(c, 1); return rc; }
+            RepairPatchArgs pp{};
+            pp.groups_per_array = gpa;
+            pp.C = c->ws().d_C; pp.c_planes = c->ws().c_planes; pp.c_plane_stride = c->ws().c_plane; pp.n_frames = n_frames;
+            launch_repair_contraction(c, c->ws(), g0, pass_rows, n_arrays, pp, st, pa.list_full, pa.n_list_full, pa.need_full);
         }
         set_call_planes(c, 1);
         const size_t smem4 = (size_t)32 * (c->Dp + 8) * sizeof(float);

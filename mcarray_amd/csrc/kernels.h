@@ -9,7 +9,7 @@ template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat_few(StftP
 __global__ void k_sum_planes(float *C, long long n4, int planes, long long stride);
 __global__ void k_scan_partial(ScanPickArgs p);
 __global__ void k_scan_carry(ScanPickArgs p);
-template <int PL, int MODE> __global__ void k_scan_pick(ScanPickArgs p);   // PL: positions per lane of the peak pick (2 / 6 / 8, by D)
+template <int PL, int MODE> __global__ void k_scan_pick(ScanPickArgs p);   // PL: positions per lane of the peak pick (2 / 6 / 8, by D); MODE 0 plain, 1 adaptive coarse pass, 2 the same with two work lists
 template <int PL> __global__ void k_scan_repick(ScanPickArgs p);
 __global__ void k_repair_patch(RepairPatchArgs p);
 __global__ void k_hist_list(int *list, int *n_list, int *need, int n_units);      // lazy tails (round 5): settle_history

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(512) void k_scan_carry(ScanPickArgs p)
     // grid (arrays, slices of 64 delays): one wave per slice spreads the strided loads over many CUs (17.7 -> 16 us; four waves
     // per slice fetching side by side into LDS with one of them composing measured 19.6 us: the composition wants registers)
     const int tl = threadIdx.x, d = blockIdx.y * blockDim.x + tl, a = blockIdx.x;
-    if (p.mode == 1 && a == 0 && d == 0) { *p.n_list = 0; *p.n_clist = 0; }   // adaptive SRP precision: the repair lists start empty
+    if (p.mode == 1 && a == 0 && d == 0) { *p.n_list = 0; *p.n_clist = 0; if (p.n_list_full) *p.n_list_full = 0; }   // adaptive SRP precision: the repair lists start empty
     if (tl == 0) s_lv = -1;
     for (int n = tl; n <= SCAN_CHUNK; n += blockDim.x) {
         float g = 1.f;
@@ -639,13 +639,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     __shared__ int s_bin[SCAN_SUB * MCA_MAX_SOURCES];
     __shared__ float s_val[SCAN_SUB * MCA_MAX_SOURCES];
     __shared__ unsigned s_flagmask;                                     // MODE 1: the flags of a batch of SCAN_SUB (<= 32) frames
-    __shared__ unsigned s_cm[MODE == 1 ? 10 : 1][CAND_WORDS_MAX];       // MODE 1: the candidate columns of the flagged frame a wave is planning
+    __shared__ unsigned s_cm[MODE >= 1 ? 10 : 1][CAND_WORDS_MAX];       // MODE 1: the candidate columns of the flagged frame a wave is planning
     // MODE 1, candidate columns without the gate: the plan of the whole batch is put together in LDS -- the 12 repair units a chunk's frames
     // can need (its own 8 and the 4 before it), their column masks, the earliest row -- and goes to the device-side lists in ONE round
     constexpr int PLAN_UNITS = (SCAN_CHUNK + REPAIR_WARM) / REPAIR_GROUP;
-    __shared__ unsigned s_um[MODE == 1 ? PLAN_UNITS : 1][CAND_WORDS_MAX];
+    __shared__ unsigned s_um[MODE >= 1 ? PLAN_UNITS : 1][CAND_WORDS_MAX];
     __shared__ unsigned s_uneed, s_ncol, s_nall;
-    __shared__ int s_umin, s_ue[MODE == 1 ? PLAN_UNITS : 1];
+    __shared__ unsigned s_uneed_full;                                   // MODE 2: the units of the frames that want whole rows (ScanPickArgs::list_full)
+    __shared__ int s_umin, s_ue[MODE >= 1 ? PLAN_UNITS : 1];
     static_assert(REPAIR_WARM % REPAIR_GROUP == 0 && SCAN_CHUNK % REPAIR_GROUP == 0, "the units of a chunk's plan are whole");
     static_assert(SCAN_SUB <= 32, "one 32-bit mask per batch");
     static_assert(SCAN_CHUNK <= 64, "one ballot per chunk");
@@ -685,11 +686,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     } else if (act) {
         E = p.e_start[((long long)a * p.n_chunks + blockIdx.x) * D + d];
     }
-    const int last_vchunk = p.lookback > 0 ? p.n_chunks - 1 : (MODE == 1 ? p.last_vchunk[a] : -1);
-    if (MODE == 1 && p.lookback > 0 && (int)blockIdx.x == p.n_chunks - 1 && d == 0) p.last_vchunk[a] = p.n_chunks - 1;
+    const int last_vchunk = p.lookback > 0 ? p.n_chunks - 1 : (MODE >= 1 ? p.last_vchunk[a] : -1);
+    if (MODE >= 1 && p.lookback > 0 && (int)blockIdx.x == p.n_chunks - 1 && d == 0) p.last_vchunk[a] = p.n_chunks - 1;
     // MODE 1: the array's last frame that advances the recursion (this chunk holds it) is always repaired
     int t_force = -1;
-    if (MODE == 1 && (int)blockIdx.x == last_vchunk && !p.lazy) {        // (lazy tails: the next call repairs this call's last rows if it needs them)
+    if (MODE >= 1 && (int)blockIdx.x == last_vchunk && !p.lazy) {        // (lazy tails: the next call repairs this call's last rows if it needs them)
         const int u = t_start + lane;
         const unsigned long long m = __ballot(u < t_end && (!vc || vc[u] != 0));
         if (m) t_force = t_start + 63 - __clzll((long long)m);
@@ -697,9 +698,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     for (int ts = t_start; ts < t_end; ts += SCAN_SUB) {
         const int te = min(ts + SCAN_SUB, t_end);
         if (d == 0) s_flagmask = 0u;
-        if (MODE == 1 && p.umask && !vc) {
+        if (MODE >= 1 && p.umask && !vc) {
             if (d < PLAN_UNITS * CAND_WORDS_MAX) (&s_um[0][0])[d] = 0u;
-            if (d == 0) { s_uneed = 0u; s_ncol = 0u; s_nall = 0u; s_umin = 0x7fffffff; }
+            if (d == 0) { s_uneed = 0u; s_ncol = 0u; s_nall = 0u; s_umin = 0x7fffffff; if (MODE == 2) s_uneed_full = 0u; }
         }
         // the batch's frames that passed the power gate (all without it), one bit each: every wave works the mask out for itself
         // from one byte per lane (a load of vc[t] inside the recursion made every step of it a round trip to memory)
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         // MODE 1: frames the coarse analysis marked unsure (StftPhatArgs::unsure) are repaired with their six successors (0.8^7 of their
         // error is left after those): bit i of um = frame ts - 6 + i
         unsigned long long um = 0;
-        if (MODE == 1 && p.unsure) {
+        if (MODE >= 1 && p.unsure) {
             const int u = ts - 6 + lane;
             um = __ballot(lane < SCAN_SUB + 6 && u >= 0 && u < te && p.unsure[(long long)a * p.n_frames + u] != 0);
         }
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                         if ((vmask >> (t - ts)) & 1u) E = iir_step(mu, E, omu, c8[i]);   // :134-140
                         if (p.energy) p.energy[((long long)a * p.n_frames + t) * D + d] = E;
                         sEn[(t - ts) * Dl + d] = normalised_energy(E, mn, nd, nr);   // :155-156
-                        if (MODE == 1 && p.lazy) {
+                        if (MODE >= 1 && p.lazy) {
                             // lazy tails: the coarse rows of the call's last HIST_FRAMES frames and the energies in front of them
                             const int j = t - (p.n_frames - HIST_FRAMES);
                             if (j >= 0) p.hist_C_out[((long long)a * HIST_FRAMES + j) * p.Dp + d] = c8[i];
@@ -750,9 +751,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 #ifdef MCA_ABL_PICK      /* measurement only: wrong results */
             const bool sens = false; if (lane < S) { s_bin[tl * MCA_MAX_SOURCES + lane] = 5; s_val[tl * MCA_MAX_SOURCES + lane] = sEn[tl * Dl + lane]; }
 #else
-            const bool sens = wave_pick_pl<MODE == 1, PL>(sEn + tl * Dl, D, S, p.tau, s_bin + tl * MCA_MAX_SOURCES, s_val + tl * MCA_MAX_SOURCES, lane);
+            const bool sens = wave_pick_pl<MODE >= 1, PL>(sEn + tl * Dl, D, S, p.tau, s_bin + tl * MCA_MAX_SOURCES, s_val + tl * MCA_MAX_SOURCES, lane);
 #endif
-            if (MODE == 1 && lane == 0 && (sens || t == t_force || ((um >> tl) & 0x7full) != 0)) atomicOr(&s_flagmask, 1u << tl);
+            if (MODE >= 1 && lane == 0 && (sens || t == t_force || ((um >> tl) & 0x7full) != 0)) atomicOr(&s_flagmask, 1u << tl);
         }
         __syncthreads();
         // the batch's outputs, one thread per (frame, source)
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                 if (p.prob) p.prob[o] = s_val[tl * MCA_MAX_SOURCES + sidx];
             }
         }
-        if (MODE == 1) {
+        if (MODE >= 1) {
             const unsigned fm = s_flagmask;
             if (d < te - ts) p.flags[(long long)a * p.n_frames + ts + d] = (fm >> d) & 1u;
             // plan the repair of the flagged frames, one wave per frame
@@ -778,12 +779,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                 for (unsigned rest = fm; rest; rest &= rest - 1, ++k) {
                     if (k % nwaves != wave) continue;
                     const int t = ts + __ffs((int)rest) - 1;
-                    const bool all = wave_candidates<PL>(sEn + (t - ts) * Dl, D, p.tau, t == t_force || ((um >> (t - ts)) & 0x7full) != 0, s_cm[wave], p.umask_words, lane);
+                    const bool want_all = t == t_force || ((um >> (t - ts)) & 0x7full) != 0;
+                    // MODE 2 (two work lists: contexts that flag whole rows by construction -- eager tails, unsure rows): a frame that takes every
+                    // column goes onto the WHOLE-ROW list (k_srp_gemm_repair + k_repair_patch), the others onto the candidate list as in MODE 1
+                    bool all = MODE == 2 && want_all;
+                    if (!all) all = wave_candidates<PL>(sEn + (t - ts) * Dl, D, p.tau, want_all, s_cm[wave], p.umask_words, lane);
+                    const bool to_full = MODE == 2 && all;
                     const int r_lo = max(t - REPAIR_WARM, u_lo);
                     // a unit is needed if one of the frame's rows in it is not a frame of exact zeros (those are zero in both maps)
                     const int r = r_lo + lane;
-                    if (r <= t && !(p.dead && r >= 0 && p.dead[(long long)a * p.n_frames + r] != 0)) atomicOr(&s_uneed, 1u << ((r - r_first) >> 2));
-                    if (lane < p.umask_words) {
+                    if (r <= t && !(p.dead && r >= 0 && p.dead[(long long)a * p.n_frames + r] != 0)) atomicOr(to_full ? &s_uneed_full : &s_uneed, 1u << ((r - r_first) >> 2));
+                    if (!to_full && lane < p.umask_words) {
                         const unsigned m = s_cm[wave][lane];
                         if (m)
 #pragma nounroll
@@ -791,8 +797,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                     }
                     if (lane == 0) {
                         int nc = 0;
+                        if (!to_full) {
 #pragma nounroll
-                        for (int w = 0; w < p.umask_words; ++w) nc += __popc(s_cm[wave][w]);
+                            for (int w = 0; w < p.umask_words; ++w) nc += __popc(s_cm[wave][w]);
+                        }
                         atomicAdd(&s_ncol, (unsigned)nc);
                         if (all) atomicAdd(&s_nall, 1u);
                         atomicMin(&s_umin, r_lo);
@@ -807,6 +815,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                         s_ue[d] = e;
                         if (atomicExch(&p.need[e], 1) == 0) {
                             p.list[atomicAdd(p.n_list, 1)] = e;
+                            atomicAdd(&p.stats[1], 1ull);
+                        }
+                    }
+                    if (MODE == 2 && d >= 128 && d < 128 + PLAN_UNITS && ((s_uneed_full >> (d - 128)) & 1u)) {      // (a third wave)
+                        const int r0 = r_first + REPAIR_GROUP * (d - 128);
+                        const int e = r0 >= 0 ? a * p.groups_per_array + r0 / REPAIR_GROUP : p.hist_base + a * HIST_UNITS + (HIST_FRAMES + r0) / REPAIR_GROUP;
+                        if (atomicExch(&p.need_full[e], 1) == 0) {
+                            p.list_full[atomicAdd(p.n_list_full, 1)] = e;
                             atomicAdd(&p.stats[1], 1ull);
                         }
                     }
@@ -870,6 +886,9 @@ template __global__ void k_scan_pick<8, 0>(ScanPickArgs);
 template __global__ void k_scan_pick<2, 1>(ScanPickArgs);
 template __global__ void k_scan_pick<6, 1>(ScanPickArgs);
 template __global__ void k_scan_pick<8, 1>(ScanPickArgs);
+template __global__ void k_scan_pick<2, 2>(ScanPickArgs);
+template __global__ void k_scan_pick<6, 2>(ScanPickArgs);
+template __global__ void k_scan_pick<8, 2>(ScanPickArgs);
 
 // --------------------------------------------------------------------------------------
 // k_scan_repick / k_repair_patch -- adaptive SRP precision: the second pick of the flagged frames on the exact rows
@@ -1003,7 +1022,7 @@ __global__ __launch_bounds__(512) void k_scan_repick(ScanPickArgs p)
     const int n_part = min((int)gridDim.x, n_listed);
     if (d == 0 && ((int)blockIdx.x < n_part || (n_part == 0 && blockIdx.x == 0))) {
         __threadfence();
-        if (atomicAdd(p.n_clist + 1, 1) >= max(n_part, 1) - 1) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; }
+        if (atomicAdd(p.n_clist + 1, 1) >= max(n_part, 1) - 1) { *p.n_list = 0; *p.n_clist = 0; p.n_clist[1] = 0; if (p.n_list_full) *p.n_list_full = 0; }
     }
 }
 template __global__ void k_scan_repick<2>(ScanPickArgs);

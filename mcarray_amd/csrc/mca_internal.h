@@ -227,6 +227,10 @@ struct ScanPickArgs {
     // per unit (k_scan_pick ORs a flagged frame's candidate columns into every unit it lists; k_srp_cand -- one workgroup per unit -- takes
     // and clears them and releases the unit's test-and-set word).  NULL: whole rows (k_srp_gemm_repair + k_repair_patch).
     unsigned *umask; int umask_words;
+    // two work lists (round 6; k_scan_pick<PL, 2>: contexts whose flagged frames include whole rows by construction -- eager tails, the
+    // 16-microphone unsure marks): a frame that takes every column lists its units HERE (test-and-set words, list, length; walked by a
+    // second list-mode analysis + k_srp_gemm_repair + k_repair_patch), the others on `list` with their column masks.  NULL: one list.
+    int *need_full, *list_full, *n_list_full;
 };
 
 // The repair contraction runs on however many rows the coarse pass listed (a device-side count): the K range is what

@@ -56,6 +56,46 @@ def test_adaptive_matches_oracle(force_small, xs, step, S, thetas):
     ctx.close()
 
 
+def test_sixteen_microphones_two_work_lists_match_the_oracle(force_small, monkeypatch):
+    """Round 6 (k_scan_pick<PL, 2>): a 16-microphone context sends the flagged frames that take whole rows by construction (the last
+    frame of every array and call: eager tails; unsure rows) to k_srp_gemm_repair + k_repair_patch and every other flagged frame to
+    k_srp_cand at its candidate columns -- with MCA_HIP_ADAPT_CAND=1 only: the mode measured no faster than whole rows for every flagged
+    frame (profiles/r06_m16_two_lists_negative.log) and is not what the policy picks.  Two equal sources per array and a wide decision
+    margin (many content flags) in two calls, against the oracle; both kinds of frames occurred; the whole-row form (MCA_HIP_ADAPT_CAND=0)
+    flags the same frames."""
+    fs, N, F, A, cut = 48000, 1024, 260, 3, 120
+    xs = synth.ULA16
+    monkeypatch.setenv("MCA_HIP_ADAPT_TAU_SCALE", "40")
+    # two sources of equal strength per array (their peaks trade places from frame to frame) and a wide decision margin: content flags
+    pcm = np.stack([(synth.noise_source_stream(xs, np.deg2rad(th), fs, (F + 1) * 512, 950 + i, snr_db=10.0) * 0.5 +
+                     synth.noise_source_stream(xs, np.deg2rad(th2), fs, (F + 1) * 512, 960 + i, snr_db=10.0) * 0.5)
+                    for i, (th, th2) in enumerate(((12.0, -30.0), (-47.0, 25.0), (66.0, -5.0)))]).astype(np.float32)
+    o = [po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, 1.0, want_map=True) for a in range(A)]
+    from parity_helpers import classify_bins, assert_audio_where_bins_agree
+    res = {}
+    for cand in ("1", "0"):
+        monkeypatch.setenv("MCA_HIP_ADAPT_CAND", cand)
+        ctx = api.Context(fs, xs, N, 1.0, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+        ctx.reset_timing()
+        ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * 512], want_energy=True)
+        rb = ctx.process_frames_host(pcm[:, :, cut * 512:], want_energy=True)
+        r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out")}
+        res[cand] = (r, ctx.repair_stats(), ctx.repair_columns())
+        for a in range(A):
+            ties, bad = classify_bins(r["bin"][a], o[a]["bin"], o[a]["energy"], ctx.P)
+            assert not bad, (cand, a, bad[:5])
+            assert len(ties) <= 12
+            assert np.abs(r["energy"][a] - o[a]["energy"]).max() <= 2e-4 * np.abs(o[a]["energy"]).max()
+            assert_audio_where_bins_agree(r["out"][a][:1], o[a]["out"], r["bin"][a], o[a]["bin"], 512)
+        ctx.close()
+    st, cols = res["1"][1], res["1"][2]
+    assert cols["whole_row_frames"] >= 2 * A, cols               # the last frame of every array and call at least
+    assert st["flagged"] > cols["whole_row_frames"] + 10, (st, cols)   # ... and content flags that took the candidate kernel
+    assert 0 < cols["candidate_columns"] <= 60 * (st["flagged"] - cols["whole_row_frames"]), (st, cols)
+    assert res["0"][2] == {"candidate_columns": 0, "whole_row_frames": 0}
+    assert res["0"][1]["flagged"] == st["flagged"]
+
+
 def test_adaptive_backs_off_to_fp16x3_while_most_rows_need_the_repair(force_small, monkeypatch):
     """Noise only: every pick is a near tie, every frame is flagged, and coarse + repair of everything costs twice the direct
     exact pass.  The last kernel of an adaptive call reports its totals through page-locked memory; the call TWO calls later consumes
