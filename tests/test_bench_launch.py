@@ -65,3 +65,30 @@ def test_bench_single_rank_rccl_exchange():
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["exchange"]["backend"] == "nccl" and r["exchange"]["gather_audio"] is True
+
+
+def test_the_printed_line_is_compact_and_complete():
+    """The driver reads the END of bench.py's stdout: the line it prints must stay well under 6 KB and still carry every field
+    of the contract, `roofline` (with `traffic`) and `cpu_baseline`, and the three other BASELINE configs measured in the same run.  Checked on
+    the committed full record of the driver's command (profiles/r06_bench_driver_cmd_detail.json) -- no GPU needed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_driver_cmd_detail.json")))
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["vs_baseline"] is None and line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    assert "model" not in line["config"] and line["config"]["workload"].startswith("BASELINE configs[2]")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["bound"] == "hbm" and abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    for k in ("single_stream_4096", "das_single_stream", "mvdr_256x64"):
+        assert line["config"][k]["value" if k != "das_single_stream" else "offline_any_angle"], k
+    gemm = [e for e in line["roofline_by_kernel"] if e["kernel"] == "k_srp_gemm"][0]
+    assert 0 < gemm["mfma_pipe_frac"] < gemm["frac"] < 1
