@@ -122,18 +122,20 @@ def compact_line(line):
     return out
 
 
-def synth_batch(xs, seeds, n_frames, device, noise=0.01):
+def synth_batch(xs, seeds, n_frames, device, noise=0.01, hop=None, fs=None):
     """Far-field white source per array + 20 dB sensor noise, generated on the GPU.
-    One seed per array, derived from the array's GLOBAL index, so its data does not depend on the rank count."""
+    One seed per array, derived from the array's GLOBAL index, so its data does not depend on the rank count.
+    (hop, fs: other frame lengths / rates for tools/bench_shapes.py; the bench itself runs the module's.)"""
     n_arrays, n_mics = len(seeds), len(xs)
-    L = (n_frames + 1) * HOP
+    hop, fs = hop or HOP, fs or FS
+    L = (n_frames + 1) * hop
     xs_t = torch.tensor(xs, device=device, dtype=torch.float64)
     theta = torch.empty(n_arrays, device=device, dtype=torch.float64)
     # channel rows are ROW_PAD floats longer than their (F + 1) * hop samples (the C ABI takes the strides): a row pitch of a power
     # of two plus a little -- 257 half frames = 2^19 + 2^11 bytes at 128 arrays x 256 frames -- lines the loads of all resident
     # waves up on the same few HBM channels (k_beamform_wave 0.33 instead of 0.295 ms; HISTORY.md)
     out = torch.zeros(n_arrays, n_mics, L + ROW_PAD, device=device, dtype=torch.float32)
-    f = torch.fft.rfftfreq(L, d=1.0 / FS).to(device=device, dtype=torch.float64)
+    f = torch.fft.rfftfreq(L, d=1.0 / fs).to(device=device, dtype=torch.float64)
     for a in range(n_arrays):   # one array at a time keeps the fp64 temporaries small
         gen = torch.Generator(device=device).manual_seed(seeds[a])
         theta[a] = (torch.rand(1, device=device, dtype=torch.float64, generator=gen)[0] * 160.0 - 80.0) * (np.pi / 180.0)

@@ -61,7 +61,7 @@ struct Knobs {
     // measurement only (-DMCA_MEASURE)
     bool gemm_ks2 = false;             // MCA_HIP_GEMM_KS2: two K halves for 16 384 ... 32 767 rows (round 4) instead of four quarters
     bool no_merge = false, stft_wg = false, bf_ola = false, bf_occ2 = false, no_fused_partial = false, gemm_v1 = false, gemm_v2 = false,
-         v1_nosplit = false, no_n512 = false, no_sub2 = false, no_n2048 = false;   // (no_n2048: MCA_HIP_NO_N2048, the any-length kernels at 2048-sample frames: A/B and parity of both)
+         v1_nosplit = false, no_n512 = false, no_sub2 = false, no_n2048 = false, no_adapt_other_n = false;   // (no_n2048: MCA_HIP_NO_N2048, the any-length kernels at 2048-sample frames: A/B and parity of both)
     int spw_fpw = 0, bfw_ft = 0, bfw_abl = 0, bfw_var = 15, repair_ksplit = 0, v2_min_rows = 0, repick_grid = 256, list_grid = 512;
     bool dyn = false;                  // MCA_HIP_DYN: k_stft_phat_wave takes its runs off a device-side queue (round 5: measured slower, profiles/r05_run_queue_negative.log)
     int spw_waves = 4;                 // MCA_HIP_SPW_WAVES: 8 = the regular launches of k_stft_phat_wave as one workgroup of eight waves per CU
@@ -303,6 +303,7 @@ Knobs read_knobs(const mca_hip_config &cfg)
     k.no_n512 = measure_env("MCA_HIP_NO_N512") != nullptr;
     k.no_n2048 = env_str("MCA_HIP_NO_N2048") != nullptr;
     k.no_sub2 = measure_env("MCA_HIP_NO_SUB2") != nullptr;
+    k.no_adapt_other_n = measure_env("MCA_HIP_NO_ADAPT_OTHER_N") != nullptr;     // (A/B: 512- and 2048-sample frames as round 6 began, ADAPTIVE = FP16X3 there)
     k.spw_fpw = (int)geti(measure_env("MCA_HIP_SPW_FPW"), 0);
     k.bfw_ft = (int)geti(measure_env("MCA_HIP_BFW_FT"), 0);
     k.bfw_abl = (int)geti(measure_env("MCA_HIP_BFW_ABL"), 0);
@@ -597,7 +598,7 @@ bool adaptive_shape(const mca_hip_ctx *c, int n_arrays, int n_frames)
     // (more than one source: the S-th pick is a weak peak more often than not -- a second source, or noise when fewer than S
     // are active -- and a third to all of the frames are flagged: 8 x 4096 frames with S = 2 / 3 / 4 real sources spend 0.89 / 1.60 /
     // 1.76 ms in the repair pass, more than the 0.3 ms the coarse contraction saves; MCA_HIP_ADAPT_MAX_SOURCES lifts the limit)
-    return c->prec == MCA_HIP_SRP_ADAPTIVE && !c->generic && !c->n512 && c->N == FFT_N && c->M > 2 && c->S <= c->kn.adapt_max_sources &&
+    return c->prec == MCA_HIP_SRP_ADAPTIVE && ((!c->generic && !c->n512 && c->N == FFT_N) || ((c->n2048 || c->n512) && c->M <= 8 && !c->kn.no_adapt_other_n)) && c->M > 2 && c->S <= c->kn.adapt_max_sources &&
            rows >= c->kn.adapt_min_rows && n_frames >= 2 * SCAN_CHUNK;
 }
 bool adaptive_applies(const mca_hip_ctx *c, int n_arrays, int n_frames) { return adaptive_shape(c, n_arrays, n_frames) && !c->adapt_suspended; }
@@ -813,10 +814,64 @@ static bool wave16_applies(const mca_hip_ctx *c)
     return c->M == 16 && c->ula && !c->generic && c->cfg.gcc_weighting != MCA_HIP_GCC_NONE && !c->kn.stft_wg;
 }
 
+// 512-sample frames, up to 8 microphones: two frames of up to 8 channels per pass on the wave-level transform (k_stft_phat_512).
+// grid.x = 0: one run of frames per workgroup, sized here; list mode (a.list): grid as given, REPAIR_GROUP frames per unit.
+template <typename OutT>
+int launch_stft_512(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, hipStream_t st)
+{
+    StftPhatArgs sa = a;
+    if (!sa.list) {
+        sa.fpb = 8;
+        while (sa.fpb > 2 && (long long)grid.y * ((sa.n_frames + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
+        grid.x = (sa.n_frames + sa.fpb - 1) / sa.fpb;
+    }
+    const size_t smem5 = ((size_t)2 * 8 * 258 + 8 * FFT_SCRATCH + TW_WIN + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
+#define L512(MT, U)                                                                                                       \
+    do {                                                                                                                  \
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_512<MT, U, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5)); \
+        hipLaunchKernelGGL((k_stft_phat_512<MT, U, OutT>), grid, dim3(512), smem5, st, sa);                               \
+    } while (0)
+    if (c->M == 8 && c->ula) L512(8, true); else if (c->M == 8) L512(8, false);
+    else if (c->M == 4 && c->ula) L512(4, true); else if (c->M == 4) L512(4, false);
+    else if (c->ula) L512(0, true); else L512(0, false);
+#undef L512
+    HIP_TRY(c, hipGetLastError());
+    return MCA_HIP_OK;
+}
+
+// 2048-sample frames, 3 .. 8 microphones: a wave per channel on the 1024-point complex transform + split, spectra in LDS, thread = two bins
+// (k_stft_phat_2048).  grid.x = 0: one run of frames per workgroup, sized here; list mode (a.list): grid as given, REPAIR_GROUP frames per unit.
+static bool n2048_analysis(const mca_hip_ctx *c) { return c->n2048 && c->M > 2 && c->M <= 8; }
+template <typename OutT>
+int launch_stft_2048(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, hipStream_t st)
+{
+    StftPhatArgs sa = a;
+    const int fp = c->M == 4 ? 2 : 1, mr = c->M == 4 ? 4 : 8;
+    if (!sa.list) {
+        sa.fpb = 16;
+        while (sa.fpb > 2 && (long long)grid.y * ((sa.n_frames + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
+        grid.x = (sa.n_frames + sa.fpb - 1) / sa.fpb;
+    }
+    const size_t smem6 = ((size_t)fp * mr * 1026 + F1K_TWORDS + 8 * F1K_SCRATCH + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
+#define L2048(MT, U)                                                                                                      \
+    do {                                                                                                                  \
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_2048<MT, U, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem6)); \
+        hipLaunchKernelGGL((k_stft_phat_2048<MT, U, OutT>), grid, dim3(512), smem6, st, sa);                              \
+    } while (0)
+    if (c->M == 8 && c->ula) L2048(8, true); else if (c->M == 8) L2048(8, false);
+    else if (c->M == 4 && c->ula) L2048(4, true); else if (c->M == 4) L2048(4, false);
+    else if (c->ula) L2048(0, true); else L2048(0, false);
+#undef L2048
+    HIP_TRY(c, hipGetLastError());
+    return MCA_HIP_OK;
+}
+
 template <typename OutT>
 int launch_stft(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, size_t smem, hipStream_t st)
 {
     const int M = c->M; const bool ula = c->ula;
+    if (n2048_analysis(c)) return launch_stft_2048<OutT>(c, a, grid, st);      // (the list-mode launches of the repair pass come through here)
+    if (c->n512) return launch_stft_512<OutT>(c, a, grid, st);
     // a 16-microphone uniform linear array, one fp16 operand plane (the ADAPTIVE coarse pass, plain FP16): the wave-per-run kernel
     // with its whitened spectra packed to fp16 (k_stft_phat_wave16); the exact rows of such an array stay on k_stft_phat<16>
     if constexpr (sizeof(OutT) == 2) {
@@ -1383,26 +1438,7 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
         if (c->lazy_now) sa.hist_out = c->d_hist_pcm[c->hist_cur ^ 1];       // lazy tails: the call's last frames of PCM stay behind
         time_begin(c, MCA_HIP_K_STFT_PHAT, st);
         if (c->n512) {
-            // 512-sample frames: two frames of up to 8 channels per pass on the wave-level transform
-            sa.fpb = 8;
-            while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
-            const size_t smem5 = ((size_t)2 * 8 * 258 + 8 * FFT_SCRATCH + TW_WIN + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
-            dim3 g5((nf + sa.fpb - 1) / sa.fpb, n_arrays);
-#define L512(MT, U, T)                                                                                                    \
-            do {                                                                                                          \
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_512<MT, U, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5)); \
-                hipLaunchKernelGGL((k_stft_phat_512<MT, U, T>), g5, dim3(512), smem5, st, sa);                            \
-            } while (0)
-#define L512T(T)                                                                                                          \
-            do {                                                                                                          \
-                if (c->M == 8 && c->ula) L512(8, true, T); else if (c->M == 8) L512(8, false, T);                         \
-                else if (c->M == 4 && c->ula) L512(4, true, T); else if (c->M == 4) L512(4, false, T);                    \
-                else if (c->ula) L512(0, true, T); else L512(0, false, T);                                                \
-            } while (0)
-            if (c->prec == MCA_HIP_SRP_FP32) L512T(float); else L512T(_Float16);
-#undef L512T
-#undef L512
-            rc = MCA_HIP_OK;
+            rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft_512<float>(c, sa, dim3(0, n_arrays), st) : launch_stft_512<_Float16>(c, sa, dim3(0, n_arrays), st);
         } else if ((c->N == 4096 || c->N == 2048) && c->M == 2 && c->stream_ok && !c->kn.no_sub2) {
             // two microphones at 2048- / 4096-sample frames (FreqGCC at 32 / 44.1 / 48 kHz): 512-sample sub-sequences per channel
             sa.fpb = 8;
@@ -1418,28 +1454,8 @@ static int run_correlation_map(mca_hip_ctx *c, const float *pcm, long long array
             else { if (c->prec == MCA_HIP_SRP_FP32) LSUB(4, float); else LSUB(4, _Float16); }
 #undef LSUB
             rc = MCA_HIP_OK;
-        } else if (c->n2048 && c->M > 2 && c->M <= 8) {
-            // 2048-sample frames: a wave per channel on the 1024-point complex transform + split, spectra in LDS, thread = two bins
-            const int fp = c->M == 4 ? 2 : 1, mr = c->M == 4 ? 4 : 8;
-            sa.fpb = 16;
-            while (sa.fpb > 2 && (long long)n_arrays * ((nf + sa.fpb - 1) / sa.fpb) < 512) sa.fpb >>= 1;
-            const size_t smem6 = ((size_t)fp * mr * 1026 + F1K_TWORDS + 8 * F1K_SCRATCH + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
-            dim3 g6((nf + sa.fpb - 1) / sa.fpb, n_arrays);
-#define L2048(MT, U, T)                                                                                                   \
-            do {                                                                                                          \
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_2048<MT, U, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem6)); \
-                hipLaunchKernelGGL((k_stft_phat_2048<MT, U, T>), g6, dim3(512), smem6, st, sa);                           \
-            } while (0)
-#define L2048T(T)                                                                                                         \
-            do {                                                                                                          \
-                if (c->M == 8 && c->ula) L2048(8, true, T); else if (c->M == 8) L2048(8, false, T);                       \
-                else if (c->M == 4 && c->ula) L2048(4, true, T); else if (c->M == 4) L2048(4, false, T);                  \
-                else if (c->ula) L2048(0, true, T); else L2048(0, false, T);                                              \
-            } while (0)
-            if (c->prec == MCA_HIP_SRP_FP32) L2048T(float); else L2048T(_Float16);
-#undef L2048T
-#undef L2048
-            rc = MCA_HIP_OK;
+        } else if (n2048_analysis(c)) {
+            rc = c->prec == MCA_HIP_SRP_FP32 ? launch_stft_2048<float>(c, sa, dim3(0, n_arrays), st) : launch_stft_2048<_Float16>(c, sa, dim3(0, n_arrays), st);
         } else if (c->generic) {
             const size_t smem1 = (size_t)c->M * (c->H + 1) * sizeof(float2) + 16;
 #define GEN_LAUNCH(K)                                                                                                     \

@@ -91,8 +91,6 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
     float2 *nyq = scr + 8 * F1K_SCRATCH;                                  // [fpb][M]
     float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);             // [fpb][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int a = blockIdx.y;
-    const int f_begin = blockIdx.x * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
     const int slot = MT == 4 ? wave >> 2 : 0, ch = MT == 4 ? wave & 3 : wave;
     const bool fft_wave = ch < M;
     f1k_table_init(tab, tid, 512);
@@ -104,6 +102,20 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
 #pragma unroll
     for (int i = 0; i < 16; ++i) win[i] = reinterpret_cast<const float2 *>(p.window)[lane + 64 * i];     // (w[2n], w[2n+1]), n = lane + 64 i
     for (int e = tid; e < p.fpb * 8; e += 512) spow[e] = 0.f;
+    // list mode (the repair pass of the adaptive SRP precision, as in k_stft_phat): the workgroups walk the listed units of REPAIR_GROUP
+    // frames; unit number li - list0 of the pass writes the A rows (li - list0) * REPAIR_GROUP ...  Otherwise one run of fpb frames.
+    const int li_end = p.list ? min(*p.n_list, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
+    for (int li = p.list ? p.list0 + (int)blockIdx.x : 0; li < li_end; li += li_step) {
+    int a = blockIdx.y;
+    int f_begin = blockIdx.x * p.fpb;
+    long long row_base = (long long)a * p.n_frames;                       // A row of frame f = row_base + f
+    if (p.list) {
+        const int e = p.list[li];
+        a = e / p.groups_per_array;
+        f_begin = (e - a * p.groups_per_array) * REPAIR_GROUP;
+        row_base = (long long)(li - p.list0) * REPAIR_GROUP - f_begin;
+    }
+    const int f_end = min(f_begin + p.fpb, p.n_frames);
     __syncthreads();
 
     // cur[i] = (x[2n], x[2n+1]) of the wave's frame, n = lane + 64 i; the frames of a slot are FP apart
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
             const int fr = f + sl;
             if (fr < f_end) {
                 const float2 *xs = spec + sl * MR * ROW2K;
-                OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + fr) * (long long)p.a_row_elems;
+                OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + fr) * (long long)p.a_row_elems;
                 if (tid < M) nyq[(fr - f_begin) * M + tid] = whiten(xs[tid * ROW2K + H2K]);
                 if (p.power) {
                     // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
@@ -183,9 +195,10 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
         p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = (((((((s[0] + s[1]) + s[2]) + s[3]) + s[4]) + s[5]) + s[6]) + s[7]) / ((float)N2K * (float)N2K) / (float)M;
     }
     if (tid < f_end - f_begin) {
-        OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
+        OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f_begin + tid) * (long long)p.a_row_elems;
         pair_stage<MT, ULA, false, OutT>(nyq + tid * M, 1, M, arow, p, H2K, K2K);
     }
+    }                                                                     // (list mode: the barrier at the top of the next unit keeps nyq until every thread is through)
 }
 
 #define INST_2048(MT, ULA, T) template __global__ void k_stft_phat_2048<MT, ULA, T>(StftPhatArgs);

@@ -1358,17 +1358,29 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
     const int M = MT > 0 ? MT : p.M;
     float *spow = reinterpret_cast<float *>(nyq + p.fpb * M);               // [fpb][8] per wave (4 waves per frame: the other 4 slots stay zero)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int a = blockIdx.y;
-    const int f_begin = blockIdx.x * p.fpb, f_end = min(f_begin + p.fpb, p.n_frames);
     fft_table_init(tab, nullptr, tid, 512);
     for (int e = tid; e < p.fpb * 8; e += 512) spow[e] = 0.f;
     float wreg[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) wreg[r] = 0.5f * p.window[lane + 64 * r];
-    __syncthreads();
     FftTw tw{tab};
-    const float *base = p.pcm + (long long)a * p.array_stride;
     const int slot = wave >> 2, c0 = 2 * (wave & 3);
+    // list mode (the repair pass of the adaptive SRP precision, as in k_stft_phat): the workgroups walk the listed units of REPAIR_GROUP
+    // frames; unit number li - list0 of the pass writes the A rows (li - list0) * REPAIR_GROUP ...  Otherwise one run of fpb frames.
+    const int li_end = p.list ? min(*p.n_list, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
+    for (int li = p.list ? p.list0 + (int)blockIdx.x : 0; li < li_end; li += li_step) {
+    int a = blockIdx.y;
+    int f_begin = blockIdx.x * p.fpb;
+    long long row_base = (long long)a * p.n_frames;                         // A row of frame f = row_base + f
+    if (p.list) {
+        const int e = p.list[li];
+        a = e / p.groups_per_array;
+        f_begin = (e - a * p.groups_per_array) * REPAIR_GROUP;
+        row_base = (long long)(li - p.list0) * REPAIR_GROUP - f_begin;
+    }
+    const int f_end = min(f_begin + p.fpb, p.n_frames);
+    __syncthreads();
+    const float *base = p.pcm + (long long)a * p.array_stride;
 
     for (int f = f_begin; f < f_end; f += 2) {
         const int nfr = min(2, f_end - f);
@@ -1383,7 +1395,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
         const int fi = tid >> 8, k = tid & 255;
         if (fi < nfr) {
             float2 *xs = spec + fi * 8 * N512_ROW;
-            OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f + fi) * (long long)p.a_row_elems;
+            OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f + fi) * (long long)p.a_row_elems;
             if (k < M) nyq[(f + fi - f_begin) * M + k] = whiten(xs[k * N512_ROW + N512_H]);
             if (p.power) {
                 // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
@@ -1404,9 +1416,10 @@ __global__ __launch_bounds__(512) void k_stft_phat_512(StftPhatArgs p)
     if (p.power && tid < f_end - f_begin)
         p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = sum8(spow + tid * 8) / (512.f * 512.f) / (float)M;
     if (tid < f_end - f_begin) {
-        OutT *arow = reinterpret_cast<OutT *>(p.A) + ((long long)a * p.n_frames + f_begin + tid) * (long long)p.a_row_elems;
+        OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f_begin + tid) * (long long)p.a_row_elems;
         pair_stage<MT, ULA, false, OutT>(nyq + tid * M, 1, M, arow, p, N512_H, N512_K);
     }
+    }                                                                       // (list mode: the barrier at the top of the next unit keeps nyq until every thread is through)
 }
 
 #define INST_512(MT, ULA, T) template __global__ void k_stft_phat_512<MT, ULA, T>(StftPhatArgs);

@@ -56,6 +56,41 @@ def test_adaptive_matches_oracle(force_small, xs, step, S, thetas):
     ctx.close()
 
 
+IRR5 = [0.0, 0.028, 0.071, 0.102, 0.155]
+
+
+@pytest.mark.parametrize("fs,N", [(96000, 2048), (16000, 512)])
+@pytest.mark.parametrize("name,xs,step,tau_scale", [("ULA8", synth.ULA8, 0.5, "1"), ("ULA8-wide-margin", synth.ULA8, 0.5, "30"), ("REEMC", synth.REEM_C, 5.0, "1"),
+                                                     ("IRR5", IRR5, 1.0, "40")])
+def test_adaptive_at_other_frame_lengths_matches_the_oracle(monkeypatch, name, xs, step, tau_scale, fs, N):
+    """Round 6: the adaptive mode on 2048- and 512-sample frames (k_stft_phat_2048 / k_stft_phat_512: coarse one-plane rows for every
+    frame, their list mode for the exact rows of the repair units; 3 ... 8 microphones) -- before, such contexts ran ADAPTIVE as plain
+    FP16X3.  One source and two sources of equal strength per array (near ties: content flags; the wide decision margin flags many
+    more), two calls (the state handed over must be the exact one), bins against the oracle at the tie rule of the exact paths."""
+    monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "128")
+    monkeypatch.setenv("MCA_HIP_ADAPT_TAU_SCALE", tau_scale)
+    hop, F, cut, A = N // 2, 150, 72, 2
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(37.0), fs, (F + 1) * hop, 700, snr_db=15.0),
+                    0.5 * synth.noise_source_stream(xs, np.deg2rad(-52.0), fs, (F + 1) * hop, 701, snr_db=10.0) +
+                    0.5 * synth.noise_source_stream(xs, np.deg2rad(18.0), fs, (F + 1) * hop, 702, snr_db=10.0)]).astype(np.float32)
+    ctx = api.Context(fs, xs, N, step, 1, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+    ctx.reset_timing()
+    ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * hop], want_energy=True)
+    rb = ctx.process_frames_host(pcm[:, :, cut * hop:], want_energy=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out")}
+    st = ctx.repair_stats()
+    assert st["frames"] == A * F and st["flagged"] >= 2 * A and st["recomputed"] >= st["flagged"], st      # (the mode ran: every call repairs its own last rows)
+    if name == "ULA8-wide-margin":
+        assert st["flagged"] > 4 * A + 10, st                                                               # ... and content flags with the wide margin
+    from parity_helpers import assert_audio_where_bins_agree
+    for a in range(A):
+        o = po.ssl_stream(fs, N, xs, pcm[a].astype(np.float64), 1, step, want_map=True)
+        _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=3)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= 2e-4 * np.abs(o["energy"]).max()      # fp16-level map on unrepaired frames
+        assert_audio_where_bins_agree(r["out"][a][:o["out"].shape[0]], o["out"], r["bin"][a], o["bin"], hop)
+    ctx.close()
+
+
 def test_sixteen_microphones_two_work_lists_match_the_oracle(force_small, monkeypatch):
     """Round 6 (k_scan_pick<PL, 2>): a 16-microphone context sends the flagged frames that take whole rows by construction (the last
     frame of every array and call: eager tails; unsure rows) to k_srp_gemm_repair + k_repair_patch and every other flagged frame to

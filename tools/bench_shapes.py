@@ -16,10 +16,10 @@ def run(M, fs, N, step, A, F, prec=api.SRP_FP16X3, S=1, steps=10, gate=False, so
     dev = torch.device("cuda", 0)
     hop = N // 2
     g = torch.Generator(device=dev); g.manual_seed(1)
-    if sources:         # S far-field white sources per array (bench.py's generator, 48 kHz / 1024 only) instead of noise alone
+    if sources:         # S far-field white sources per array (bench.py's generator) instead of noise alone
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
-        pcm = sum(bench.synth_batch(xs, [1000 * s_ + a for a in range(A)], F, dev)[0] for s_ in range(S))[:, :, :(F + 1) * hop].contiguous()
+        pcm = sum(bench.synth_batch(xs, [1000 * s_ + a for a in range(A)], F, dev, hop=hop, fs=fs)[0] for s_ in range(S))[:, :, :(F + 1) * hop].contiguous()
     else:
         pcm = (torch.randn(A, M, (F + 1) * hop, device=dev, generator=g) * 0.1).contiguous()
     ctx = api.Context(fs, xs, N, step, S, srp_precision=prec, max_arrays=A, use_power_floor=gate)
@@ -74,6 +74,21 @@ if __name__ == "__main__":
         run(8, 96000, 2048, 0.5, 8, 2048, steps=30)
         run(8, 96000, 2048, 0.5, 8, 2048, prec=api.SRP_FP16, steps=30)
         run(4, 96000, 2048, 0.5, 8, 2048, steps=30)
+        # one far-field source per array: the exact split and the adaptive mode (round 6: coarse + repair at this frame length too)
+        for M in (8, 4):
+            run(M, 96000, 2048, 0.5, 8, 2048, sources=True, steps=30)
+            run(M, 96000, 2048, 0.5, 8, 2048, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n512":        # 512-sample frames at 16 kHz, one far-field source per array: the exact split and the adaptive mode
+        for M in (8, 4):
+            run(M, 16000, 512, 0.5, 8, 4096, sources=True, steps=30)
+            run(M, 16000, 512, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n2048a":      # the 8-microphone 2048-sample call alone (under rocprofv3: PMC_CMD of tools/pmc_sq.sh)
+        run(8, 96000, 2048, 0.5, 8, 2048, steps=5)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n2048b":      # ... and its adaptive call on one source per array (under rocprofv3 --kernel-trace --stats)
+        run(8, 96000, 2048, 0.5, 8, 2048, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gate":          # the reference's default usePowerFloor, in the bench's precision
         for gate in (False, True):

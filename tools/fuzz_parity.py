@@ -1,7 +1,8 @@
 """Randomised parity sweep of the stream API against the CPU oracle (a one-off check, not part of the test suite):
 random channel counts, geometries, frame lengths, frame counts, DOA grids, source counts, SRP precisions, chunked calls.
-usage (GPU box): python tools/fuzz_parity.py [cases] [seed] [fp32|fp16x3|fp16|adaptive|lazy]
-(lazy: 4 / 8 microphones through the device-pointer entry point in several calls per stream -- the form lazy tails apply to)"""
+usage (GPU box): python tools/fuzz_parity.py [cases] [seed] [fp32|fp16x3|fp16|adaptive|lazy|adaptive-n]
+(lazy: 4 / 8 microphones through the device-pointer entry point in several calls per stream -- the form lazy tails apply to;
+adaptive-n: the adaptive path at 512- and 2048-sample frames, 3 ... 8 microphones, a random decision margin)"""
 import os
 import sys
 
@@ -76,7 +77,7 @@ def dev_stream(ctx, pcm, sizes, hop, S):
     return {k: np.concatenate(v, axis=2 if k == "out" else 1) for k, v in parts.items()}
 
 
-def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False):
+def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False, other_n=False):
     rng = np.random.default_rng(seed)
     bad = 0
     n_adaptive = n_ties = n_abs = 0
@@ -97,6 +98,13 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False):
             M = int(rng.choice([3, 3, 4, 5, 8, 8, 16]))
             xs = (0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))
             fs, N, gate, F = 48000, 1024, False, int(rng.integers(64, 200))
+        if other_n:                                                  # round 6: coarse + repair on the 512- and 2048-sample analysis kernels
+            M = int(rng.choice([3, 4, 4, 5, 7, 8, 8]))
+            xs = (0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))
+            fs, N = [(16000, 512), (96000, 2048)][int(rng.integers(0, 2))]
+            F = int(rng.integers(64, 200 if N == 512 else 130))
+            S = 1 if rng.integers(0, 3) else int(rng.integers(2, 4))
+            os.environ["MCA_HIP_ADAPT_TAU_SCALE"] = str(int(rng.choice([1, 1, 10, 40])))
         sizes = None
         if lazy:                                                     # lazy tails: 4 / 8 microphones, device pointers, calls of >= 64 frames (and a short one now and then)
             M = int(rng.choice([4, 8, 8]))
@@ -205,6 +213,7 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False):
 
 
 if __name__ == "__main__":
-    only = {"fp32": api.SRP_FP32, "fp16x3": api.SRP_FP16X3, "fp16": api.SRP_FP16, "adaptive": api.SRP_ADAPTIVE, "lazy": api.SRP_ADAPTIVE}.get(sys.argv[3]) if len(sys.argv) > 3 else None
+    only = {"fp32": api.SRP_FP32, "fp16x3": api.SRP_FP16X3, "fp16": api.SRP_FP16, "adaptive": api.SRP_ADAPTIVE, "lazy": api.SRP_ADAPTIVE,
+            "adaptive-n": api.SRP_ADAPTIVE}.get(sys.argv[3]) if len(sys.argv) > 3 else None
     sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1, only, len(sys.argv) > 4,
-                       lazy=len(sys.argv) > 3 and sys.argv[3] == "lazy") else 0)
+                       lazy=len(sys.argv) > 3 and sys.argv[3] == "lazy", other_n=len(sys.argv) > 3 and sys.argv[3] == "adaptive-n") else 0)

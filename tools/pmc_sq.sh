@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of every mca:: kernel (rocprofv3 PMC, two passes of up to 8 counters, --kernel-trace only).
 # usage: tools/pmc_sq.sh <precision> <outdir> ["more bench.py flags", e.g. "--config mvdr"]
+#        PMC_CMD="python3 tools/bench_shapes.py n2048" tools/pmc_sq.sh n2048 <outdir>     (another program under the same passes; <precision> only names the file)
 # Also keeps every kernel's average duration UNDER the counters of pass 1 (kernel trace of the same run): SQ_BUSY_CYCLES / 32 / duration is
 # the shader clock the issue-rate roofline of bench.py is priced with.
 prec=${1:-fp16x3}; out=${2:-gpurun_out/pmc_sq}; extra=${3:-}
@@ -11,7 +12,7 @@ P2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WA
 i=0
 for set in "$P1" "$P2"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --single-stream 0 --extras 0 --precision $prec $extra > $out/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- ${PMC_CMD:-python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --single-stream 0 --extras 0 --precision $prec $extra} > $out/p$i.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json
