@@ -404,7 +404,8 @@ int cur_kp(const mca_hip_ctx *c) { return (c->merged && c->a_planes == 1) ? c->K
 int build_merged_tables(mca_hip_ctx *c)
 {
     c->merged = false;
-    if (!c->ula || c->generic || c->n512 || (c->M != 4 && c->M != 8) || c->Dp % 64 != 0 || c->kn.no_merge || c->kn.stft_wg) return MCA_HIP_OK;
+    // (round 6: also at 2048-sample frames, k_stft_phat_2048<..., MERGE>)
+    if (!c->ula || (c->generic && !c->n2048) || c->n512 || (c->M != 4 && c->M != 8) || c->Dp % 64 != 0 || c->kn.no_merge || c->kn.stft_wg) return MCA_HIP_OK;
     if (c->prec != MCA_HIP_SRP_ADAPTIVE && c->prec != MCA_HIP_SRP_FP16) return MCA_HIP_OK;
     const int K = c->K, D = c->D, Dp = c->Dp, G = c->G;
     const double N = 2.0 * (K - 1);
@@ -492,7 +493,7 @@ GemmPlan plan_gemm(const mca_hip_ctx *c, long long rows)
         // quarters where the contraction is deep (round 5: 16 microphones, 15 392 terms per row -- 16 384 rows were 128 workgroups on half
         // the CUs: 0.280 -> 0.183 ms + 0.021 for k_sum_planes, which folds the four partial maps before the scan; with the 3 968 merged terms
         // of 8 microphones the fold costs what the quarters save: 75 -> 54 + 22 us, profiles/r05_gemm_ksplit4.log)
-        g.ksplit = rows >= 65536 ? 1 : (rows >= 32768 || c->kn.gemm_ks2 || cur_kp(c) < 8192 ? 2 : 4);
+        g.ksplit = rows >= 65536 ? 1 : (rows >= 32768 || c->kn.gemm_ks2 || cur_kp(c) < 6144 ? 2 : 4);      // (6144: the merged rows of 2048-sample frames, 7 936 deep, take quarters)
     } else {
         // 128 x 192 tiles: small batches (a single stream) would leave most CUs idle and walk the whole K range
         // in a handful of workgroups (0.29 ms however few frames); split K until ~512 workgroups exist, keeping
@@ -855,10 +856,24 @@ int launch_stft_2048(mca_hip_ctx *c, const StftPhatArgs &a, dim3 grid, hipStream
     const size_t smem6 = ((size_t)fp * mr * 1026 + F1K_TWORDS + 8 * F1K_SCRATCH + (size_t)sa.fpb * c->M) * sizeof(float2) + (size_t)sa.fpb * 8 * sizeof(float);
 #define L2048(MT, U)                                                                                                      \
     do {                                                                                                                  \
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_2048<MT, U, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem6)); \
-        hipLaunchKernelGGL((k_stft_phat_2048<MT, U, OutT>), grid, dim3(512), smem6, st, sa);                              \
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_2048<MT, U, OutT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem6)); \
+        hipLaunchKernelGGL((k_stft_phat_2048<MT, U, OutT, false>), grid, dim3(512), smem6, st, sa);                              \
     } while (0)
-    if (c->M == 8 && c->ula) L2048(8, true); else if (c->M == 8) L2048(8, false);
+    bool done = false;
+    if constexpr (sizeof(OutT) == 2) {
+        if (sa.mrank && sa.a_planes == 1 && !sa.list && c->ula && (c->M == 8 || c->M == 4)) {      // merged contraction index: ULA, one plane
+            if (c->M == 8) {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_2048<8, true, _Float16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem6));
+                hipLaunchKernelGGL((k_stft_phat_2048<8, true, _Float16, true>), grid, dim3(512), smem6, st, sa);
+            } else {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stft_phat_2048<4, true, _Float16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem6));
+                hipLaunchKernelGGL((k_stft_phat_2048<4, true, _Float16, true>), grid, dim3(512), smem6, st, sa);
+            }
+            done = true;
+        }
+    }
+    if (done) { }
+    else if (c->M == 8 && c->ula) L2048(8, true); else if (c->M == 8) L2048(8, false);
     else if (c->M == 4 && c->ula) L2048(4, true); else if (c->M == 4) L2048(4, false);
     else if (c->ula) L2048(0, true); else L2048(0, false);
 #undef L2048

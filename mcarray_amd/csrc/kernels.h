@@ -25,7 +25,7 @@ __global__ void k_beamform_gen(BeamformArgs p);
 __global__ void k_bf_table(float2 *tab, const float *grid, const double *mic_x, int M, int n_pairs, double unit);
 template <bool ODD, int VAR, int ABL> __global__ void k_beamform_wave(BeamformWaveArgs p);
 template <bool POWER> __global__ void k_stft_phat_wave16(StftPhatArgs p);   // 16-microphone ULA, one fp16 plane
-template <int MT, bool ULA, typename OutT> __global__ void k_stft_phat_2048(StftPhatArgs p);   // 2048-sample frames, M <= 8 (kernels_2048.hip)
+template <int MT, bool ULA, typename OutT, bool MERGE = false> __global__ void k_stft_phat_2048(StftPhatArgs p);   // 2048-sample frames, M <= 8 (kernels_2048.hip)
 __global__ void k_bf_table_2048(float2 *tab, const float *grid, const double *mic_x, int M, double unit);
 __global__ void k_beamform_wave_2048(BeamformWaveArgs p);
 template <int NPT, bool ODD> __global__ void k_beamform_wave_ms(BeamformWaveArgs p);   // several sources, forward transforms shared (M <= 8)

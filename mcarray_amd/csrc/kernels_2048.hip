@@ -78,9 +78,20 @@ __device__ __forceinline__ void split_twiddles(float2 (&wk)[8], int lam)
 // of a frame stays in registers as the first half of the next.
 // LDS: spectra FP x M rows | twiddle table | 8 transform scratches | [fpb][M] Nyquist bins | [fpb][8] power partials.
 // --------------------------------------------------------------------------------------
-template <int MT, bool ULA, typename OutT>
+// MERGE (ULA of 4 / 8 microphones, one fp16 plane: the ADAPTIVE coarse pass, plain FP16): the contraction index is the product m = k (j - i)
+// -- all (bin, spacing) combinations of equal product share one steering column (api.hip, build_merged_tables) -- so their PHAT sums are added
+// up before the row is stored: 3 924 complex values per row instead of 7 x 1 025.  The 512 threads add their 2 x (M - 1) sums into ONE region
+// per frame slot with ds_add_u32 on 2^26 fixed point (|sum| <= 28: 31 bits; the step 1.5e-8 is four decades below the fp16 rounding the row
+// gets anyway), so the order in which the waves arrive does not matter: the row is the same bits every run.  The region lies on the
+// transforms' scratches (idle during the pair stage); every wave zeroes its own scratch after its transform.
+constexpr float MERGE_SCALE = 67108864.f, MERGE_UNSCALE = 1.f / 67108864.f;
+// (the LDS atomics are what the merged stage costs -- +50 us per 16 384 frames against -68 us of contraction, profiles/r06_ab_merge_2048.log; one
+// ds_add_u64 per complex addend, re + 2^32 im, measured slower than the two 32-bit ones: 0.430 against 0.415 ms)
+
+template <int MT, bool ULA, typename OutT, bool MERGE>
 __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
 {
+    static_assert(!MERGE || (ULA && (MT == 4 || MT == 8) && sizeof(OutT) == 2), "the merged index serves the one-plane fp16 rows of a 4 / 8 microphone ULA");
     constexpr int FP = MT == 4 ? 2 : 1;                                   // frames per pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int M = MT > 0 ? MT : p.M;
@@ -102,6 +113,17 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
 #pragma unroll
     for (int i = 0; i < 16; ++i) win[i] = reinterpret_cast<const float2 *>(p.window)[lane + 64 * i];     // (w[2n], w[2n+1]), n = lane + 64 i
     for (int e = tid; e < p.fpb * 8; e += 512) spow[e] = 0.f;
+    // MERGE: the region offsets of the thread's products k g (k = tid, tid + 512; g = 1 .. M - 1) and, threads 0 .. M - 2, of the Nyquist bin's
+    const int nmp = MERGE ? (p.n_merged + 63) & ~63 : 0;
+    int *msum = reinterpret_cast<int *>(scr);                             // [FP][2][nmp]: real parts | imaginary parts
+    unsigned short rk[2][MT > 1 ? MT - 1 : 1], rkn = 0;
+    if constexpr (MERGE) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < MT - 1; ++g) rk[h][g] = p.mrank[(tid + 512 * h) * (g + 1)];
+        if (tid < MT - 1) rkn = p.mrank[H2K * (tid + 1)];
+    }
     // list mode (the repair pass of the adaptive SRP precision, as in k_stft_phat): the workgroups walk the listed units of REPAIR_GROUP
     // frames; unit number li - list0 of the pass writes the A rows (li - list0) * REPAIR_GROUP ...  Otherwise one run of fpb frames.
     const int li_end = p.list ? min(*p.n_list, p.list0 + p.list_cap) : 1, li_step = p.list ? (int)gridDim.x : 1;
@@ -156,6 +178,12 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
             }
             if (lane == 0) row[512] = make_float2(z512.x, -z512.y);              // X[512] = conj Z[512]
         }
+        if constexpr (MERGE) {
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < F1K_SCRATCH / 64; ++i)
+                if (wave * F1K_SCRATCH + 64 * i < FP * nmp) scr[wave * F1K_SCRATCH + lane + 64 * i] = make_float2(0.f, 0.f);     // (the region's words only)
+        }
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < FP; ++sl) {
@@ -163,7 +191,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
             if (fr < f_end) {
                 const float2 *xs = spec + sl * MR * ROW2K;
                 OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + fr) * (long long)p.a_row_elems;
-                if (tid < M) nyq[(fr - f_begin) * M + tid] = whiten(xs[tid * ROW2K + H2K]);
+                if (tid < M) nyq[(MERGE ? 0 : (fr - f_begin) * M) + tid] = whiten(xs[tid * ROW2K + H2K]);
                 if (p.power) {
                     // dsp::SignalPower::FFTPower [INFERRED, SURVEY A.8]: (1/N^2) sum_k w_k |X[k]|^2, w = 2 except DC and Nyquist
                     float acc = 0.f, acc2 = 0.f;
@@ -177,6 +205,34 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
                     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
                     if (lane == 0) spow[(fr - f_begin) * 8 + wave] = acc;         // (one slot per wave, summed in wave order below)
                 }
+                if constexpr (MERGE) {
+                    int *ms = msum + sl * nmp * 2;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float2 r[MT], out[MT - 1];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) r[m] = whiten(xs[m * ROW2K + tid + 512 * h]);
+                        pair_products<MT, true>(r, out);
+#pragma unroll
+                        for (int g = 0; g < MT - 1; ++g) {               // (real parts | imaginary parts: an instruction's 64 words spread over all banks)
+                            atomicAdd(ms + rk[h][g], __float2int_rn(out[g].x * MERGE_SCALE));
+                            atomicAdd(ms + nmp + rk[h][g], __float2int_rn(out[g].y * MERGE_SCALE));
+                        }
+                    }
+                    if (tid < MT - 1) {                                   // the Nyquist bin: spacing tid + 1 (its whitened values were written by this wave)
+                        wave_lds_fence();
+                        float2 acc = make_float2(0.f, 0.f);
+                        for (int i = 0; i + tid + 1 < MT; ++i) acc = cmacc(acc, nyq[i], nyq[i + tid + 1]);
+                        atomicAdd(ms + rkn, __float2int_rn(acc.x * MERGE_SCALE));
+                        atomicAdd(ms + nmp + rkn, __float2int_rn(acc.y * MERGE_SCALE));
+                    }
+                    __syncthreads();
+                    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                    h2v *arow2 = reinterpret_cast<h2v *>(arow);
+                    for (int r = tid; r < nmp; r += 512) {
+                        arow2[r] = h2v{(_Float16)((float)ms[r] * MERGE_UNSCALE), (_Float16)((float)ms[nmp + r] * MERGE_UNSCALE)};
+                    }
+                } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int k = tid + 512 * h;
@@ -186,6 +242,7 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
                     }
                     pair_stage<MT, ULA, true, OutT>(xs + k, ROW2K, M, arow, p, k, K2K);
                 }
+                }
             }
         }
         __syncthreads();
@@ -194,16 +251,18 @@ __global__ __launch_bounds__(512) void k_stft_phat_2048(StftPhatArgs p)
         const float *s = spow + tid * 8;
         p.power[(long long)a * p.total_frames + p.frame0 + f_begin + tid] = (((((((s[0] + s[1]) + s[2]) + s[3]) + s[4]) + s[5]) + s[6]) + s[7]) / ((float)N2K * (float)N2K) / (float)M;
     }
-    if (tid < f_end - f_begin) {
+    if (!MERGE && tid < f_end - f_begin) {
         OutT *arow = reinterpret_cast<OutT *>(p.A) + (row_base + f_begin + tid) * (long long)p.a_row_elems;
         pair_stage<MT, ULA, false, OutT>(nyq + tid * M, 1, M, arow, p, H2K, K2K);
     }
     }                                                                     // (list mode: the barrier at the top of the next unit keeps nyq until every thread is through)
 }
 
-#define INST_2048(MT, ULA, T) template __global__ void k_stft_phat_2048<MT, ULA, T>(StftPhatArgs);
+#define INST_2048(MT, ULA, T) template __global__ void k_stft_phat_2048<MT, ULA, T, false>(StftPhatArgs);
 INST_2048(0, false, float) INST_2048(0, true, float) INST_2048(4, false, float) INST_2048(4, true, float) INST_2048(8, false, float) INST_2048(8, true, float)
 INST_2048(0, false, _Float16) INST_2048(0, true, _Float16) INST_2048(4, false, _Float16) INST_2048(4, true, _Float16) INST_2048(8, false, _Float16) INST_2048(8, true, _Float16)
+template __global__ void k_stft_phat_2048<4, true, _Float16, true>(StftPhatArgs);
+template __global__ void k_stft_phat_2048<8, true, _Float16, true>(StftPhatArgs);
 
 // --------------------------------------------------------------------------------------
 // k_bf_table_2048: grid (D + 1, M) x 256.  Row 0: DOA = 0 rad (the module's initial _currentDOA, BeamformingSeparationAndLocalisation.cpp:51),

@@ -90,6 +90,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "n2048b":      # ... and its adaptive call on one source per array (under rocprofv3 --kernel-trace --stats)
         run(8, 96000, 2048, 0.5, 8, 2048, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n2048c":      # ... of 8 and of 4 microphones, adaptive and plain fp16 (tools/ab_merge_2048.sh)
+        for M in (8, 4):
+            run(M, 96000, 2048, 0.5, 8, 2048, prec=api.SRP_ADAPTIVE, sources=True, steps=30)
+            run(M, 96000, 2048, 0.5, 8, 2048, prec=api.SRP_FP16, sources=True, steps=30)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gate":          # the reference's default usePowerFloor, in the bench's precision
         for gate in (False, True):
             run(8, 48000, 1024, 0.5, 8, 4096, prec=api.SRP_ADAPTIVE, gate=gate, steps=30)
