@@ -119,6 +119,26 @@ def test_2048_sample_frames_on_the_wave_level_transform(name, xs, S, step, prec)
     assert np.abs(g["energy"] - r["energy"]).max() <= (4e-6 if prec != api.SRP_FP16 else 2e-4) * np.abs(r["energy"]).max()
 
 
+def test_2048_merged_rows_are_the_same_bits_every_run():
+    """Round 6: the one-plane rows of an 8-microphone ULA at 2048-sample frames are stored on the merged index (k_stft_phat_2048<..., MERGE>):
+    512 threads add their PHAT sums into one LDS region per frame with integer atomics (2^26 fixed point), so the result does not depend
+    on the order the waves arrive in -- the energies of three runs over the same stream (fresh state each time) are bit-identical, and so
+    are those of a second context."""
+    fs, N, hop, F, A = 96000, 2048, 1024, 96, 4
+    xs = synth.ULA8
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(-65.0 + 40.0 * a), fs, (F + 1) * hop, 400 + a, snr_db=12.0) for a in range(A)]).astype(np.float32)
+    runs = []
+    for rep in range(2):
+        ctx = api.Context(fs, xs, N, 0.5, 1, srp_precision=api.SRP_FP16, max_arrays=A)
+        for _ in range(3 if rep == 0 else 1):
+            ctx.reset()
+            r = ctx.process_frames_host(pcm, want_energy=True)
+            runs.append((r["energy"].copy(), r["bin"].copy()))
+        ctx.close()
+    for e, b in runs[1:]:
+        assert np.array_equal(e.view(np.uint32), runs[0][0].view(np.uint32)) and np.array_equal(b, runs[0][1])
+
+
 def test_2048_sample_frames_power_gate():
     """the gate on the 2048-sample analysis (FFTPower from the spectra in LDS; 3 s at 96 kHz = 141 frames of 2048 samples)"""
     fs, N, F = 96000, 2048, 230

@@ -3,7 +3,8 @@
 IDENTICAL (the adaptive mode recomputes exactly the frames whose pick is sensitive to the fp16 error); reports the flips of
 the plain fp16 mode on the same data, the flagged / recomputed fractions, and how the measured fp16 error of the normalised
 energy compares with the decision margin tau the sensitivity test assumes.
-usage (GPU box): python tools/adaptive_check.py [cases] [seed] > profiles/rNN_adaptive_check.json"""
+usage (GPU box): python tools/adaptive_check.py [cases] [seed] > profiles/rNN_adaptive_check.json
+(MCA_CHECK_N=2048 MCA_CHECK_FS=96000, or 512 / 16000: the same check on the other frame lengths the mode applies to, 3 ... 8 microphones)"""
 import os
 os.environ.setdefault("MCA_HIP_ADAPT_FALLBACK", "0")      # the check is about coarse + repair itself: no backing off to FP16X3
 os.environ.setdefault("MCA_HIP_ADAPT_MAX_SOURCES", "4")   # ... with any number of sources
@@ -17,7 +18,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcarray_amd import api  # noqa: E402
 
-FS, N, HOP = 48000, 1024, 512
+N = int(os.environ.get("MCA_CHECK_N", "1024"))
+FS, HOP = int(os.environ.get("MCA_CHECK_FS", "48000")), N // 2
 
 
 def synth(xs, n_arrays, n_frames, kind, rng, dev):
@@ -98,13 +100,13 @@ def main(cases, seed):
     tot = dict(frames=0, adaptive_flips=0, fp16_flips=0, flagged=0, recomputed=0, frames_differing=0, of_which_exact_level_ties=0)
     worst_margin = 0.0
     for case in range(cases):
-        M = int(rng.choice([3, 4, 5, 8, 8, 8, 16]))
+        M = int(rng.choice([3, 4, 5, 8, 8, 8, 16] if N == 1024 else [3, 4, 5, 8, 8, 8, 7]))
         ula = bool(rng.integers(0, 2))
         xs = ((0.02 + 0.03 * rng.random()) * np.arange(M) if ula else np.sort(rng.uniform(0, 0.05 * M, M))).tolist()
         step = float(rng.choice([0.5, 0.5, 1.0, 3.0, 5.0]))
         S = int(rng.choice([1, 1, 2, 3, 4]))
         A = int(rng.choice([4, 8]))
-        F = int(rng.choice([2048, 2304, 4096]))
+        F = int(rng.choice([2048, 2304, 4096])) * (1024 if N <= 1024 else 512) // 1024
         kind = str(rng.choice(["static", "static", "two", "noise", "moving"]))
         cut = int(rng.integers(200, F - 200)) if rng.integers(0, 2) else 0
         pcm = synth(xs, A, F, kind, rng, dev)
@@ -156,7 +158,7 @@ def main(cases, seed):
         en_err_at = float(err_f[shadow].max()) if n_undefined else 0.0
         en_err = float(err_f[~shadow].max())
         sum_n2 = sum((M - 1 - g) ** 2 for g in range(M - 1)) if ula and M > 2 else P
-        tau = 8.0 * np.sqrt(2.0) * 5.0e-4 * np.sqrt(0.5 * 513 * sum_n2) / (30.0 * P)      # as mca_hip_create
+        tau = 8.0 * np.sqrt(2.0) * 5.0e-4 * np.sqrt(0.5 * (N // 2 + 1) * sum_n2) / (30.0 * P)      # as mca_hip_create
         worst_margin = max(worst_margin, en_err / tau)
         if not fl_a:
             row_frames = 0
