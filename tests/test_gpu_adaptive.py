@@ -312,6 +312,42 @@ def test_adaptive_with_power_gate_matches_oracle(force_small):
     ctx.close()
 
 
+@pytest.mark.parametrize("fs,N,lead", [(96000, 2048, 141), (16000, 512, 94)])
+def test_adaptive_with_power_gate_at_other_frame_lengths(monkeypatch, fs, N, lead):
+    """the gated adaptive mode on the 2048- and 512-sample analysis kernels (FFTPower of the coarse launch, the planning wave's walk
+    over the voiced flags, eager tails): a quiet lead-in of 3 s, then bursts; against the oracle in two calls"""
+    monkeypatch.setenv("MCA_HIP_ADAPT_MIN_ROWS", "128")
+    hop, A, F, cut = N // 2, 2, 330, 200
+    xs = synth.ULA8
+    rng = np.random.default_rng(12)
+    pcm = np.stack([synth.noise_source_stream(xs, np.deg2rad(rng.uniform(-70, 70)), fs, (F + 1) * hop, 40 + a, snr_db=15.0) for a in range(A)])
+    env = np.full(F + 1, 0.004)
+    t = lead + 9
+    while t < F:
+        b = int(rng.integers(3, 40))
+        env[t:t + b] = 1.0
+        t += b + int(rng.integers(2, 30))
+    pcm = (pcm * np.repeat(env, hop)[None, None, :]).astype(np.float32)
+    ctx = api.Context(fs, xs, N, 0.5, 1, use_power_floor=True, srp_precision=api.SRP_ADAPTIVE, max_arrays=A)
+    ctx.reset_timing()
+    ra = ctx.process_frames_host(pcm[:, :, :(cut + 1) * hop], want_energy=True)
+    rb = ctx.process_frames_host(pcm[:, :, cut * hop:], want_energy=True)
+    r = {k: np.concatenate([ra[k], rb[k]], axis=2 if k == "out" else 1) for k in ("bin", "energy", "out", "voiced")}
+    st = ctx.repair_stats()
+    assert st["frames"] == A * F and st["flagged"] >= A, st
+    fired = 0
+    from parity_helpers import assert_audio_where_bins_agree
+    for a in range(A):
+        o = po.ssl_stream_gated(fs, N, xs, pcm[a].astype(np.float64), 1, 0.5, True)
+        assert np.array_equal(r["voiced"][a].astype(bool), o["fired"].astype(bool))
+        fired += int(o["fired"].sum())
+        _assert_bins(r["bin"][a], o["bin"], o["energy"], ctx.P, max_ties=3)
+        assert np.abs(r["energy"][a] - o["energy"]).max() <= 2e-4 * np.abs(o["energy"]).max()
+        assert_audio_where_bins_agree(r["out"][a][:o["out"].shape[0]], o["out"], r["bin"][a], o["bin"], hop)
+    assert 40 < fired < A * (F - lead)
+    ctx.close()
+
+
 def test_adaptive_with_power_gate_equals_fp16x3_at_full_size():
     from oracle import np_twin as tw
     dev = torch.device("cuda:0")

@@ -105,6 +105,8 @@ def main(cases, seed, only_prec=None, adaptive_shapes=False, lazy=False, other_n
             F = int(rng.integers(64, 200 if N == 512 else 130))
             S = 1 if rng.integers(0, 3) else int(rng.integers(2, 4))
             os.environ["MCA_HIP_ADAPT_TAU_SCALE"] = str(int(rng.choice([1, 1, 10, 40])))
+            if N == 512 and rng.integers(0, 4) == 0:                 # ... with the power gate (3 s of floor estimation = 94 frames at 16 kHz)
+                gate, F = True, int(rng.integers(150, 260))
         sizes = None
         if lazy:                                                     # lazy tails: 4 / 8 microphones, device pointers, calls of >= 64 frames (and a short one now and then)
             M = int(rng.choice([4, 8, 8]))
