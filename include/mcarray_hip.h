@@ -50,7 +50,8 @@ typedef enum {
     MCA_HIP_SRP_ADAPTIVE = 3 /* fp16 coarse scan of every frame + exact repair: the frames whose peak pick is sensitive to the
                                 fp16 error (and the rows their energy depends on) are recomputed with the FP16X3 split and
                                 picked again, so the DOA bins are those of FP16X3 at about the cost of FP16.  Applies to large
-                                batches (>= 4096 frames per call) on the 1024-sample path with more than two microphones and
+                                batches (>= 4096 frames per call) of 1024-sample frames -- and of 2048- or 512-sample frames
+                                with up to 8 microphones -- with more than two microphones and
                                 ONE source (with several, the S-th pick is a near tie too often), with or without the power
                                 gate; every other call of such a context runs as FP16X3 -- as do its calls while most rows
                                 need the repair (noise only, silence: the context backs off by itself and probes again

@@ -34,7 +34,7 @@ bash tools/pmc_sq.sh adaptive gpurun_out/pmc_sq > gpurun_out/final/pmc_sq.log 2>
 timeout 600 python tools/precision_report.py > gpurun_out/final/precision_report.json 2> gpurun_out/final/precision_report.log
 timeout 300 python tools/host_path_rate.py > gpurun_out/final/host_path.log 2>&1
 python tools/bench_fallback.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/fallback.log
-(python tools/bench_shapes.py; python tools/bench_shapes.py m16; python tools/bench_shapes.py sources; python tools/bench_shapes.py gate; python tools/bench_shapes.py n2048; echo "--- the any-length kernels at 2048-sample frames (MCA_HIP_NO_N2048=1):"; MCA_HIP_NO_N2048=1 python tools/bench_shapes.py n2048) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/shapes.log
+(python tools/bench_shapes.py; python tools/bench_shapes.py m16; python tools/bench_shapes.py sources; python tools/bench_shapes.py gate; python tools/bench_shapes.py n2048; python tools/bench_shapes.py n512; echo "--- the any-length kernels at 2048-sample frames (MCA_HIP_NO_N2048=1):"; MCA_HIP_NO_N2048=1 python tools/bench_shapes.py n2048) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/shapes.log
 timeout 300 python tools/stream_latency.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/stream_latency.log
 fi
 if [[ $PART == *c* ]]; then
